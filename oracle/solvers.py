@@ -1,0 +1,204 @@
+"""ORACLE (test infrastructure only -- never imported by the product path).
+
+Solvers over :class:`oracle.objectives.OracleProblem`:
+
+* :func:`solve_ref_as_configured` -- what the reference does per frame (optimizer.py:77-102): hand the
+  closure (value WITHOUT the norm_delta term, gradient WITH it -- quirk Q1) to SLSQP with ``ftol_abs`` =
+  1e-6 / 1e-5 and the +-1e-3 box (optimizer.py:54-60,136,239,397).  nlopt is absent, scipy's SLSQP (the same
+  Kraft routine) stands in.  This is the timed "reference CPU path" (bench.py cpu_baseline, kind "port").
+* :func:`solve_tight` -- the well-posed parity target: argmin over the same box of
+  ``F(x) = f(x) + norm_delta*||x-last||^2`` (the function whose gradient the reference supplies), driven to a
+  projected-gradient norm ~1e-10 with scipy (L-BFGS-B polish after SLSQP).  Independent of the GPU algorithm.
+* :func:`solve_lm_batched` -- float64, batched numpy statement of a projected Levenberg-Marquardt /
+  Newton iteration on F; used to check thousands of items quickly.  It is validated against solve_tight
+  in tests/test_oracle.py before anything is compared with it.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from .objectives import OracleProblem, smooth_l1
+
+
+# ----------------------------------------------------------------------------------------------
+def _per_item_kw(kw, b):
+    return {k: (v[b:b + 1] if v is not None else None) for k, v in kw.items()}
+
+
+def solve_ref_as_configured(prob: OracleProblem, ref, fixed, last, **kw):
+    """Per-item SLSQP exactly as configured by the reference.  Returns (x (B,n) float32, n_evals (B,))."""
+    from scipy.optimize import minimize
+
+    ref = np.asarray(ref)
+    B = ref.shape[0]
+    last = np.asarray(last).reshape(B, -1)
+    lo, hi = prob.bounds
+    out = np.zeros((B, prob.n_opt), dtype=np.float32)
+    evals = np.zeros(B, dtype=int)
+    for b in range(B):
+        last32 = last[b].astype(np.float32)  # optimizer.py:93
+        fx = None if fixed is None else np.asarray(fixed).reshape(B, -1)[b:b + 1]
+        cnt = [0]
+
+        def fun(x):
+            cnt[0] += 1
+            f, g, _ = prob.evaluate(x[None], ref[b:b + 1], fx, last32[None], **_per_item_kw(kw, b))
+            return float(f[0]), g[0]
+
+        x0 = np.clip(last[b].astype(np.float64), lo, hi)
+        res = minimize(fun, x0, jac=True, method="SLSQP", bounds=list(zip(lo, hi)),
+                       options=dict(ftol=prob.ftol, maxiter=200))
+        out[b] = res.x.astype(np.float32)  # optimizer.py:99
+        evals[b] = cnt[0]
+    return out, evals
+
+
+def solve_tight(prob: OracleProblem, ref, fixed, last, x0=None, **kw):
+    """Per-item tight minimisation of F with scipy.  Returns x (B,n) float64."""
+    from scipy.optimize import minimize
+
+    ref = np.asarray(ref)
+    B = ref.shape[0]
+    last = np.asarray(last).reshape(B, -1)
+    lo, hi = prob.bounds
+    out = np.zeros((B, prob.n_opt))
+    for b in range(B):
+        last32 = last[b].astype(np.float32).astype(np.float64)
+        fx = None if fixed is None else np.asarray(fixed).reshape(B, -1)[b:b + 1]
+        kb = _per_item_kw(kw, b)
+
+        def fun(x):
+            f, g, _ = prob.evaluate(x[None], ref[b:b + 1], fx, last32[None], **kb)
+            F = f[0] + prob.norm_delta * ((x - last32) ** 2).sum()
+            return float(F), g[0]
+
+        x = np.clip((last[b] if x0 is None else x0[b]).astype(np.float64), lo, hi)
+        bounds = list(zip(lo, hi))
+        res = minimize(fun, x, jac=True, method="SLSQP", bounds=bounds, options=dict(ftol=1e-15, maxiter=500))
+        res = minimize(fun, np.clip(res.x, lo, hi), jac=True, method="L-BFGS-B", bounds=bounds,
+                       options=dict(ftol=1e-16, gtol=1e-11, maxiter=2000, maxcor=30))
+        out[b] = res.x
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+def _terms(prob: OracleProblem, x, ref, fixed, kw):
+    """Residual blocks of F at x: returns (r (B,T,3), Jt (B,T,3,n), w (B,T), per_coord flag)."""
+    B = x.shape[0]
+    q = prob.full_qpos(x, fixed)
+    pos = prob.robot.link_positions(q, prob.computed_links)
+    J = prob._fold_jacobian(prob.robot.point_jacobians(q, prob.computed_links))
+    if prob.kind == "position":
+        tgt = np.asarray(ref).astype(np.float64).reshape(B, -1, 3)
+        return pos - tgt, J, np.full((B, pos.shape[1]), 1.0 / (3 * pos.shape[1])), True
+    if prob.kind == "vector":
+        rv = np.asarray(ref)
+        tgt = (rv * rv.dtype.type(prob.scaling)).astype(np.float64).reshape(B, -1, 3)
+        w = np.ones((B, prob.n_ref))
+    else:
+        tgt = np.asarray(kw["dexpilot_ref"], dtype=np.float64).reshape(B, -1, 3)
+        w = np.asarray(kw["weights"], dtype=np.float64).reshape(B, -1)
+    r = pos[:, prob.task_idx] - pos[:, prob.origin_idx] - tgt
+    Jt = J[:, prob.task_idx] - J[:, prob.origin_idx]
+    return r, Jt, w / prob.n_ref, False
+
+
+def _second_order(prob, x, fixed, force_terms):
+    """sum_t force_t . d2 r_t / dx2 in optimiser coordinates (mimic-folded): the term Gauss-Newton drops."""
+    B = x.shape[0]
+    q = prob.full_qpos(x, fixed)
+    L = len(prob.computed_links)
+    if prob.kind == "position":
+        fpos = force_terms
+    else:
+        fpos = np.zeros((B, L, 3))
+        np.add.at(fpos, (slice(None), prob.task_idx), force_terms)
+        np.add.at(fpos, (slice(None), prob.origin_idx), -force_terms)
+    Hq = prob.robot.point_hessian_contraction(q, prob.computed_links, fpos)
+    return prob._fold_jacobian(np.swapaxes(prob._fold_jacobian(Hq), 1, 2))
+
+
+def _model(prob, x, ref, fixed, last, kw, exact_loss_hessian=True, newton=False):
+    """F, gradient, Gauss-Newton (or full Newton) Hessian with the robust loss's own curvature at x."""
+    r, Jt, w, per_coord = _terms(prob, x, ref, fixed, kw)
+    beta = prob.huber_delta
+    n = x.shape[1]
+    if per_coord:
+        val, der = smooth_l1(r, beta)
+        F = (val * w[..., None]).sum((1, 2))
+        g = np.einsum("btc,btcn->bn", der * w[..., None], Jt)
+        psi = np.where(np.abs(r) < beta, 1.0 / beta, 1.0 / np.maximum(np.abs(r), 1e-30))  # IRLS majoriser
+        H = np.einsum("btc,btcn,btcm->bnm", psi * w[..., None], Jt, Jt)
+        if newton:
+            H = H + _second_order(prob, x, fixed, der * w[..., None])
+    else:
+        d = np.linalg.norm(r, axis=2)
+        val, der = smooth_l1(d, beta)
+        F = (val * w).sum(1)
+        quad = d < beta
+        psi = np.where(quad, 1.0 / beta, 1.0 / np.maximum(d, 1e-30))
+        u = np.einsum("btc,btcn->btn", r, Jt)  # J^T r
+        g = np.einsum("bt,btn->bn", psi * w, u)
+        H = np.einsum("bt,btcn,btcm->bnm", psi * w, Jt, Jt)
+        if exact_loss_hessian:  # d>=beta: Hess_r rho = (I - rr^T/d^2)/d
+            k = np.where(quad, 0.0, 1.0 / np.maximum(d, 1e-30) ** 3)
+            H = H - np.einsum("bt,btn,btm->bnm", k * w, u, u)
+        if newton:
+            H = H + _second_order(prob, x, fixed, (psi * w)[..., None] * r)
+    dx = x - last
+    F = F + prob.norm_delta * (dx * dx).sum(1)
+    g = g + 2 * prob.norm_delta * dx
+    H = H + 2 * prob.norm_delta * np.eye(n)[None]
+    return F, g, H
+
+
+def solve_lm_batched(prob: OracleProblem, ref, fixed, last, x0=None, max_iter: int = 60, tol: float = 1e-10,
+                     lam0: float = 1e-4, return_info: bool = False, newton: bool = False,
+                     exact_loss_hessian: bool = True, history=None, **kw):
+    """Projected Levenberg-Marquardt on F (float64, batched).  Returns x (B,n) [and info dict]."""
+    ref = np.asarray(ref)
+    B = ref.shape[0]
+    last = np.asarray(last).reshape(B, -1).astype(np.float32).astype(np.float64)
+    lo, hi = prob.bounds
+    x = np.clip(last.copy() if x0 is None else np.asarray(x0, dtype=np.float64).copy(), lo, hi)
+    n = x.shape[1]
+    lam = np.full(B, lam0)
+    nu = np.full(B, 2.0)
+    done = np.zeros(B, bool)
+    iters = np.zeros(B, int)
+    mk = dict(exact_loss_hessian=exact_loss_hessian, newton=newton)
+    F, g, H = _model(prob, x, ref, fixed, last, kw, **mk)
+    eye = np.eye(n)[None]
+    for it in range(max_iter):
+        act = ((x <= lo) & (g > 0)) | ((x >= hi) & (g < 0))
+        free = ~act
+        m = free[:, :, None] & free[:, None, :]
+        Hf = np.where(m, H, 0.0) + np.where(free, lam[:, None], 1.0)[:, :, None] * eye
+        gf = np.where(free, g, 0.0)
+        step = -np.linalg.solve(Hf, gf[..., None])[..., 0]
+        xt = np.clip(x + step, lo, hi)
+        s = xt - x
+        pred = -(np.einsum("bn,bn->b", g, s) + 0.5 * np.einsum("bn,bnm,bm->b", s, H, s))
+        Ft, gt, Ht = _model(prob, xt, ref, fixed, last, kw, **mk)
+        rho = (F - Ft) / np.maximum(pred, 1e-300)
+        accept = (Ft <= F) & (pred > 0) & ~done
+        small = (np.abs(s).max(1) < tol) | (pred <= 1e-18 * np.maximum(F, 1e-30))
+        upd = accept
+        x = np.where(upd[:, None], xt, x)
+        F = np.where(upd, Ft, F)
+        g = np.where(upd[:, None], gt, g)
+        H = np.where(upd[:, None, None], Ht, H)
+        fac = np.maximum(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3)
+        lam = np.where(accept, np.maximum(lam * fac, 1e-12), np.where(done, lam, lam * nu))
+        nu = np.where(accept, 2.0, np.where(done, nu, nu * 2.0))
+        iters = iters + (~done)
+        if history is not None:
+            history.append(x.copy())
+        done = done | (accept & small) | (~accept & (lam > 1e12))
+        if done.all():
+            break
+    if return_info:
+        return x, dict(iters=iters, F=F, done=done, pg=np.where(((x <= lo) & (g > 0)) | ((x >= hi) & (g < 0)), 0, g))
+    return x
