@@ -1,0 +1,76 @@
+"""Build libdexr.so (hipcc, gfx950) in-tree.  Used by __graft_entry__.build(); hipcc cross-compiles without a GPU."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(REPO, "include")
+BUILD = os.path.join(REPO, "build")
+LIB = os.path.join(HERE, "libdexr.so")
+BUCKETS = (4, 8, 16, 24, 32)
+VARIANTS = ((0, 0), (1, 0), (1, 1), (1, 2))  # (float64?, mode): f32 solve, f64 solve, f64 eval, f64 fk
+HEADERS = [os.path.join(CSRC, "dexr_kernel.hpp"), os.path.join(CSRC, "dexr_launch.hpp"),
+           os.path.join(INCLUDE, "dexr.h"), os.path.join(INCLUDE, "dexr_tables.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(BUILD, exist_ok=True)
+    hipcc = _hipcc()
+    jobs = []
+    objs = []
+    api_s, api_o = os.path.join(CSRC, "dexr_api.hip"), os.path.join(BUILD, "dexr_api.o")
+    objs.append(api_o)
+    if force or _stale(api_o, [api_s] + HEADERS):
+        jobs.append((api_s, api_o, []))
+    inst_s = os.path.join(CSRC, "dexr_inst.hip")
+    # biggest kernels first so the thread pool stays busy
+    for n in sorted(BUCKETS, reverse=True):
+        for f64, mode in VARIANTS:
+            o = os.path.join(BUILD, f"dexr_inst_{n}_{f64}_{mode}.o")
+            objs.append(o)
+            if force or _stale(o, [inst_s] + HEADERS):
+                jobs.append((inst_s, o, [f"-DDEXR_NMAX={n}", f"-DDEXR_F64={f64}", f"-DDEXR_MODE={mode}"]))
+
+    def compile_one(job):
+        s, o, defs = job
+        cmd = [hipcc] + FLAGS + defs + ["-c", s, "-o", o]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {s}:\n{r.stderr[-4000:]}")
+        if verbose:
+            print("compiled", os.path.basename(o), file=sys.stderr)
+        return o
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(compile_one, jobs))
+    if force or jobs or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

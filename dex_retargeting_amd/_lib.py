@@ -1,0 +1,162 @@
+"""ctypes binding of libdexr.so (include/dexr.h).  Fails loudly when the HIP library is missing: there is no
+CPU fallback anywhere in this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdexr.so")
+
+_lib: Optional[C.CDLL] = None
+
+
+class DexrError(RuntimeError):
+    pass
+
+
+class SolveOptions(C.Structure):
+    _fields_ = [("max_iter", C.c_int32), ("tol", C.c_float), ("lambda0", C.c_float), ("newton", C.c_int32),
+                ("precision", C.c_int32)]
+
+
+EXPORTS = ["dexr_last_error", "dexr_version", "dexr_device_count", "dexr_default_options", "dexr_model_create",
+           "dexr_model_destroy", "dexr_model_info", "dexr_retarget_dev", "dexr_retarget", "dexr_retarget_f64",
+           "dexr_eval", "dexr_fk"]
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DexrError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950). dex_retargeting_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i64, f32p, u32p, i32p, f64p = C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_uint32), \
+        C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    optp = C.POINTER(SolveOptions)
+    lib.dexr_last_error.restype = C.c_char_p
+    lib.dexr_version.restype = C.c_char_p
+    lib.dexr_device_count.restype = C.c_int
+    lib.dexr_default_options.argtypes = [optp]
+    lib.dexr_default_options.restype = None
+    lib.dexr_model_create.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(vp)]
+    lib.dexr_model_destroy.argtypes = [vp]
+    lib.dexr_model_destroy.restype = None
+    lib.dexr_model_info.argtypes = [vp, C.c_void_p]
+    lib.dexr_retarget_dev.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, optp, vp]
+    lib.dexr_retarget.argtypes = [vp, i64, f32p, f32p, f32p, u32p, f32p, i32p, i32p, f32p, optp]
+    lib.dexr_retarget_f64.argtypes = [vp, i64, f32p, f32p, f32p, u32p, f64p, i32p, i32p, optp]
+    lib.dexr_eval.argtypes = [vp, i64, f32p, f32p, f32p, f64p, u32p, f64p, f64p]
+    lib.dexr_fk.argtypes = [vp, i64, f64p, f64p]
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise DexrError(f"libdexr error {rc}: {load().dexr_last_error().decode()}")
+
+
+def default_options(**kw) -> SolveOptions:
+    o = SolveOptions()
+    load().dexr_default_options(C.byref(o))
+    for k, v in kw.items():
+        if v is not None:
+            setattr(o, k, v)
+    return o
+
+
+def _ptr(a: Optional[np.ndarray], ctype):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+class Model:
+    """Owns one dexr_model (compiled tables resident in HBM)."""
+
+    def __init__(self, blob: bytes):
+        lib = load()
+        self._h = C.c_void_p()
+        buf = C.create_string_buffer(blob, len(blob))
+        check(lib.dexr_model_create(buf, len(blob), C.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value and _lib is not None:
+            _lib.dexr_model_destroy(h)
+            self._h = None
+
+    @property
+    def handle(self) -> C.c_void_p:
+        return self._h
+
+    # host-pointer entry points -------------------------------------------------------------------
+    def retarget(self, ref, fixed, last, state=None, opts: Optional[SolveOptions] = None, want_info=False):
+        lib = load()
+        ref = np.ascontiguousarray(ref, dtype=np.float32)
+        last = np.ascontiguousarray(last, dtype=np.float32)
+        B = last.shape[0]
+        fixed = None if fixed is None or fixed.size == 0 else np.ascontiguousarray(fixed, dtype=np.float32)
+        q = np.empty_like(last)
+        status = np.zeros(B, dtype=np.int32)
+        iters = np.zeros(B, dtype=np.int32)
+        fval = np.zeros(B, dtype=np.float32)
+        check(lib.dexr_retarget(self._h, B, _ptr(ref, C.c_float), _ptr(fixed, C.c_float), _ptr(last, C.c_float),
+                                _ptr(state, C.c_uint32), _ptr(q, C.c_float), _ptr(status, C.c_int32),
+                                _ptr(iters, C.c_int32), _ptr(fval, C.c_float),
+                                C.byref(opts) if opts is not None else None))
+        if want_info:
+            return q, dict(status=status, iters=iters, fval=fval)
+        return q
+
+    def retarget_f64(self, ref, fixed, last, state=None, opts: Optional[SolveOptions] = None, want_info=False):
+        lib = load()
+        ref = np.ascontiguousarray(ref, dtype=np.float32)
+        last = np.ascontiguousarray(last, dtype=np.float32)
+        B = last.shape[0]
+        fixed = None if fixed is None or fixed.size == 0 else np.ascontiguousarray(fixed, dtype=np.float32)
+        q = np.empty(last.shape, dtype=np.float64)
+        status = np.zeros(B, dtype=np.int32)
+        iters = np.zeros(B, dtype=np.int32)
+        check(lib.dexr_retarget_f64(self._h, B, _ptr(ref, C.c_float), _ptr(fixed, C.c_float), _ptr(last, C.c_float),
+                                    _ptr(state, C.c_uint32), _ptr(q, C.c_double), _ptr(status, C.c_int32),
+                                    _ptr(iters, C.c_int32), C.byref(opts) if opts is not None else None))
+        if want_info:
+            return q, dict(status=status, iters=iters)
+        return q
+
+    def eval(self, ref, fixed, last, x, state=None):
+        lib = load()
+        ref = np.ascontiguousarray(ref, dtype=np.float32)
+        last = np.ascontiguousarray(last, dtype=np.float32)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        B = x.shape[0]
+        fixed = None if fixed is None or fixed.size == 0 else np.ascontiguousarray(fixed, dtype=np.float32)
+        f = np.zeros(B, dtype=np.float64)
+        g = np.zeros_like(x)
+        check(lib.dexr_eval(self._h, B, _ptr(ref, C.c_float), _ptr(fixed, C.c_float), _ptr(last, C.c_float),
+                            _ptr(x, C.c_double), _ptr(state, C.c_uint32), _ptr(f, C.c_double), _ptr(g, C.c_double)))
+        return f, g
+
+    def fk(self, q, n_links: int):
+        lib = load()
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        B = q.shape[0]
+        out = np.zeros((B, n_links, 3), dtype=np.float64)
+        check(lib.dexr_fk(self._h, B, _ptr(q, C.c_double), _ptr(out, C.c_double)))
+        return out
+
+    # device-pointer entry point (torch tensors on the current device) ------------------------------
+    def retarget_dev(self, B: int, ref_ptr: int, fixed_ptr: int, last_ptr: int, state_ptr: int, q_ptr: int,
+                     status_ptr: int = 0, iters_ptr: int = 0, fval_ptr: int = 0,
+                     opts: Optional[SolveOptions] = None, stream: int = 0):
+        check(load().dexr_retarget_dev(self._h, B, ref_ptr or None, fixed_ptr or None, last_ptr or None,
+                                       state_ptr or None, q_ptr or None, status_ptr or None, iters_ptr or None,
+                                       fval_ptr or None, C.byref(opts) if opts is not None else None,
+                                       stream or None))

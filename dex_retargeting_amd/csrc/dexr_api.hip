@@ -1,0 +1,386 @@
+// dexr_api.hip -- C ABI of libdexr.so (see include/dexr.h): table loading, launch geometry, host-pointer
+// convenience wrappers.  No torch, no exceptions across the boundary.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "dexr.h"
+#include "dexr_launch.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) return fail(DEXR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));     \
+  } while (0)
+
+struct DevBuf {  // RAII device buffer for the host-pointer wrappers
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+  template <typename T> T* as() { return static_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct dexr_model {
+  dexr_model_header h;
+  std::vector<dexr_comp_table> comps;
+  dexr_comp_table* d_comps = nullptr;
+  int bucket = 0;      // NMAX instantiation used for every component of this model
+  int lds_frames = 1;  // max n_frame over components
+  int lds_terms = 1;   // max n_term over components
+};
+
+namespace {
+
+int pick_bucket(int nj) {
+  const int buckets[] = {4, 8, 16, 24, 32};
+  for (int b : buckets)
+    if (nj <= b) return b;
+  return -1;
+}
+
+void fill_params(const dexr_model* m, dexr::KernelParams& kp, int64_t B) {
+  std::memset(&kp, 0, sizeof(kp));
+  const dexr_model_header& h = m->h;
+  kp.comps = m->d_comps;
+  kp.B = B;
+  kp.n_comp = h.n_comp;
+  kp.n_opt = h.n_opt;
+  kp.n_fixed = h.n_fixed;
+  kp.n_ref = h.n_ref;
+  kp.n_q = h.n_q;
+  kp.kind = h.kind;
+  kp.num_fingers = h.num_fingers;
+  kp.huber_delta = h.huber_delta;
+  kp.norm_delta = h.norm_delta;
+  kp.scaling = h.scaling;
+  kp.inv_norm = h.inv_norm;
+  kp.project_dist = h.project_dist;
+  kp.escape_dist = h.escape_dist;
+  kp.eta1 = h.eta1;
+  kp.eta2 = h.eta2;
+  kp.lds_frames = m->lds_frames;
+  kp.lds_terms = m->lds_terms;
+}
+
+// launch geometry: one wave per (64-item tile, component); waves of a block sit on consecutive components so
+// that the rows of ref/last they share are fetched by one CU.
+int launch(const dexr_model* m, int mode, int f64, const dexr::KernelParams& kp, hipStream_t st) {
+  if (kp.B <= 0) return DEXR_OK;
+  const size_t real_sz = f64 ? 8 : 4;
+  const size_t per_wave = 64 * real_sz * (size_t)(3 * m->lds_frames + 4 * m->lds_terms);
+  int wpb = 4;
+  while (wpb > 1 && per_wave * wpb > 48 * 1024) wpb >>= 1;
+  if (per_wave > 64 * 1024) return fail(DEXR_ERR_UNSUPPORTED, "component needs %zu B of LDS per wave", per_wave);
+  const int64_t tiles = (kp.B + 63) / 64;
+  const int64_t waves = tiles * kp.n_comp;
+  const int64_t blocks = (waves + wpb - 1) / wpb;
+  if (blocks > 0x7fffffffLL) return fail(DEXR_ERR_INVALID, "batch too large for one launch");
+  dexr::launch_fn fn = dexr::find_launcher(m->bucket, f64, mode);
+  if (!fn) return fail(DEXR_ERR_UNSUPPORTED, "no kernel for bucket %d / f64=%d / mode=%d", m->bucket, f64, mode);
+  hipError_t e = fn(kp, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, st);
+  if (e != hipSuccess) return fail(DEXR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return DEXR_OK;
+}
+
+void apply_options(dexr::KernelParams& kp, const dexr_solve_options* opt) {
+  dexr_solve_options o;
+  dexr_default_options(&o);
+  if (opt) o = *opt;
+  kp.max_iter = o.max_iter > 0 ? o.max_iter : 64;
+  kp.tol = o.tol > 0 ? o.tol : 2e-6f;
+  kp.lam0 = o.lambda0 > 0 ? o.lambda0 : 1e-4f;
+  kp.newton = o.newton;
+  kp.max_blind = 8;
+  if (const char* e = std::getenv("DEXR_MAX_BLIND")) kp.max_blind = std::atoi(e);  // developer knob
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dexr_last_error(void) { return g_err.c_str(); }
+
+const char* dexr_version(void) { return "dexr 0.1 (gfx950; table v3)"; }
+
+int dexr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void dexr_default_options(dexr_solve_options* opt) {
+  if (!opt) return;
+  opt->max_iter = 64;
+  opt->tol = 2e-6f;
+  opt->lambda0 = 1e-4f;
+  opt->newton = 1;
+  opt->precision = 0;
+}
+
+int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out) {
+  if (!blob || !out) return fail(DEXR_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (nbytes < sizeof(dexr_model_header)) return fail(DEXR_ERR_INVALID, "blob shorter than the header");
+  dexr_model_header h;
+  std::memcpy(&h, blob, sizeof(h));
+  if (h.magic != DEXR_MAGIC) return fail(DEXR_ERR_INVALID, "bad magic 0x%08x", h.magic);
+  if (h.version != DEXR_TABLE_VERSION) return fail(DEXR_ERR_INVALID, "table version %u, library expects %u", h.version, DEXR_TABLE_VERSION);
+  if (h.comp_bytes != (int32_t)sizeof(dexr_comp_table)) return fail(DEXR_ERR_INVALID, "component record is %d B, library expects %zu", h.comp_bytes, sizeof(dexr_comp_table));
+  if (h.n_comp < 1 || h.n_comp > 4096) return fail(DEXR_ERR_INVALID, "n_comp=%d out of range", h.n_comp);
+  if (h.kind < DEXR_KIND_VECTOR || h.kind > DEXR_KIND_FKONLY) return fail(DEXR_ERR_INVALID, "unknown kind %d", h.kind);
+  if (nbytes != sizeof(h) + (size_t)h.n_comp * sizeof(dexr_comp_table)) return fail(DEXR_ERR_INVALID, "blob size %zu does not match n_comp=%d", nbytes, h.n_comp);
+  if (h.n_opt < 0 || h.n_fixed < 0 || h.n_ref < 0 || h.n_q < 0) return fail(DEXR_ERR_INVALID, "negative size in header");
+  if (h.kind == DEXR_KIND_DEXPILOT) {
+    if (h.num_fingers < 2 || h.num_fingers > 5) return fail(DEXR_ERR_INVALID, "DexPilot needs 2..5 fingers, got %d", h.num_fingers);
+    if (h.n_comp != 1) return fail(DEXR_ERR_INVALID, "DexPilot tables must have exactly one component");
+    const int F = h.num_fingers;
+    if (h.n_ref != F * (F - 1) / 2 + F) return fail(DEXR_ERR_INVALID, "DexPilot n_ref=%d does not match %d fingers", h.n_ref, F);
+  }
+  dexr_model* m = new (std::nothrow) dexr_model();
+  if (!m) return fail(DEXR_ERR_INVALID, "out of host memory");
+  m->h = h;
+  m->comps.resize(h.n_comp);
+  std::memcpy(m->comps.data(), static_cast<const char*>(blob) + sizeof(h), (size_t)h.n_comp * sizeof(dexr_comp_table));
+  int maxj = 0;
+  for (const dexr_comp_table& c : m->comps) {
+    if (c.n_joint < 0 || c.n_joint > DEXR_MAXJ || c.n_frame < 0 || c.n_frame > DEXR_MAXF || c.n_term < 0 ||
+        c.n_term > DEXR_MAXT || c.n_base_frame < 0 || c.n_base_frame > c.n_frame) {
+      delete m;
+      return fail(DEXR_ERR_INVALID, "component sizes out of range");
+    }
+    for (int k = 0; k < c.n_joint; ++k) {
+      const bool bad = c.restore[k] < -2 || c.restore[k] >= DEXR_NSLOT || c.save[k] < -1 || c.save[k] >= DEXR_NSLOT ||
+                       c.fbeg[k] < 0 || c.fend[k] > c.n_frame || c.src_kind[k] < 0 || c.src_kind[k] > DEXR_SRC_DIRECT ||
+                       (c.src_kind[k] == DEXR_SRC_OPT && (c.api[k] < 0 || c.api[k] >= h.n_opt)) ||
+                       (c.src_kind[k] == DEXR_SRC_FIXED && (c.src_idx[k] < 0 || c.src_idx[k] >= h.n_fixed)) ||
+                       (c.src_kind[k] == DEXR_SRC_MIMIC && (c.src_idx[k] < 0 || c.src_idx[k] >= c.n_joint)) ||
+                       (c.src_kind[k] == DEXR_SRC_DIRECT && (c.src_idx[k] < 0 || c.src_idx[k] >= h.n_q));
+      if (bad) {
+        delete m;
+        return fail(DEXR_ERR_INVALID, "joint record %d malformed", k);
+      }
+    }
+    for (int t = 0; t < c.n_term; ++t) {
+      if (c.term_task[t] < 0 || c.term_task[t] >= c.n_frame || c.term_origin[t] < -1 || c.term_origin[t] >= c.n_frame ||
+          c.term_ref[t] < 0 || c.term_ref[t] >= h.n_ref) {
+        delete m;
+        return fail(DEXR_ERR_INVALID, "term record %d malformed", t);
+      }
+    }
+    if (c.n_joint > maxj) maxj = c.n_joint;
+    if (c.n_frame > m->lds_frames) m->lds_frames = c.n_frame;
+    if (c.n_term > m->lds_terms) m->lds_terms = c.n_term;
+  }
+  m->bucket = pick_bucket(maxj > 0 ? maxj : 1);
+  if (m->bucket < 0) {
+    delete m;
+    return fail(DEXR_ERR_UNSUPPORTED, "component with %d joints exceeds the largest kernel bucket", maxj);
+  }
+  hipError_t e = hipMalloc((void**)&m->d_comps, m->comps.size() * sizeof(dexr_comp_table));
+  if (e == hipSuccess) e = hipMemcpy(m->d_comps, m->comps.data(), m->comps.size() * sizeof(dexr_comp_table), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (m->d_comps) (void)hipFree(m->d_comps);
+    delete m;
+    return fail(DEXR_ERR_HIP, "uploading tables failed: %s", hipGetErrorString(e));
+  }
+  *out = m;
+  return DEXR_OK;
+}
+
+void dexr_model_destroy(dexr_model* m) {
+  if (!m) return;
+  if (m->d_comps) (void)hipFree(m->d_comps);
+  delete m;
+}
+
+int dexr_model_info(const dexr_model* m, dexr_model_header* header_out) {
+  if (!m || !header_out) return fail(DEXR_ERR_INVALID, "null argument");
+  *header_out = m->h;
+  return DEXR_OK;
+}
+
+int dexr_retarget_dev(const dexr_model* m, int64_t B, const float* ref, const float* fixed, const float* last,
+                      uint32_t* state, float* qpos_out, int32_t* status_out, int32_t* iters_out, float* fval_out,
+                      const dexr_solve_options* opt, void* stream) {
+  if (!m || !ref || !last || !qpos_out) return fail(DEXR_ERR_INVALID, "null argument");
+  if (m->h.kind == DEXR_KIND_FKONLY) return fail(DEXR_ERR_INVALID, "model is an FK-only table");
+  if (m->h.n_fixed > 0 && !fixed) return fail(DEXR_ERR_INVALID, "model has %d fixed joints but fixed_qpos is NULL", m->h.n_fixed);
+  if (B < 0) return fail(DEXR_ERR_INVALID, "negative batch");
+  if (B == 0) return DEXR_OK;
+  if (opt && opt->precision != 0) return fail(DEXR_ERR_INVALID, "use dexr_retarget_f64 for float64 arithmetic");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  dexr::KernelParams kp;
+  fill_params(m, kp, B);
+  apply_options(kp, opt);
+  kp.ref = ref;
+  kp.fixed = fixed;
+  kp.last = last;
+  kp.state = state;
+  kp.qout = qpos_out;
+  kp.status = status_out;
+  kp.iters = iters_out;
+  kp.fval = fval_out;
+  if (status_out) HIP_TRY(hipMemsetAsync(status_out, 0, (size_t)B * sizeof(int32_t), st));
+  if (iters_out) HIP_TRY(hipMemsetAsync(iters_out, 0, (size_t)B * sizeof(int32_t), st));
+  if (fval_out) HIP_TRY(hipMemsetAsync(fval_out, 0, (size_t)B * sizeof(float), st));
+  return launch(m, dexr::MODE_SOLVE, 0, kp, st);
+}
+
+static int retarget_host(const dexr_model* m, int64_t B, const float* ref, const float* fixed, const float* last,
+                         uint32_t* state, float* q32, double* q64, int32_t* status_out, int32_t* iters_out,
+                         float* fval_out, const dexr_solve_options* opt, int f64) {
+  if (!m || !ref || !last || (!q32 && !q64)) return fail(DEXR_ERR_INVALID, "null argument");
+  if (m->h.kind == DEXR_KIND_FKONLY) return fail(DEXR_ERR_INVALID, "model is an FK-only table");
+  if (m->h.n_fixed > 0 && !fixed) return fail(DEXR_ERR_INVALID, "model has %d fixed joints but fixed_qpos is NULL", m->h.n_fixed);
+  if (B < 0) return fail(DEXR_ERR_INVALID, "negative batch");
+  if (B == 0) return DEXR_OK;
+  const size_t nb = (size_t)B;
+  const size_t ref_b = nb * m->h.n_ref * 3 * sizeof(float), fix_b = nb * m->h.n_fixed * sizeof(float);
+  const size_t q_b = nb * m->h.n_opt * sizeof(float);
+  DevBuf d_ref, d_fix, d_last, d_state, d_q, d_q64, d_status, d_iters, d_fval;
+  HIP_TRY(d_ref.alloc(ref_b));
+  HIP_TRY(d_fix.alloc(fix_b));
+  HIP_TRY(d_last.alloc(q_b));
+  HIP_TRY(d_q.alloc(q_b));
+  HIP_TRY(d_q64.alloc(q64 ? nb * m->h.n_opt * sizeof(double) : 0));
+  HIP_TRY(d_state.alloc(nb * sizeof(uint32_t)));
+  HIP_TRY(d_status.alloc(nb * sizeof(int32_t)));
+  HIP_TRY(d_iters.alloc(nb * sizeof(int32_t)));
+  HIP_TRY(d_fval.alloc(nb * sizeof(float)));
+  HIP_TRY(hipMemcpy(d_ref.p, ref, ref_b, hipMemcpyHostToDevice));
+  if (fix_b) HIP_TRY(hipMemcpy(d_fix.p, fixed, fix_b, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_last.p, last, q_b, hipMemcpyHostToDevice));
+  if (state) HIP_TRY(hipMemcpy(d_state.p, state, nb * sizeof(uint32_t), hipMemcpyHostToDevice));
+  else HIP_TRY(hipMemset(d_state.p, 0, nb * sizeof(uint32_t)));
+  HIP_TRY(hipMemset(d_status.p, 0, nb * sizeof(int32_t)));
+  HIP_TRY(hipMemset(d_iters.p, 0, nb * sizeof(int32_t)));
+  HIP_TRY(hipMemset(d_fval.p, 0, nb * sizeof(float)));
+  dexr::KernelParams kp;
+  fill_params(m, kp, B);
+  apply_options(kp, opt);
+  kp.ref = d_ref.as<float>();
+  kp.fixed = d_fix.as<float>();
+  kp.last = d_last.as<float>();
+  kp.state = d_state.as<uint32_t>();
+  kp.qout = d_q.as<float>();
+  kp.qout64 = q64 ? d_q64.as<double>() : nullptr;
+  kp.status = d_status.as<int32_t>();
+  kp.iters = d_iters.as<int32_t>();
+  kp.fval = d_fval.as<float>();
+  int rc = launch(m, dexr::MODE_SOLVE, f64, kp, nullptr);
+  if (rc != DEXR_OK) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  if (q32) HIP_TRY(hipMemcpy(q32, d_q.p, q_b, hipMemcpyDeviceToHost));
+  if (q64) HIP_TRY(hipMemcpy(q64, d_q64.p, nb * m->h.n_opt * sizeof(double), hipMemcpyDeviceToHost));
+  if (state) HIP_TRY(hipMemcpy(state, d_state.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (status_out) HIP_TRY(hipMemcpy(status_out, d_status.p, nb * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (iters_out) HIP_TRY(hipMemcpy(iters_out, d_iters.p, nb * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (fval_out) HIP_TRY(hipMemcpy(fval_out, d_fval.p, nb * sizeof(float), hipMemcpyDeviceToHost));
+  return DEXR_OK;
+}
+
+int dexr_retarget(const dexr_model* m, int64_t B, const float* ref, const float* fixed, const float* last,
+                  uint32_t* state, float* qpos_out, int32_t* status_out, int32_t* iters_out, float* fval_out,
+                  const dexr_solve_options* opt) {
+  if (opt && opt->precision != 0) return fail(DEXR_ERR_INVALID, "use dexr_retarget_f64 for float64 arithmetic");
+  return retarget_host(m, B, ref, fixed, last, state, qpos_out, nullptr, status_out, iters_out, fval_out, opt, 0);
+}
+
+int dexr_retarget_f64(const dexr_model* m, int64_t B, const float* ref, const float* fixed, const float* last,
+                      uint32_t* state, double* qpos_out, int32_t* status_out, int32_t* iters_out,
+                      const dexr_solve_options* opt) {
+  return retarget_host(m, B, ref, fixed, last, state, nullptr, qpos_out, status_out, iters_out, nullptr, opt, 1);
+}
+
+int dexr_eval(const dexr_model* m, int64_t B, const float* ref, const float* fixed, const float* last,
+              const double* x, uint32_t* state, double* f_out, double* grad_out) {
+  if (!m || !ref || !last || !x || !f_out || !grad_out) return fail(DEXR_ERR_INVALID, "null argument");
+  if (m->h.kind == DEXR_KIND_FKONLY) return fail(DEXR_ERR_INVALID, "model is an FK-only table");
+  if (m->h.n_fixed > 0 && !fixed) return fail(DEXR_ERR_INVALID, "model has %d fixed joints but fixed_qpos is NULL", m->h.n_fixed);
+  if (B < 0) return fail(DEXR_ERR_INVALID, "negative batch");
+  if (B == 0) return DEXR_OK;
+  const size_t nb = (size_t)B;
+  const size_t ref_b = nb * m->h.n_ref * 3 * sizeof(float), fix_b = nb * m->h.n_fixed * sizeof(float);
+  const size_t q_b = nb * m->h.n_opt * sizeof(float), x_b = nb * m->h.n_opt * sizeof(double);
+  DevBuf d_ref, d_fix, d_last, d_x, d_state, d_f, d_g;
+  HIP_TRY(d_ref.alloc(ref_b));
+  HIP_TRY(d_fix.alloc(fix_b));
+  HIP_TRY(d_last.alloc(q_b));
+  HIP_TRY(d_x.alloc(x_b));
+  HIP_TRY(d_state.alloc(nb * sizeof(uint32_t)));
+  HIP_TRY(d_f.alloc(nb * sizeof(double)));
+  HIP_TRY(d_g.alloc(x_b));
+  HIP_TRY(hipMemcpy(d_ref.p, ref, ref_b, hipMemcpyHostToDevice));
+  if (fix_b) HIP_TRY(hipMemcpy(d_fix.p, fixed, fix_b, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_last.p, last, q_b, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_x.p, x, x_b, hipMemcpyHostToDevice));
+  if (state) HIP_TRY(hipMemcpy(d_state.p, state, nb * sizeof(uint32_t), hipMemcpyHostToDevice));
+  else HIP_TRY(hipMemset(d_state.p, 0, nb * sizeof(uint32_t)));
+  HIP_TRY(hipMemset(d_f.p, 0, nb * sizeof(double)));
+  HIP_TRY(hipMemset(d_g.p, 0, x_b));
+  dexr::KernelParams kp;
+  fill_params(m, kp, B);
+  kp.ref = d_ref.as<float>();
+  kp.fixed = d_fix.as<float>();
+  kp.last = d_last.as<float>();
+  kp.xin = d_x.as<double>();
+  kp.state = d_state.as<uint32_t>();
+  kp.f64out = d_f.as<double>();
+  kp.g64out = d_g.as<double>();
+  int rc = launch(m, dexr::MODE_EVAL, 1, kp, nullptr);
+  if (rc != DEXR_OK) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(f_out, d_f.p, nb * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(grad_out, d_g.p, x_b, hipMemcpyDeviceToHost));
+  if (state) HIP_TRY(hipMemcpy(state, d_state.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return DEXR_OK;
+}
+
+int dexr_fk(const dexr_model* m, int64_t B, const double* q, double* pos_out) {
+  if (!m || !q || !pos_out) return fail(DEXR_ERR_INVALID, "null argument");
+  if (m->h.kind != DEXR_KIND_FKONLY) return fail(DEXR_ERR_INVALID, "model is not an FK-only table");
+  if (B < 0) return fail(DEXR_ERR_INVALID, "negative batch");
+  if (B == 0) return DEXR_OK;
+  const size_t nb = (size_t)B;
+  const size_t q_b = nb * m->h.n_q * sizeof(double), p_b = nb * m->h.n_ref * 3 * sizeof(double);
+  DevBuf d_q, d_p;
+  HIP_TRY(d_q.alloc(q_b));
+  HIP_TRY(d_p.alloc(p_b));
+  HIP_TRY(hipMemcpy(d_q.p, q, q_b, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(d_p.p, 0, p_b));
+  dexr::KernelParams kp;
+  fill_params(m, kp, B);
+  kp.xin = d_q.as<double>();
+  kp.f64out = d_p.as<double>();
+  int rc = launch(m, dexr::MODE_FK, 1, kp, nullptr);
+  if (rc != DEXR_OK) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(pos_out, d_p.p, p_b, hipMemcpyDeviceToHost));
+  return DEXR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,24 @@
+// dexr_inst.hip -- one kernel instantiation per translation unit so that the 20 (bucket, precision, mode)
+// variants compile in parallel.  Compile with -DDEXR_NMAX=<4|8|16|24|32> -DDEXR_F64=<0|1> -DDEXR_MODE=<0|1|2>.
+#include "dexr_launch.hpp"
+
+#ifndef DEXR_NMAX
+#error "DEXR_NMAX not defined"
+#endif
+
+namespace dexr {
+#if DEXR_F64
+typedef double inst_real;
+#else
+typedef float inst_real;
+#endif
+
+#define DEXR_CAT_(a, b, c, d) a##b##_##c##_##d
+#define DEXR_CAT(a, b, c, d) DEXR_CAT_(a, b, c, d)
+
+hipError_t DEXR_CAT(launch_, DEXR_NMAX, DEXR_F64, DEXR_MODE)(const KernelParams& kp, dim3 grid, dim3 block, size_t lds,
+                                                          hipStream_t st) {
+  hipLaunchKernelGGL((dexr_kernel<DEXR_NMAX, inst_real, DEXR_MODE>), grid, block, lds, st, kp);
+  return hipGetLastError();
+}
+}  // namespace dexr

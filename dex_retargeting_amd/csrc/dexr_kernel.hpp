@@ -1,0 +1,690 @@
+// dexr_kernel.hpp -- hand-written HIP kernels for gfx950 (MI355X): batched retargeting solve.
+//
+// Mapping (MI355X-first):
+//   * one LANE   = one (frame, component) sub-problem; all solver state (q, world axes/origins of the chain,
+//     gradient, the dense lower-triangular Hessian and its Cholesky factor) lives in VGPRs with STATIC indices;
+//   * one WAVE64 = 64 frames of the SAME component, so every table read (joint placements, masks, limits) is
+//     wave-uniform -> scalar loads / SGPR operands, and every branch on the tree topology is a scalar branch;
+//   * LDS holds only what needs a (uniform) dynamic index: frame positions and per-term targets/weights,
+//     laid out [index][lane] so each ds_read/ds_write is conflict-free.
+//
+// What is computed follows the reference's objective closures
+// (/root/reference/src/dex_retargeting/optimizer.py:138-200, 241-306, 456-577): forward kinematics of the
+// chain, world-aligned point Jacobians J = a x (p - o), SmoothL1 of the vector norm (vector/dexpilot) or per
+// coordinate (position), the mimic fold of kinematics_adaptor.py:102-113 and the 2*norm_delta*(x-last)
+// regulariser.  The minimiser is ours: projected Levenberg-Marquardt/Newton with a register Cholesky.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dexr_tables.h"
+
+namespace dexr {
+
+struct KernelParams {
+  const dexr_comp_table* __restrict__ comps;
+  const float* __restrict__ ref;    // B x n_ref x 3
+  const float* __restrict__ fixed;  // B x n_fixed
+  const float* __restrict__ last;   // B x n_opt
+  const double* __restrict__ xin;   // eval: B x n_opt ; fk: B x n_q
+  uint32_t* state;                  // B
+  float* qout;                      // B x n_opt
+  double* qout64;                   // B x n_opt (optional)
+  int32_t* status;                  // B
+  int32_t* iters;                   // B
+  float* fval;                      // B
+  double* f64out;                   // eval: B ; fk: B x n_ref x 3
+  double* g64out;                   // eval: B x n_opt
+  int64_t B;
+  int32_t n_comp, n_opt, n_fixed, n_ref, n_q, kind, num_fingers;
+  float huber_delta, norm_delta, scaling, inv_norm, project_dist, escape_dist, eta1, eta2;
+  int32_t max_iter;
+  float tol, lam0;
+  int32_t newton;
+  int32_t max_blind;  // accepted steps below the rounding floor of F before giving up on further progress
+  int32_t lds_frames, lds_terms;  // per-wave LDS rows: max frames / max terms over the model's components
+};
+
+enum { MODE_SOLVE = 0, MODE_EVAL = 1, MODE_FK = 2 };
+enum { ST_CONVERGED = 0, ST_MAXITER = 1, ST_FALLBACK = 2 };  // == DEXR_STATUS_* in dexr.h
+
+template <typename real> struct RealTraits;
+template <> struct RealTraits<float> {
+  static __device__ __forceinline__ float rsqrt(float v) { return __frsqrt_rn(v); }
+  static __device__ __forceinline__ float sqrt(float v) { return __fsqrt_rn(v); }
+  // sin/cos for joint angles (|a| <~ 1e3 rad): 3-term Cody-Waite reduction by pi/2 + degree-7/8 minimax
+  // polynomials on [-pi/4, pi/4]; ~1 ulp, no scratch, no slow path (ocml's sincosf carries a Payne-Hanek
+  // fallback that costs ~100 VGPRs and private memory inside this kernel).
+  static __device__ __forceinline__ void sincos(float a, float* s, float* c) {
+    const float kf = rintf(a * 0.63661977236758134f);
+    float r = fmaf(-kf, 1.5707962513e+00f, a);
+    r = fmaf(-kf, 7.5497894159e-08f, r);
+    r = fmaf(-kf, 5.3903029534e-15f, r);
+    const float z = r * r;
+    const float sp = r + r * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
+    const float cp = 1.0f - 0.5f * z + z * z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
+    const int k = (int)kf;
+    const float ss = (k & 1) ? cp : sp;
+    const float cc = (k & 1) ? sp : cp;
+    *s = (k & 2) ? -ss : ss;
+    *c = ((k + 1) & 2) ? -cc : cc;
+  }
+  static __device__ __forceinline__ float eps() { return 5.9604645e-8f; }
+};
+template <> struct RealTraits<double> {
+  static __device__ __forceinline__ double rsqrt(double v) { return 1.0 / ::sqrt(v); }
+  static __device__ __forceinline__ double sqrt(double v) { return ::sqrt(v); }
+  static __device__ __forceinline__ void sincos(double a, double* s, double* c) { ::sincos(a, s, c); }
+  static __device__ __forceinline__ double eps() { return 1.1102230246251565e-16; }
+};
+
+template <int NMAX, typename real>
+struct LaneSolver {
+  static constexpr int NH = NMAX * (NMAX + 1) / 2;
+  using RT = RealTraits<real>;
+
+  // ---- per-lane register state ---------------------------------------------------------------------------
+  real x[NMAX];      // joint values of every local joint (optimised, fixed-valued and mimic alike)
+  real xl[NMAX];     // regularisation target (last_qpos) for optimised joints
+  real ax[NMAX][3];  // world joint axes
+  real og[NMAX][3];  // world joint origins
+  real g[NMAX];
+  real H[NH];
+
+  static __host__ __device__ __forceinline__ constexpr int hidx(int r, int c) { return r * (r + 1) / 2 + c; }
+
+  template <typename T>
+  static __device__ __forceinline__ T pick(const T (&arr)[NMAX], int idx) {
+    // wave-uniform idx.  Written as a masked sum so that the optimiser cannot turn it back into a dynamically
+    // indexed load (which would push the whole register-resident solver state into scratch memory).
+    T v = 0;
+#pragma unroll
+    for (int s = 0; s < NMAX; ++s) v += (s == idx ? (T)1 : (T)0) * arr[s];
+    return v;
+  }
+
+  // ---- forward kinematics of the component's joint list ---------------------------------------------------
+  // Writes ax/og for every joint and the world position of every frame to LDS  P[(f*3+c)*64 + lane].
+  __device__ __forceinline__ void fk(const dexr_comp_table& tb, int nj, real* P, int lane) {
+    real R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    real p[3] = {0, 0, 0};
+    real sR[DEXR_NSLOT][9];
+    real sp[DEXR_NSLOT][3];
+#pragma unroll
+    for (int s = 0; s < DEXR_NSLOT; ++s) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) sR[s][i] = 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) sp[s][i] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+      if (k < nj) {
+        const int rs = tb.restore[k];
+        if (rs == -2) {
+          R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+          p[0] = 0; p[1] = 0; p[2] = 0;
+        } else if (rs >= 0) {
+#pragma unroll
+          for (int s = 0; s < DEXR_NSLOT; ++s)
+            if (rs == s) {
+#pragma unroll
+              for (int i = 0; i < 9; ++i) R[i] = sR[s][i];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) p[i] = sp[s][i];
+            }
+        }
+        const float* X = tb.X[k];
+        // p += R * Xp ; R = R * Xr
+#pragma unroll
+        for (int i = 0; i < 3; ++i) p[i] += R[3 * i] * (real)X[9] + R[3 * i + 1] * (real)X[10] + R[3 * i + 2] * (real)X[11];
+        real Rn[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            Rn[3 * i + j] = R[3 * i] * (real)X[j] + R[3 * i + 1] * (real)X[3 + j] + R[3 * i + 2] * (real)X[6 + j];
+        real q = x[k];
+        if (tb.src_kind[k] == DEXR_SRC_MIMIC) {  // kinematics_adaptor.py:102-105
+          q = (real)tb.mult[k] * pick(x, tb.src_idx[k]) + (real)tb.off[k];
+          x[k] = q;
+        }
+        if (tb.jtype[k] == DEXR_JOINT_REVOLUTE) {
+          real s, c;
+          RT::sincos(q, &s, &c);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const real c0 = Rn[3 * i], c1 = Rn[3 * i + 1];
+            R[3 * i] = c * c0 + s * c1;
+            R[3 * i + 1] = c * c1 - s * c0;
+            R[3 * i + 2] = Rn[3 * i + 2];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) p[i] += q * Rn[3 * i + 2];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          ax[k][i] = R[3 * i + 2];
+          og[k][i] = p[i];
+        }
+        const int sv = tb.save[k];
+        if (sv >= 0) {
+#pragma unroll
+          for (int s = 0; s < DEXR_NSLOT; ++s)
+            if (sv == s) {
+#pragma unroll
+              for (int i = 0; i < 9; ++i) sR[s][i] = R[i];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) sp[s][i] = p[i];
+            }
+        }
+        const int fb = tb.fbeg[k], fe = tb.fend[k];
+        for (int f = fb; f < fe; ++f) {
+          const real o0 = (real)tb.frame_off[f][0], o1 = (real)tb.frame_off[f][1], o2 = (real)tb.frame_off[f][2];
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            P[(f * 3 + i) * 64 + lane] = p[i] + R[3 * i] * o0 + R[3 * i + 1] * o1 + R[3 * i + 2] * o2;
+        }
+      }
+    }
+  }
+
+  // ---- residuals (+ optional gradient / Hessian assembly) --------------------------------------------------
+  // Returns the data term f(x) (reference "huber_distance", no regulariser).
+  // ASM = 0: value only.  ASM = 1: value + g (data term only).  ASM = 2: value + g + H (data term only).
+  template <int ASM>
+  __device__ __forceinline__ real residuals(const dexr_comp_table& tb, const KernelParams& kp, int nt, uint32_t vmask,
+                                            const real* P, const real* T, const real* W, int lane) {
+    const bool per_coord = (kp.kind == DEXR_KIND_POSITION);
+    const bool weighted = (kp.kind == DEXR_KIND_DEXPILOT);
+    const real beta = (real)kp.huber_delta;
+    const real ibeta = (real)1 / beta;
+    real F = 0;
+    if (ASM >= 1) {
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k) g[k] = 0;
+    }
+    if (ASM >= 2) {
+#pragma unroll
+      for (int i = 0; i < NH; ++i) H[i] = 0;
+    }
+    for (int t = 0; t < nt; ++t) {
+      const int ft = tb.term_task[t], fo = tb.term_origin[t];
+      real pt[3], po[3] = {0, 0, 0}, r[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) pt[i] = P[(ft * 3 + i) * 64 + lane];
+      if (fo >= 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) po[i] = P[(fo * 3 + i) * 64 + lane];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) r[i] = pt[i] - po[i] - T[(t * 3 + i) * 64 + lane];
+      real w = (real)kp.inv_norm;
+      if (weighted) w *= W[t * 64 + lane];
+
+      real fvec[3];  // dF/dr
+      real hw[3];    // diagonal curvature weights of the loss in r
+      real kap = 0;  // rank-one curvature correction: H -= kap * (J^T r)(J^T r)^T
+      if (per_coord) {  // SmoothL1 per coordinate (optimizer.py:130,166)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const real e = r[i], ae = fabs(e);
+          const bool quad = ae < beta;
+          F += w * (quad ? (real)0.5 * e * e * ibeta : ae - (real)0.5 * beta);
+          fvec[i] = w * (quad ? e * ibeta : (e > 0 ? (real)1 : (real)-1));
+          hw[i] = w * (quad ? ibeta : (real)1 / ae);  // IRLS majoriser in the linear region
+        }
+      } else {  // SmoothL1 of the vector norm (optimizer.py:272-273, 534-541)
+        const real d2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+        const real d = RT::sqrt(d2);
+        const bool quad = d < beta;
+        F += w * (quad ? (real)0.5 * d2 * ibeta : d - (real)0.5 * beta);
+        const real id = quad ? ibeta : (real)1 / d;  // d >= beta > 0 in the linear branch
+        const real psi = w * id;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          fvec[i] = psi * r[i];
+          hw[i] = psi;
+        }
+        kap = quad ? (real)0 : psi * id * id;
+      }
+      if (ASM >= 1) {
+        const uint32_t mt = tb.frame_anc[ft];
+        const uint32_t mo = (fo >= 0) ? tb.frame_anc[fo] : 0u;
+        const uint32_t mu = (mt | mo) & vmask;
+        real col[NMAX][3];
+        real u[NMAX];
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k) {
+          if ((mu >> k) & 1u) {
+            const bool in_t = (mt >> k) & 1u, in_o = (mo >> k) & 1u;
+            if (tb.jtype[k] == DEXR_JOINT_REVOLUTE) {
+              real v[3] = {0, 0, 0};
+              if (in_t) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) v[i] += pt[i] - og[k][i];
+              }
+              if (in_o) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) v[i] -= po[i] - og[k][i];
+              }
+              col[k][0] = ax[k][1] * v[2] - ax[k][2] * v[1];
+              col[k][1] = ax[k][2] * v[0] - ax[k][0] * v[2];
+              col[k][2] = ax[k][0] * v[1] - ax[k][1] * v[0];
+            } else {
+              const real sg = (in_t ? (real)1 : (real)0) - (in_o ? (real)1 : (real)0);
+#pragma unroll
+              for (int i = 0; i < 3; ++i) col[k][i] = sg * ax[k][i];
+            }
+            g[k] += col[k][0] * fvec[0] + col[k][1] * fvec[1] + col[k][2] * fvec[2];
+            u[k] = col[k][0] * r[0] + col[k][1] * r[1] + col[k][2] * r[2];
+          } else {
+            col[k][0] = 0; col[k][1] = 0; col[k][2] = 0; u[k] = 0;
+          }
+        }
+        if (ASM >= 2) {
+          const bool newton = kp.newton != 0;
+#pragma unroll
+          for (int rr = 0; rr < NMAX; ++rr) {
+            if ((mu >> rr) & 1u) {
+              const real cw0 = hw[0] * col[rr][0], cw1 = hw[1] * col[rr][1], cw2 = hw[2] * col[rr][2];
+              const real ku = kap * u[rr];
+              // cf = col_r x f  (second-order term: d2p/dq_c dq_r . f = a_c . (col_r x f), c ancestor of r)
+              const real cf0 = col[rr][1] * fvec[2] - col[rr][2] * fvec[1];
+              const real cf1 = col[rr][2] * fvec[0] - col[rr][0] * fvec[2];
+              const real cf2 = col[rr][0] * fvec[1] - col[rr][1] * fvec[0];
+#pragma unroll
+              for (int cc = 0; cc <= rr; ++cc) {
+                if ((mu >> cc) & 1u) {
+                  real h = cw0 * col[cc][0] + cw1 * col[cc][1] + cw2 * col[cc][2] - ku * u[cc];
+                  const bool same = (((mt >> cc) & (mt >> rr)) | ((mo >> cc) & (mo >> rr))) & 1u;
+                  if (newton && same && tb.jtype[cc] == DEXR_JOINT_REVOLUTE)
+                    h += ax[cc][0] * cf0 + ax[cc][1] * cf1 + ax[cc][2] * cf2;
+                  H[hidx(rr, cc)] += h;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    return F;
+  }
+
+  // ---- mimic fold (kinematics_adaptor.py:107-113) applied to g (and H): x_k = m * x_s + b ------------------
+  template <bool WITH_H>
+  __device__ __forceinline__ void fold_mimic(const dexr_comp_table& tb, int nj) {
+    for (int k = 0; k < nj; ++k) {
+      if (tb.src_kind[k] != DEXR_SRC_MIMIC) continue;
+      const int s = tb.src_idx[k];
+      const real m = (real)tb.mult[k];
+      real gk = 0;
+#pragma unroll
+      for (int j = 0; j < NMAX; ++j)
+        if (j == k) {
+          gk = g[j];
+          g[j] = 0;
+        }
+#pragma unroll
+      for (int j = 0; j < NMAX; ++j)
+        if (j == s) g[j] += m * gk;
+      if (WITH_H) {
+        real v[NMAX];  // v[j] = H[j][k]
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) v[j] = 0;
+#pragma unroll
+        for (int rr = 0; rr < NMAX; ++rr)
+#pragma unroll
+          for (int cc = 0; cc <= rr; ++cc) {
+            if (cc == k) v[rr] = H[hidx(rr, cc)];
+            else if (rr == k) v[cc] = H[hidx(rr, cc)];
+          }
+        const real hkk = pick(v, k);
+        const real vs = pick(v, s);
+#pragma unroll
+        for (int rr = 0; rr < NMAX; ++rr)
+#pragma unroll
+          for (int cc = 0; cc <= rr; ++cc) {
+            if (rr == k || cc == k) {
+              H[hidx(rr, cc)] = 0;
+            } else if (rr == s && cc == s) {
+              H[hidx(rr, cc)] += (real)2 * m * vs + m * m * hkk;
+            } else if (cc == s) {
+              H[hidx(rr, cc)] += m * v[rr];
+            } else if (rr == s) {
+              H[hidx(rr, cc)] += m * v[cc];
+            }
+          }
+      }
+    }
+  }
+
+  // ---- in-place Cholesky of H (lower) + solve H d = -g --------------------------------------------------------
+  // Returns false where a pivot was not positive (indefinite Newton Hessian: caller raises the damping).
+  __device__ __forceinline__ bool chol_solve(real (&d)[NMAX]) {
+    bool ok = true;
+    real inv[NMAX];
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+      real dj = H[hidx(j, j)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) dj -= H[hidx(j, k)] * H[hidx(j, k)];
+      if (!(dj > (real)1e-30)) {
+        ok = false;
+        dj = 1;
+      }
+      const real iv = RT::rsqrt(dj);
+      inv[j] = iv;
+      H[hidx(j, j)] = dj * iv;
+#pragma unroll
+      for (int i = j + 1; i < NMAX; ++i) {
+        real s = H[hidx(i, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= H[hidx(i, k)] * H[hidx(j, k)];
+        H[hidx(i, j)] = s * iv;
+      }
+    }
+    // forward: L y = -g
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) {
+      real s = -g[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) s -= H[hidx(i, k)] * d[k];
+      d[i] = s * inv[i];
+    }
+    // backward: L^T d = y
+#pragma unroll
+    for (int i = NMAX - 1; i >= 0; --i) {
+      real s = d[i];
+#pragma unroll
+      for (int k = i + 1; k < NMAX; ++k) s -= H[hidx(k, i)] * d[k];
+      d[i] = s * inv[i];
+    }
+    return ok;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// Kernel: one wave = 64 items x one component.  blockDim.x = 64 * waves_per_block; dynamic LDS =
+// waves_per_block * 64 * sizeof(real) * (3*lds_frames + 4*lds_terms).
+template <int NMAX, typename real, int MODE>
+__global__ void __launch_bounds__(256) dexr_kernel(const KernelParams kp) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  using LS = LaneSolver<NMAX, real>;
+  using RT = RealTraits<real>;
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = threadIdx.x >> 6;
+  const int waves_per_block = blockDim.x >> 6;
+  const int64_t wave_global = (int64_t)blockIdx.x * waves_per_block + wave_in_block;
+  const int comp = (int)(wave_global % kp.n_comp);
+  const int64_t tile = wave_global / kp.n_comp;
+  if (tile * 64 >= kp.B) return;
+  const int64_t item_raw = tile * 64 + lane;
+  const bool valid = item_raw < kp.B;
+  const int64_t item = valid ? item_raw : kp.B - 1;
+
+  const int per_wave = 64 * (3 * kp.lds_frames + 4 * kp.lds_terms);
+  real* P = reinterpret_cast<real*>(lds_raw) + (size_t)wave_in_block * per_wave;
+  real* T = P + 64 * 3 * kp.lds_frames;
+  real* W = T + 64 * 3 * kp.lds_terms;
+
+  const dexr_comp_table& tb = kp.comps[comp];
+  const int nj = tb.n_joint, nt = tb.n_term;
+
+  LS S;
+  uint32_t vmask = 0;   // joints that carry an optimisation variable (directly or as a mimic)
+  uint32_t optmask = 0; // joints that ARE an optimisation variable
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k) {
+    S.x[k] = 0;
+    S.xl[k] = 0;
+    if (k < nj) {
+      const int sk = tb.src_kind[k];
+      if (sk == DEXR_SRC_OPT) {
+        real v;
+        if (MODE == MODE_EVAL) v = (real)kp.xin[item * kp.n_opt + tb.api[k]];
+        else v = (real)kp.last[item * kp.n_opt + tb.api[k]];
+        S.xl[k] = (real)kp.last[item * kp.n_opt + tb.api[k]];
+        S.x[k] = v;
+        vmask |= 1u << k;
+        optmask |= 1u << k;
+      } else if (sk == DEXR_SRC_FIXED) {
+        S.x[k] = (real)tb.mult[k] * (real)kp.fixed[item * kp.n_fixed + tb.src_idx[k]] + (real)tb.off[k];
+      } else if (sk == DEXR_SRC_MIMIC) {
+        vmask |= 1u << k;
+      } else {
+        S.x[k] = (real)kp.xin[item * kp.n_q + tb.src_idx[k]];
+      }
+    }
+  }
+
+  // base frames
+  for (int f = 0; f < tb.n_base_frame; ++f) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) P[(f * 3 + i) * 64 + lane] = (real)tb.frame_off[f][i];
+  }
+
+  if (MODE == MODE_FK) {
+    S.fk(tb, nj, P, lane);
+    if (valid) {
+      for (int t = 0; t < nt; ++t) {
+        const int f = tb.term_task[t], row = tb.term_ref[t];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) kp.f64out[(item * kp.n_ref + row) * 3 + i] = (double)P[(f * 3 + i) * 64 + lane];
+      }
+    }
+    return;
+  }
+
+  // ---- per-term targets (and DexPilot weights / projection state) ------------------------------------------
+  if (kp.kind == DEXR_KIND_DEXPILOT) {
+    // optimizer.py:462-508.  Terms are the model's vectors in order: pairs first, then wrist->finger.
+    const int F = kp.num_fingers;
+    const int n_pair = F * (F - 1) / 2, len_s1 = F - 1;
+    uint32_t st = kp.state ? kp.state[item] : 0u;
+    uint32_t nst = 0;
+    // S1 bits
+    for (int i = 0; i < len_s1; ++i) {
+      const float* rv = kp.ref + (item * kp.n_ref + i) * 3;
+      const float dist = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+      bool b = (st >> i) & 1u;
+      if (dist < kp.project_dist) b = true;
+      if (dist > kp.escape_dist) b = false;
+      nst |= (b ? 1u : 0u) << i;
+    }
+    int idx = len_s1;
+    for (int a = 0; a < F - 2; ++a)
+      for (int b2 = a + 1; b2 < F - 1; ++b2) {
+        const float* rv = kp.ref + (item * kp.n_ref + idx) * 3;
+        const float dist = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+        const bool b = ((nst >> b2) & 1u) && ((nst >> a) & 1u) && (dist <= 0.03f);
+        nst |= (b ? 1u : 0u) << idx;
+        ++idx;
+      }
+    for (int t = 0; t < nt; ++t) {
+      const int row = tb.term_ref[t];
+      const float* rv = kp.ref + (item * kp.n_ref + row) * 3;
+      float tv[3];
+      float wt;
+      if (row < n_pair) {
+        const bool pr = (nst >> row) & 1u;
+        if (pr) {
+          const float dist = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+          const float eta = row < len_s1 ? kp.eta1 : kp.eta2;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) tv[i] = (rv[i] / (dist + 1e-6f)) * eta;
+          wt = row < len_s1 ? 200.f : 400.f;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) tv[i] = rv[i] * kp.scaling;
+          wt = 1.f;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tv[i] = rv[i] * kp.scaling;
+        wt = (float)(n_pair + F);
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) T[(t * 3 + i) * 64 + lane] = (real)tv[i];
+      W[t * 64 + lane] = (real)wt;
+    }
+    if (kp.state && valid && comp == 0) kp.state[item] = nst;
+  } else {
+    const float sc = (kp.kind == DEXR_KIND_VECTOR) ? kp.scaling : 1.f;
+    for (int t = 0; t < nt; ++t) {
+      const float* rv = kp.ref + (item * kp.n_ref + tb.term_ref[t]) * 3;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) T[(t * 3 + i) * 64 + lane] = (real)(rv[i] * sc);  // f32 multiply: optimizer.py:246
+    }
+  }
+
+  const real delta = (real)kp.norm_delta;
+
+  if (MODE == MODE_EVAL) {  // objective(x, grad): value without, gradient with the regulariser (quirk Q1)
+    S.fk(tb, nj, P, lane);
+    const real f = S.template residuals<1>(tb, kp, nt, vmask, P, T, W, lane);
+    S.template fold_mimic<false>(tb, nj);
+    if (valid) {
+      atomicAdd(&kp.f64out[item], (double)f);
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k)
+        if ((optmask >> k) & 1u)
+          kp.g64out[item * kp.n_opt + tb.api[k]] = (double)(S.g[k] + (real)2 * delta * (S.x[k] - S.xl[k]));
+    }
+    return;
+  }
+
+  // ---- MODE_SOLVE: projected Levenberg-Marquardt / Newton --------------------------------------------------
+  // start point: last_qpos clipped into the box (nlopt requires lb <= x0 <= ub; seq_retarget.py:118-120 clips)
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k)
+    if ((optmask >> k) & 1u) S.x[k] = fmin(fmax(S.x[k], (real)tb.lo[k]), (real)tb.hi[k]);
+
+  real lam = (real)kp.lam0, nu = 2;
+  bool done = false;
+  int status = ST_MAXITER;
+  int my_iters = 0, blind = 0;
+  real sprev = (real)1e30;
+  real xo[NMAX];
+
+  S.fk(tb, nj, P, lane);
+  real F = S.template residuals<0>(tb, kp, nt, vmask, P, T, W, lane);
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k)
+    if ((optmask >> k) & 1u) F += delta * (S.x[k] - S.xl[k]) * (S.x[k] - S.xl[k]);
+
+  for (int it = 0; it < kp.max_iter; ++it) {
+    if (__all(done)) break;
+    // quadratic model at x (the FK state in ax/og/P belongs to x here)
+    S.template residuals<2>(tb, kp, nt, vmask, P, T, W, lane);
+    S.template fold_mimic<true>(tb, nj);
+    uint32_t freemask = 0;  // lane-varying: optimised joints not held at a bound by the gradient sign
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+      if ((optmask >> k) & 1u) {
+        S.g[k] += (real)2 * delta * (S.x[k] - S.xl[k]);
+        const bool act = (S.x[k] <= (real)tb.lo[k] && S.g[k] > 0) || (S.x[k] >= (real)tb.hi[k] && S.g[k] < 0);
+        if (act) S.g[k] = 0;
+        else freemask |= 1u << k;
+      } else {
+        S.g[k] = 0;
+      }
+    }
+    // reduced, damped system: rows/cols of held or non-variable joints become identity
+#pragma unroll
+    for (int rr = 0; rr < NMAX; ++rr) {
+      const bool fr = (freemask >> rr) & 1u;
+#pragma unroll
+      for (int cc = 0; cc < rr; ++cc) {
+        const bool fc = (freemask >> cc) & 1u;
+        if (!(fr && fc)) S.H[LS::hidx(rr, cc)] = 0;
+      }
+      S.H[LS::hidx(rr, rr)] = fr ? S.H[LS::hidx(rr, rr)] + (real)2 * delta + lam : (real)1;
+    }
+    real d[NMAX];
+    const bool ok = S.chol_solve(d);
+    // trial point (projected onto the box)
+    real smax = 0, pred = 0;
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+      xo[k] = S.x[k];
+      if ((optmask >> k) & 1u) {
+        const real xt = fmin(fmax(S.x[k] + d[k], (real)tb.lo[k]), (real)tb.hi[k]);
+        pred += (real)0.5 * d[k] * (lam * d[k] - S.g[k]);
+        smax = fmax(smax, fabs(xt - S.x[k]));
+        if (!done) S.x[k] = xt;
+      }
+    }
+    S.fk(tb, nj, P, lane);
+    real Ft = S.template residuals<0>(tb, kp, nt, vmask, P, T, W, lane);
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k)
+      if ((optmask >> k) & 1u) Ft += delta * (S.x[k] - S.xl[k]) * (S.x[k] - S.xl[k]);
+
+    const real noise = (real)16 * RT::eps() * fabs(F);
+    const bool finite = (Ft == Ft) && (smax == smax) && (fabs(Ft) < (real)1e30);
+    // below the rounding floor of F the decrease test is meaningless: trust the (small) Newton step
+    const bool below_floor = ok && finite && (pred <= noise) && (smax < (real)1e-2);
+    const bool accept = !done && ok && finite && ((Ft <= F) || below_floor);
+    bool redo = false;
+    if (!done) {
+      ++my_iters;
+      if (accept) {
+        const real rho = (F - Ft) / fmax(pred, (real)1e-30);
+        const real t = (real)2 * rho - (real)1;
+        if (!below_floor) lam = fmax(lam * fmax((real)(1.0 / 3.0), (real)1 - t * t * t), (real)1e-9);
+        nu = 2;
+        F = Ft;
+        // below the floor, progress is judged by the step length alone: stop when it is under tol, when it no
+        // longer contracts (rounding noise of the gradient reached), or after max_blind such steps.
+        const bool stalled = below_floor && blind >= 1 && smax > (real)0.9 * sprev;
+        blind = below_floor ? blind + 1 : 0;
+        sprev = smax;
+        if (smax < (real)kp.tol || stalled || blind >= kp.max_blind) {
+          done = true;
+          status = ST_CONVERGED;
+        }
+      } else {
+        lam = fmax(lam, (real)1e-6) * nu;
+        nu *= 2;
+        if (lam > (real)1e10) {  // no descent direction resolvable any more
+          done = true;
+          status = finite ? ST_CONVERGED : ST_FALLBACK;
+        }
+        redo = !done;
+      }
+    }
+    if (!accept) {
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k) S.x[k] = xo[k];
+    }
+    if (__any(redo)) S.fk(tb, nj, P, lane);  // rejected lanes: bring ax/og/P back to their (unchanged) x
+  }
+
+  // non-finite guard: hand back last_qpos like the reference's RuntimeError path (optimizer.py:100-102)
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k)
+    if ((optmask >> k) & 1u) bad = bad || !(S.x[k] == S.x[k]);
+  if (bad) status = 2;
+
+  if (valid) {
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+      if ((optmask >> k) & 1u) {
+        const real v = bad ? S.xl[k] : S.x[k];
+        kp.qout[item * kp.n_opt + tb.api[k]] = (float)v;
+        if (kp.qout64) kp.qout64[item * kp.n_opt + tb.api[k]] = (double)v;
+      }
+    }
+    if (kp.status) atomicMax(&kp.status[item], status);
+    if (kp.iters) atomicMax(&kp.iters[item], my_iters);
+    if (kp.fval) atomicAdd(&kp.fval[item], (float)F);
+  }
+}
+
+}  // namespace dexr

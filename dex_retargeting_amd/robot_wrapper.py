@@ -1,0 +1,109 @@
+"""RobotWrapper: the reference's pinocchio façade (/root/reference/src/dex_retargeting/robot_wrapper.py:8-95)
+re-hosted on the compiled kinematic tables.  Metadata queries are answered from the host-side
+KinematicModel; forward kinematics runs on the GPU through libdexr's ``dexr_fk``."""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+import numpy.typing as npt
+
+from . import _lib
+from .model_compiler import compile_fk
+from .urdf import KinematicModel, parse_urdf
+
+
+class _ModelView:
+    """Just enough of ``pin.Model`` for code that pokes at ``robot.model`` (tests/test_optimizer.py:50)."""
+
+    def __init__(self, km: KinematicModel):
+        self.nq = km.dof
+        self.nv = km.dof
+        self.names = ["universe"] + km.dof_joint_names
+        self.lowerPositionLimit = km.joint_limits[:, 0].copy()
+        self.upperPositionLimit = km.joint_limits[:, 1].copy()
+
+
+class RobotWrapper:
+    """This class does not take mimic joint into consideration (same as the reference)."""
+
+    def __init__(self, urdf_path: str, use_collision=False, use_visual=False, add_dummy_free_joints: bool = False):
+        if use_visual or use_collision:
+            raise NotImplementedError
+        self.kin = KinematicModel(parse_urdf(urdf_path, add_dummy_free_joints=add_dummy_free_joints))
+        self.model = _ModelView(self.kin)
+        self.q0 = np.zeros(self.kin.dof)  # pin.neutral for 1-DoF joints
+        self._qpos = np.zeros((1, self.kin.dof))
+        self._fk_models = {}
+
+    # ---- properties (robot_wrapper.py:28-52) ------------------------------------------------------
+    @property
+    def joint_names(self) -> List[str]:
+        return list(self.model.names)
+
+    @property
+    def dof_joint_names(self) -> List[str]:
+        return self.kin.dof_joint_names
+
+    @property
+    def dof(self) -> int:
+        return self.kin.dof
+
+    @property
+    def link_names(self) -> List[str]:
+        return self.kin.link_names
+
+    @property
+    def joint_limits(self):
+        return self.kin.joint_limits
+
+    # ---- queries (robot_wrapper.py:57-77) ---------------------------------------------------------
+    def get_joint_index(self, name: str):
+        return self.dof_joint_names.index(name)
+
+    def get_link_index(self, name: str):
+        if name not in self.link_names:
+            raise ValueError(f"{name} is not a link name. Valid link names: \n{self.link_names}")
+        return self.kin.body_frame_index(name)
+
+    def get_link_name(self, index: int) -> str:
+        return self.kin.frames[index].name
+
+    # ---- kinematics (robot_wrapper.py:82-87), batched ----------------------------------------------
+    def compute_forward_kinematics(self, qpos: npt.NDArray):
+        self._qpos = np.atleast_2d(np.asarray(qpos, dtype=np.float64))
+
+    def link_positions(self, qpos: npt.NDArray, link_indices: Sequence[int]) -> np.ndarray:
+        """(B, nq) -> (B, L, 3) world positions of the given body frames, computed on the GPU."""
+        key = tuple(int(i) for i in link_indices)
+        if key not in self._fk_models:
+            names = [self.kin.frames[i].name for i in key]
+            self._fk_models[key] = _lib.Model(compile_fk(self.kin, names).to_blob())
+        q = np.atleast_2d(np.asarray(qpos, dtype=np.float64))
+        return self._fk_models[key].fk(q, len(key))
+
+    def get_link_pose(self, link_id: int) -> npt.NDArray:
+        """4x4 pose of one link at the configuration last given to compute_forward_kinematics.  Only the
+        translation is produced by the device path (that is all the retargeting objectives read,
+        optimizer.py:157-159,260,521); the rotation block is filled on the host from the same tables."""
+        pos = self.link_positions(self._qpos[:1], [link_id])[0, 0]
+        T = np.eye(4)
+        T[:3, :3] = self._host_rotation(self._qpos[0], link_id)
+        T[:3, 3] = pos
+        return T
+
+    def get_link_pose_inv(self, link_id: int) -> npt.NDArray:
+        return np.linalg.inv(self.get_link_pose(link_id))
+
+    def _host_rotation(self, q: np.ndarray, link_id: int) -> np.ndarray:
+        # cold path helper for warm_start (seq_retarget.py:84-95): orientation of one body frame
+        f = self.kin.frames[link_id]
+        R = np.eye(3)
+        for j in self.kin.ancestors(f.parent) if f.parent >= 0 else []:
+            jt = self.kin.joints[j]
+            R = R @ jt.placement[:3, :3]
+            if jt.type == "revolute":
+                a, th = jt.axis, q[j]
+                K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+                R = R @ (np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K))
+        return R @ f.placement[:3, :3]

@@ -1,0 +1,191 @@
+"""SeqRetargeting: the reference's per-frame wrapper (/root/reference/src/dex_retargeting/seq_retarget.py:12-161)
+with the same public surface (retarget, warm_start, set_qpos, get_qpos, reset, verbose, joint_names), plus
+``BatchedSeqRetargeting`` for B sequences advanced in lock-step (one kernel launch per time step)."""
+from __future__ import annotations
+
+import time
+from typing import Optional
+
+import numpy as np
+
+from .constants import OPERATOR2MANO, HandType
+from .optimizer import Optimizer
+from .optimizer_utils import LPFilter
+
+
+def _matrix_from_quaternion(q) -> np.ndarray:
+    """(w, x, y, z) -> rotation matrix (pytransform3d.rotations.matrix_from_quaternion convention)."""
+    w, x, y, z = np.asarray(q, dtype=np.float64) / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _intrinsic_xyz_euler(R: np.ndarray) -> np.ndarray:
+    """Angles (a, b, c) with R = Rx(a) Ry(b) Rz(c): euler_from_matrix(R, 0, 1, 2, extrinsic=False)."""
+    b = np.arcsin(np.clip(R[0, 2], -1.0, 1.0))
+    a = np.arctan2(-R[1, 2], R[2, 2])
+    c = np.arctan2(-R[0, 1], R[0, 0])
+    return np.array([a, b, c])
+
+
+class SeqRetargeting:
+    def __init__(self, optimizer: Optimizer, has_joint_limits=True, lp_filter: Optional[LPFilter] = None):
+        self.optimizer = optimizer
+        robot = self.optimizer.robot
+
+        # Joint limit (seq_retarget.py:23-31)
+        self.has_joint_limits = has_joint_limits
+        joint_limits = np.ones_like(robot.joint_limits)
+        joint_limits[:, 0] = -1e4
+        joint_limits[:, 1] = 1e4
+        if has_joint_limits:
+            joint_limits[:] = robot.joint_limits[:]
+            self.optimizer.set_joint_limit(joint_limits[self.optimizer.idx_pin2target])
+        self.joint_limits = joint_limits[self.optimizer.idx_pin2target]
+
+        # Temporal information
+        self.last_qpos = joint_limits.mean(1)[self.optimizer.idx_pin2target].astype(np.float32)
+        self.accumulated_time = 0
+        self.num_retargeting = 0
+        self.filter = lp_filter
+        self.is_warm_started = False
+
+    def warm_start(self, wrist_pos: np.ndarray, wrist_quat: np.ndarray, hand_type: HandType = HandType.right,
+                   is_mano_convention: bool = False):
+        """Analytic initialisation of the 6 dummy free joints (seq_retarget.py:45-110)."""
+        if len(wrist_pos) != 3:
+            raise ValueError(f"Wrist pos: {wrist_pos} is not a 3-dim vector.")
+        if len(wrist_quat) != 4:
+            raise ValueError(f"Wrist quat: {wrist_quat} is not a 4-dim vector.")
+
+        operator2mano = OPERATOR2MANO[hand_type] if is_mano_convention else np.eye(3)
+        robot = self.optimizer.robot
+        target_wrist_pose = np.eye(4)
+        target_wrist_pose[:3, :3] = _matrix_from_quaternion(wrist_quat) @ operator2mano.T
+        target_wrist_pose[:3, 3] = wrist_pos
+
+        name_list = ["dummy_x_translation_joint", "dummy_y_translation_joint", "dummy_z_translation_joint",
+                     "dummy_x_rotation_joint", "dummy_y_rotation_joint", "dummy_z_rotation_joint"]
+        # child link of the last dummy joint = the hand's original root link
+        urdf_joint = robot.kin.urdf.joint_map[name_list[5]]
+        wrist_link_id = robot.get_link_index(urdf_joint.child)
+
+        old_qpos = robot.q0
+        new_qpos = old_qpos.copy()
+        for num, joint_name in enumerate(self.optimizer.target_joint_names):
+            if joint_name in name_list:
+                new_qpos[num] = 0
+
+        robot.compute_forward_kinematics(new_qpos)
+        root2wrist = robot.get_link_pose_inv(wrist_link_id)
+        target_root_pose = target_wrist_pose @ root2wrist
+
+        euler = _intrinsic_xyz_euler(target_root_pose[:3, :3])
+        pose_vec = np.concatenate([target_root_pose[:3, 3], euler])
+
+        for num, joint_name in enumerate(self.optimizer.target_joint_names):
+            if joint_name in name_list:
+                index = name_list.index(joint_name)
+                self.last_qpos[num] = pose_vec[index]
+
+        self.is_warm_started = True
+
+    def retarget(self, ref_value, fixed_qpos=np.array([])):
+        tic = time.perf_counter()
+        qpos = self.optimizer.retarget(
+            ref_value=ref_value.astype(np.float32),
+            fixed_qpos=fixed_qpos.astype(np.float32),
+            last_qpos=np.clip(self.last_qpos, self.joint_limits[:, 0], self.joint_limits[:, 1]),
+        )
+        self.accumulated_time += time.perf_counter() - tic
+        self.num_retargeting += 1
+        self.last_qpos = qpos
+        robot_qpos = np.zeros(self.optimizer.robot.dof)
+        robot_qpos[self.optimizer.idx_pin2fixed] = fixed_qpos
+        robot_qpos[self.optimizer.idx_pin2target] = qpos
+
+        if self.optimizer.adaptor is not None:
+            robot_qpos = self.optimizer.adaptor.forward_qpos(robot_qpos)
+
+        if self.filter is not None:
+            robot_qpos = self.filter.next(robot_qpos)
+        return robot_qpos
+
+    def set_qpos(self, robot_qpos: np.ndarray):
+        target_qpos = robot_qpos[self.optimizer.idx_pin2target]
+        self.last_qpos = target_qpos
+
+    def get_qpos(self, fixed_qpos: Optional[np.ndarray] = None):
+        robot_qpos = np.zeros(self.optimizer.robot.dof)
+        robot_qpos[self.optimizer.idx_pin2target] = self.last_qpos
+        if fixed_qpos is not None:
+            robot_qpos[self.optimizer.idx_pin2fixed] = fixed_qpos
+        return robot_qpos
+
+    def verbose(self):
+        min_value = self.optimizer.opt.last_optimum_value()
+        print(f"Retargeting {self.num_retargeting} times takes: {self.accumulated_time}s")
+        print(f"Last distance: {min_value}")
+
+    def reset(self):
+        self.last_qpos = self.joint_limits.mean(1).astype(np.float32)
+        self.num_retargeting = 0
+        self.accumulated_time = 0
+
+    @property
+    def joint_names(self):
+        return self.optimizer.robot.dof_joint_names
+
+
+class BatchedSeqRetargeting:
+    """B independent sequences advanced in lock-step: every call to ``retarget`` solves frame t of all B
+    sequences in one kernel launch and carries, per sequence, exactly the state the reference carries per object:
+    the UNFILTERED last_qpos (seq_retarget.py:124), the low-pass filter output (optimizer_utils.py:7-13) and the
+    DexPilot projection bits (optimizer.py:466-476)."""
+
+    def __init__(self, optimizer: Optimizer, batch: int, has_joint_limits=True, low_pass_alpha: Optional[float] = None):
+        self.optimizer = optimizer
+        self.batch = int(batch)
+        robot = optimizer.robot
+        joint_limits = np.ones_like(robot.joint_limits)
+        joint_limits[:, 0], joint_limits[:, 1] = -1e4, 1e4
+        if has_joint_limits:
+            joint_limits[:] = robot.joint_limits[:]
+            optimizer.set_joint_limit(joint_limits[optimizer.idx_pin2target])
+        self.joint_limits = joint_limits[optimizer.idx_pin2target]
+        self.alpha = low_pass_alpha
+        self.reset()
+
+    def reset(self):
+        mid = self.joint_limits.mean(1).astype(np.float32)
+        self.last_qpos = np.repeat(mid[None], self.batch, 0)
+        self.filtered: Optional[np.ndarray] = None
+        st = self.optimizer._state_in(self.batch)
+        self.state = None if st is None else np.zeros(self.batch, dtype=np.uint32)
+        self.num_retargeting = 0
+
+    def retarget(self, ref_value: np.ndarray, fixed_qpos: Optional[np.ndarray] = None) -> np.ndarray:
+        """ref_value (B,n_ref,3); returns float64 (B, robot.dof) in pinocchio dof order."""
+        opt = self.optimizer
+        B = self.batch
+        last = np.clip(self.last_qpos, self.joint_limits[:, 0], self.joint_limits[:, 1]).astype(np.float32)
+        fixed = np.zeros((B, len(opt.idx_pin2fixed)), dtype=np.float32) if fixed_qpos is None else fixed_qpos
+        q = opt.retarget_batch(ref_value.astype(np.float32), fixed, last, state=self.state)
+        bad = opt.last_info["status"] == 2
+        if bad.any():
+            q[bad] = last[bad]
+        self.last_qpos = q
+        self.num_retargeting += 1
+        robot_qpos = np.zeros((B, opt.robot.dof))
+        robot_qpos[:, opt.idx_pin2fixed] = fixed
+        robot_qpos[:, opt.idx_pin2target] = q
+        if opt.adaptor is not None:
+            robot_qpos = opt.adaptor.forward_qpos(robot_qpos)
+        if self.alpha is not None and 0 <= self.alpha <= 1:
+            if self.filtered is None:
+                self.filtered = robot_qpos
+            else:
+                self.filtered = self.filtered + self.alpha * (robot_qpos - self.filtered)
+            return self.filtered.copy()
+        return robot_qpos

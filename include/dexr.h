@@ -1,0 +1,94 @@
+/* dexr.h -- C ABI of libdexr.so: the MI355X (gfx950) batched retargeting solver.
+ *
+ * The reference (dexsuite/dex-retargeting v0.5.0) has no FFI layer: its boundary for this path is the
+ * Python method  Optimizer.retarget(ref_value, fixed_qpos, last_qpos) -> float32 qpos
+ * (/root/reference/src/dex_retargeting/optimizer.py:77-102) plus the nlopt-style closure
+ * objective(x, grad) -> float (optimizer.py:146, 249, 510) and RobotWrapper's forward kinematics
+ * (/root/reference/src/dex_retargeting/robot_wrapper.py:82-87).  The entry points below are what a
+ * ctypes binding on the reference side binds instead of nlopt + pinocchio + torch.
+ *
+ * Conventions: plain pointers and sizes only; all arrays C-contiguous; every function returns 0 on success
+ * or a negative error code (message via dexr_last_error(), thread-local); no exceptions cross the ABI.
+ * "_dev" entry points take DEVICE pointers and enqueue on `stream` (a hipStream_t passed as void*, NULL =
+ * default stream) without synchronising; the others take HOST pointers, copy, run and synchronise.
+ */
+#ifndef DEXR_H
+#define DEXR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "dexr_tables.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dexr_model dexr_model; /* opaque: compiled tables resident in HBM */
+
+/* error codes */
+#define DEXR_OK 0
+#define DEXR_ERR_INVALID (-1) /* bad argument / malformed table blob   */
+#define DEXR_ERR_HIP (-2)     /* HIP runtime error (no device, OOM, ..) */
+#define DEXR_ERR_UNSUPPORTED (-3)
+
+/* per-item solver status written to status_out (max over the item's components) */
+#define DEXR_STATUS_CONVERGED 0
+#define DEXR_STATUS_MAXITER 1
+#define DEXR_STATUS_FALLBACK 2 /* non-finite state: last_qpos returned, like optimizer.py:100-102 */
+
+/* solver options; zero-initialise then call dexr_default_options() */
+typedef struct dexr_solve_options {
+  int32_t max_iter;   /* outer iterations (default 64)                                    */
+  float tol;          /* stop when the accepted step's inf-norm < tol [rad|m] (default 2e-6) */
+  float lambda0;      /* initial Levenberg-Marquardt damping (default 1e-4)                */
+  int32_t newton;     /* 1: add the second-order kinematic term to the Hessian (default 1) */
+  int32_t precision;  /* 0: float32 arithmetic (default); 1: float64 arithmetic            */
+} dexr_solve_options;
+
+const char* dexr_last_error(void);
+const char* dexr_version(void);
+int dexr_device_count(void);
+void dexr_default_options(dexr_solve_options* opt);
+
+/* Build a model from a table blob (dexr_model_header + n_comp * dexr_comp_table, see dexr_tables.h).
+ * Replaces what Optimizer.__init__ / set_joint_limit / set_kinematic_adaptor cache on the Python side
+ * (optimizer.py:18-75) and pin.buildModelFromUrdf (robot_wrapper.py:15). */
+int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out);
+void dexr_model_destroy(dexr_model* m);
+int dexr_model_info(const dexr_model* m, dexr_model_header* header_out);
+
+/* == Optimizer.retarget x B  (optimizer.py:77-102).
+ *   ref      B x n_ref x 3 float32  (vector/dexpilot: task-origin vectors; position: target positions)
+ *   fixed    B x n_fixed float32    (may be NULL when n_fixed == 0)
+ *   last     B x n_opt float32      (start point AND regularisation target, optimizer.py:93,98)
+ *   state    B uint32 in/out        (DexPilot projection bits, optimizer.py:466-476; may be NULL)
+ *   qpos_out B x n_opt float32      (target_joint_names order)
+ *   status_out, iters_out  B int32  (may be NULL)
+ *   fval_out B float32              (final f + norm_delta*|x-last|^2, may be NULL)                */
+int dexr_retarget_dev(const dexr_model* m, int64_t B, const float* ref, const float* fixed, const float* last,
+                      uint32_t* state, float* qpos_out, int32_t* status_out, int32_t* iters_out, float* fval_out,
+                      const dexr_solve_options* opt, void* stream);
+int dexr_retarget(const dexr_model* m, int64_t B, const float* ref, const float* fixed, const float* last,
+                  uint32_t* state, float* qpos_out, int32_t* status_out, int32_t* iters_out, float* fval_out,
+                  const dexr_solve_options* opt);
+/* same, float64 arithmetic and float64 result (validation aid; host pointers) */
+int dexr_retarget_f64(const dexr_model* m, int64_t B, const float* ref, const float* fixed, const float* last,
+                      uint32_t* state, double* qpos_out, int32_t* status_out, int32_t* iters_out,
+                      const dexr_solve_options* opt);
+
+/* == objective(x, grad) x B  (optimizer.py:146-198, 249-304, 510-575): value WITHOUT the norm_delta term,
+ * gradient WITH it, float64 arithmetic.  x, grad_out: B x n_opt float64; f_out: B float64.
+ * `state` (DexPilot) is read, and updated exactly as get_objective_function's pre-amble does. Host pointers. */
+int dexr_eval(const dexr_model* m, int64_t B, const float* ref, const float* fixed, const float* last,
+              const double* x, uint32_t* state, double* f_out, double* grad_out);
+
+/* == RobotWrapper.compute_forward_kinematics + get_link_pose(...)[:3,3] x B (robot_wrapper.py:82-87).
+ * `m` must come from an FK table (kind DEXR_KIND_FKONLY). q: B x n_q float64 (pinocchio dof order);
+ * pos_out: B x n_ref x 3 float64.  Host pointers. */
+int dexr_fk(const dexr_model* m, int64_t B, const double* q, double* pos_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEXR_H */

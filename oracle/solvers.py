@@ -129,7 +129,10 @@ def _model(prob, x, ref, fixed, last, kw, exact_loss_hessian=True, newton=False)
         val, der = smooth_l1(r, beta)
         F = (val * w[..., None]).sum((1, 2))
         g = np.einsum("btc,btcn->bn", der * w[..., None], Jt)
-        psi = np.where(np.abs(r) < beta, 1.0 / beta, 1.0 / np.maximum(np.abs(r), 1e-30))  # IRLS majoriser
+        if exact_loss_hessian and newton:
+            psi = np.where(np.abs(r) < beta, 1.0 / beta, 0.0)  # true curvature of SmoothL1
+        else:
+            psi = np.where(np.abs(r) < beta, 1.0 / beta, 1.0 / np.maximum(np.abs(r), 1e-30))  # IRLS majoriser
         H = np.einsum("btc,btcn,btcm->bnm", psi * w[..., None], Jt, Jt)
         if newton:
             H = H + _second_order(prob, x, fixed, der * w[..., None])

@@ -1,0 +1,66 @@
+"""world_size-2 gloo tests (CPU) of the N > 1 path: contiguous sharding + one all-gather reassembles exactly what a
+single process would have produced.  The per-shard solver is injected (the HIP solve needs a GPU); what is
+tested is the partition, padding, ordering and state plumbing that bench.py / ShardedRetargeter rely on."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from dex_retargeting_amd.distributed import shard_bounds
+
+
+def test_shard_bounds_partition():
+    for B in (0, 1, 7, 64, 65536, 524288 + 3):
+        for world in (1, 2, 3, 8):
+            edges = [shard_bounds(B, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == B
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
+
+
+def _fake_solve(ref, fixed, last, state):
+    if state is not None:
+        state[:] = (state + 1) * 3
+    return (last * 2 + ref.reshape(ref.shape[0], -1).sum(1, keepdims=True)).astype(np.float32)
+
+
+def _worker(rank, world, port, B, out_dir):
+    import torch.distributed as dist
+
+    from dex_retargeting_amd.distributed import ShardedRetargeter
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(0)  # same inputs on every rank
+    ref = rng.standard_normal((B, 4, 3)).astype(np.float32)
+    last = rng.standard_normal((B, 16)).astype(np.float32)
+    state = np.arange(B, dtype=np.uint32)
+    sr = ShardedRetargeter(solve=_fake_solve, device="cpu")
+    q = sr.retarget(ref, None, last, state)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), q=q, state=state)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [10, 129])
+def test_two_rank_gloo_allgather_equals_single_process(tmp_path, B):
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, B, str(tmp_path)), nprocs=2, join=True)
+    rng = np.random.default_rng(0)
+    ref = rng.standard_normal((B, 4, 3)).astype(np.float32)
+    last = rng.standard_normal((B, 16)).astype(np.float32)
+    st = np.arange(B, dtype=np.uint32)
+    want = _fake_solve(ref, None, last, st)
+    for r in range(2):
+        got = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        assert np.array_equal(got["q"], want)
+        assert np.array_equal(got["state"], st)
