@@ -20,7 +20,7 @@ class DexrError(RuntimeError):
 
 class SolveOptions(C.Structure):
     _fields_ = [("max_iter", C.c_int32), ("tol", C.c_float), ("lambda0", C.c_float), ("newton", C.c_int32),
-                ("precision", C.c_int32)]
+                ("precision", C.c_int32), ("polish", C.c_int32)]
 
 
 EXPORTS = ["dexr_last_error", "dexr_version", "dexr_device_count", "dexr_default_options", "dexr_model_create",
@@ -32,6 +32,14 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    if not os.environ.get("DEXR_NO_TORCH_PRELOAD"):
+        # torch-ROCm bundles its own libamdhip64; whichever HIP runtime is loaded first serves the whole process.
+        # Let torch's win when torch is installed, so tensors / streams created by torch and the kernels launched by
+        # libdexr share one runtime (device-pointer entry points, bench.py).
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for the host-pointer API
+            pass
     if not os.path.exists(LIB_PATH):
         raise DexrError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950). dex_retargeting_amd has no CPU fallback.")

@@ -118,6 +118,20 @@ void apply_options(dexr::KernelParams& kp, const dexr_solve_options* opt) {
   if (const char* e = std::getenv("DEXR_MAX_BLIND")) kp.max_blind = std::atoi(e);  // developer knob
 }
 
+// Optional float64 polish: same kernel in double precision, started at the float32 answer (x0 = qout, in place),
+// regularised towards the ORIGINAL last_qpos.  Stream-ordered after the float32 launch.
+int polish_launch(const dexr_model* m, dexr::KernelParams kp, const dexr_solve_options* opt, hipStream_t st) {
+  int polish = opt ? opt->polish : -1;
+  if (polish < 0) polish = (m->h.kind == DEXR_KIND_POSITION || m->h.kind == DEXR_KIND_DEXPILOT) ? 12 : 0;
+  if (polish == 0) return DEXR_OK;
+  kp.x0 = kp.qout;
+  kp.max_iter = polish;
+  kp.tol *= 0.25f;
+  kp.fval = nullptr;  // fval/iters keep the float32 launch's diagnostics; status is the polish pass's verdict
+  if (kp.status) HIP_TRY(hipMemsetAsync(kp.status, 0, (size_t)kp.B * sizeof(int32_t), st));
+  return launch(m, dexr::MODE_SOLVE, 1, kp, st);
+}
+
 }  // namespace
 
 extern "C" {
@@ -139,6 +153,7 @@ void dexr_default_options(dexr_solve_options* opt) {
   opt->lambda0 = 1e-4f;
   opt->newton = 1;
   opt->precision = 0;
+  opt->polish = -1;
 }
 
 int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out) {
@@ -247,7 +262,9 @@ int dexr_retarget_dev(const dexr_model* m, int64_t B, const float* ref, const fl
   if (status_out) HIP_TRY(hipMemsetAsync(status_out, 0, (size_t)B * sizeof(int32_t), st));
   if (iters_out) HIP_TRY(hipMemsetAsync(iters_out, 0, (size_t)B * sizeof(int32_t), st));
   if (fval_out) HIP_TRY(hipMemsetAsync(fval_out, 0, (size_t)B * sizeof(float), st));
-  return launch(m, dexr::MODE_SOLVE, 0, kp, st);
+  int rc = launch(m, dexr::MODE_SOLVE, 0, kp, st);
+  if (rc != DEXR_OK) return rc;
+  return polish_launch(m, kp, opt, st);
 }
 
 static int retarget_host(const dexr_model* m, int64_t B, const float* ref, const float* fixed, const float* last,
@@ -293,6 +310,10 @@ static int retarget_host(const dexr_model* m, int64_t B, const float* ref, const
   kp.fval = d_fval.as<float>();
   int rc = launch(m, dexr::MODE_SOLVE, f64, kp, nullptr);
   if (rc != DEXR_OK) return rc;
+  if (!f64) {
+    rc = polish_launch(m, kp, opt, nullptr);
+    if (rc != DEXR_OK) return rc;
+  }
   HIP_TRY(hipDeviceSynchronize());
   if (q32) HIP_TRY(hipMemcpy(q32, d_q.p, q_b, hipMemcpyDeviceToHost));
   if (q64) HIP_TRY(hipMemcpy(q64, d_q64.p, nb * m->h.n_opt * sizeof(double), hipMemcpyDeviceToHost));

@@ -27,6 +27,7 @@ struct KernelParams {
   const float* __restrict__ ref;    // B x n_ref x 3
   const float* __restrict__ fixed;  // B x n_fixed
   const float* __restrict__ last;   // B x n_opt
+  const float* x0;                  // B x n_opt start point (NULL: start from `last`); may alias qout
   const double* __restrict__ xin;   // eval: B x n_opt ; fk: B x n_q
   uint32_t* state;                  // B
   float* qout;                      // B x n_opt
@@ -417,7 +418,9 @@ __global__ void __launch_bounds__(256) dexr_kernel(const KernelParams kp) {
   using LS = LaneSolver<NMAX, real>;
   using RT = RealTraits<real>;
   const int lane = threadIdx.x & 63;
-  const int wave_in_block = threadIdx.x >> 6;
+  // readfirstlane: tell the compiler the wave index (hence the component, every table address and every branch on
+  // table contents) is wave-uniform -> s_load / SGPR operands / scalar branches instead of per-lane loads + exec masks
+  const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int waves_per_block = blockDim.x >> 6;
   const int64_t wave_global = (int64_t)blockIdx.x * waves_per_block + wave_in_block;
   const int comp = (int)(wave_global % kp.n_comp);
@@ -447,6 +450,7 @@ __global__ void __launch_bounds__(256) dexr_kernel(const KernelParams kp) {
       if (sk == DEXR_SRC_OPT) {
         real v;
         if (MODE == MODE_EVAL) v = (real)kp.xin[item * kp.n_opt + tb.api[k]];
+        else if (kp.x0) v = (real)kp.x0[item * kp.n_opt + tb.api[k]];
         else v = (real)kp.last[item * kp.n_opt + tb.api[k]];
         S.xl[k] = (real)kp.last[item * kp.n_opt + tb.api[k]];
         S.x[k] = v;

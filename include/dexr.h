@@ -44,6 +44,9 @@ typedef struct dexr_solve_options {
   float lambda0;      /* initial Levenberg-Marquardt damping (default 1e-4)                */
   int32_t newton;     /* 1: add the second-order kinematic term to the Hessian (default 1) */
   int32_t precision;  /* 0: float32 arithmetic (default); 1: float64 arithmetic            */
+  int32_t polish;     /* float64 polishing iterations run after the float32 solve, started at its answer:
+                         -1 auto (default: 12 for position / DexPilot models, whose float32 rounding floor sits
+                         near 1e-4 rad; 0 for vector models), 0 off, n > 0 at most n iterations           */
 } dexr_solve_options;
 
 const char* dexr_last_error(void);
