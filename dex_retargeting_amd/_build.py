@@ -13,6 +13,7 @@ INCLUDE = os.path.join(REPO, "include")
 BUILD = os.path.join(REPO, "build")
 LIB = os.path.join(HERE, "libdexr.so")
 BUCKETS = (4, 8, 16, 24, 32)
+CHAIN_BUCKETS = (4,)
 VARIANTS = ((0, 0), (1, 0), (1, 1), (1, 2))  # (float64?, mode): f32 solve, f64 solve, f64 eval, f64 fk
 HEADERS = [os.path.join(CSRC, "dexr_kernel.hpp"), os.path.join(CSRC, "dexr_launch.hpp"),
            os.path.join(INCLUDE, "dexr.h"), os.path.join(INCLUDE, "dexr_tables.h")]
@@ -43,13 +44,26 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if force or _stale(api_o, [api_s] + HEADERS):
         jobs.append((api_s, api_o, []))
     inst_s = os.path.join(CSRC, "dexr_inst.hip")
+    # developer shortcut: DEXR_BUILD_ONLY="4,8" rebuilds only those buckets and reuses the other objects as they are
+    # (only valid while KernelParams / the launcher signature are unchanged)
+    only = os.environ.get("DEXR_BUILD_ONLY")
+    only = None if not only else {int(v) for v in only.split(",")}
     # biggest kernels first so the thread pool stays busy
     for n in sorted(BUCKETS, reverse=True):
         for f64, mode in VARIANTS:
+            if n == 32 and (f64, mode) == (0, 0):
+                continue  # bucket 32 serves float32 requests with its float64 kernel (see dexr_launch.hpp)
             o = os.path.join(BUILD, f"dexr_inst_{n}_{f64}_{mode}.o")
             objs.append(o)
+            if only is not None and n not in only and os.path.exists(o):
+                continue
             if force or _stale(o, [inst_s] + HEADERS):
                 jobs.append((inst_s, o, [f"-DDEXR_NMAX={n}", f"-DDEXR_F64={f64}", f"-DDEXR_MODE={mode}"]))
+    for n in CHAIN_BUCKETS:  # serial-chain specialisation, float32 solve only
+        o = os.path.join(BUILD, f"dexr_inst_chain_{n}_0_0.o")
+        objs.append(o)
+        if force or _stale(o, [inst_s] + HEADERS):
+            jobs.append((inst_s, o, [f"-DDEXR_NMAX={n}", "-DDEXR_F64=0", "-DDEXR_MODE=0", "-DDEXR_CHAIN=1"]))
 
     def compile_one(job):
         s, o, defs = job

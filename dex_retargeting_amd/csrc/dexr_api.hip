@@ -51,6 +51,7 @@ struct dexr_model {
   int bucket = 0;      // NMAX instantiation used for every component of this model
   int lds_frames = 1;  // max n_frame over components
   int lds_terms = 1;   // max n_term over components
+  bool chain = false;  // every component is a plain serial chain filling its bucket (CHAIN kernel applies)
 };
 
 namespace {
@@ -90,6 +91,7 @@ void fill_params(const dexr_model* m, dexr::KernelParams& kp, int64_t B) {
 // that the rows of ref/last they share are fetched by one CU.
 int launch(const dexr_model* m, int mode, int f64, const dexr::KernelParams& kp, hipStream_t st) {
   if (kp.B <= 0) return DEXR_OK;
+  if (m->bucket == 32 && mode == dexr::MODE_SOLVE) f64 = 1;  // see find_launcher: bucket 32 is float64 only
   const size_t real_sz = f64 ? 8 : 4;
   const size_t per_wave = 64 * real_sz * (size_t)(3 * m->lds_frames + 4 * m->lds_terms);
   int wpb = 4;
@@ -99,7 +101,7 @@ int launch(const dexr_model* m, int mode, int f64, const dexr::KernelParams& kp,
   const int64_t waves = tiles * kp.n_comp;
   const int64_t blocks = (waves + wpb - 1) / wpb;
   if (blocks > 0x7fffffffLL) return fail(DEXR_ERR_INVALID, "batch too large for one launch");
-  dexr::launch_fn fn = dexr::find_launcher(m->bucket, f64, mode);
+  dexr::launch_fn fn = dexr::find_launcher(m->bucket, f64, mode, m->chain);
   if (!fn) return fail(DEXR_ERR_UNSUPPORTED, "no kernel for bucket %d / f64=%d / mode=%d", m->bucket, f64, mode);
   hipError_t e = fn(kp, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, st);
   if (e != hipSuccess) return fail(DEXR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -123,7 +125,7 @@ void apply_options(dexr::KernelParams& kp, const dexr_solve_options* opt) {
 int polish_launch(const dexr_model* m, dexr::KernelParams kp, const dexr_solve_options* opt, hipStream_t st) {
   int polish = opt ? opt->polish : -1;
   if (polish < 0) polish = (m->h.kind == DEXR_KIND_POSITION || m->h.kind == DEXR_KIND_DEXPILOT) ? 12 : 0;
-  if (polish == 0) return DEXR_OK;
+  if (polish == 0 || m->bucket == 32) return DEXR_OK;  // bucket 32 already ran in float64
   kp.x0 = kp.qout;
   kp.max_iter = polish;
   kp.tol *= 0.25f;
@@ -211,6 +213,14 @@ int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out) {
     if (c.n_term > m->lds_terms) m->lds_terms = c.n_term;
   }
   m->bucket = pick_bucket(maxj > 0 ? maxj : 1);
+  m->chain = (h.kind == DEXR_KIND_VECTOR || h.kind == DEXR_KIND_POSITION) && !std::getenv("DEXR_NO_CHAIN");
+  for (const dexr_comp_table& c : m->comps) {
+    if (c.n_joint != m->bucket) m->chain = false;
+    for (int k = 0; k < c.n_joint && m->chain; ++k)
+      if (c.restore[k] != (k == 0 ? -2 : -1) || c.save[k] != -1 || c.src_kind[k] != DEXR_SRC_OPT ||
+          c.jtype[k] != DEXR_JOINT_REVOLUTE)
+        m->chain = false;
+  }
   if (m->bucket < 0) {
     delete m;
     return fail(DEXR_ERR_UNSUPPORTED, "component with %d joints exceeds the largest kernel bucket", maxj);

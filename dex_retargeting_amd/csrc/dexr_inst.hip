@@ -5,6 +5,9 @@
 #ifndef DEXR_NMAX
 #error "DEXR_NMAX not defined"
 #endif
+#ifndef DEXR_CHAIN
+#define DEXR_CHAIN 0
+#endif
 
 namespace dexr {
 #if DEXR_F64
@@ -16,9 +19,15 @@ typedef float inst_real;
 #define DEXR_CAT_(a, b, c, d) a##b##_##c##_##d
 #define DEXR_CAT(a, b, c, d) DEXR_CAT_(a, b, c, d)
 
-hipError_t DEXR_CAT(launch_, DEXR_NMAX, DEXR_F64, DEXR_MODE)(const KernelParams& kp, dim3 grid, dim3 block, size_t lds,
-                                                          hipStream_t st) {
-  hipLaunchKernelGGL((dexr_kernel<DEXR_NMAX, inst_real, DEXR_MODE>), grid, block, lds, st, kp);
+#if DEXR_CHAIN
+#define DEXR_PREFIX launch_chain_
+#else
+#define DEXR_PREFIX launch_
+#endif
+
+hipError_t DEXR_CAT(DEXR_PREFIX, DEXR_NMAX, DEXR_F64, DEXR_MODE)(const KernelParams& kp, dim3 grid, dim3 block, size_t lds,
+                                                              hipStream_t st) {
+  hipLaunchKernelGGL((dexr_kernel<DEXR_NMAX, inst_real, DEXR_MODE, (DEXR_CHAIN != 0)>), grid, block, lds, st, kp, kp.comps);
   return hipGetLastError();
 }
 }  // namespace dexr

@@ -20,6 +20,10 @@
 
 #include "dexr_tables.h"
 
+#ifndef DEXR_CHAIN_MINW
+#define DEXR_CHAIN_MINW 3  // minimum waves per SIMD requested for the serial-chain kernel (caps its VGPR budget)
+#endif
+
 namespace dexr {
 
 struct KernelParams {
@@ -80,7 +84,10 @@ template <> struct RealTraits<double> {
   static __device__ __forceinline__ double eps() { return 1.1102230246251565e-16; }
 };
 
-template <int NMAX, typename real>
+// CHAIN = true prunes, at compile time, everything a plain serial chain does not need: the component is one
+// unbranched chain of exactly NMAX revolute joints hanging off the base, every joint is an optimised variable (no
+// mimic / fixed-valued joints).  An Allegro or LEAP finger under VectorOptimizer is exactly that.
+template <int NMAX, typename real, bool CHAIN = false>
 struct LaneSolver {
   static constexpr int NH = NMAX * (NMAX + 1) / 2;
   using RT = RealTraits<real>;
@@ -121,8 +128,8 @@ struct LaneSolver {
     }
 #pragma unroll
     for (int k = 0; k < NMAX; ++k) {
-      if (k < nj) {
-        const int rs = tb.restore[k];
+      if (CHAIN || k < nj) {
+        const int rs = CHAIN ? (k == 0 ? -2 : -1) : tb.restore[k];
         if (rs == -2) {
           R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
           p[0] = 0; p[1] = 0; p[2] = 0;
@@ -147,11 +154,11 @@ struct LaneSolver {
           for (int j = 0; j < 3; ++j)
             Rn[3 * i + j] = R[3 * i] * (real)X[j] + R[3 * i + 1] * (real)X[3 + j] + R[3 * i + 2] * (real)X[6 + j];
         real q = x[k];
-        if (tb.src_kind[k] == DEXR_SRC_MIMIC) {  // kinematics_adaptor.py:102-105
+        if (!CHAIN && tb.src_kind[k] == DEXR_SRC_MIMIC) {  // kinematics_adaptor.py:102-105
           q = (real)tb.mult[k] * pick(x, tb.src_idx[k]) + (real)tb.off[k];
           x[k] = q;
         }
-        if (tb.jtype[k] == DEXR_JOINT_REVOLUTE) {
+        if (CHAIN || tb.jtype[k] == DEXR_JOINT_REVOLUTE) {
           real s, c;
           RT::sincos(q, &s, &c);
 #pragma unroll
@@ -172,7 +179,7 @@ struct LaneSolver {
           ax[k][i] = R[3 * i + 2];
           og[k][i] = p[i];
         }
-        const int sv = tb.save[k];
+        const int sv = CHAIN ? -1 : tb.save[k];
         if (sv >= 0) {
 #pragma unroll
           for (int s = 0; s < DEXR_NSLOT; ++s)
@@ -263,7 +270,7 @@ struct LaneSolver {
         for (int k = 0; k < NMAX; ++k) {
           if ((mu >> k) & 1u) {
             const bool in_t = (mt >> k) & 1u, in_o = (mo >> k) & 1u;
-            if (tb.jtype[k] == DEXR_JOINT_REVOLUTE) {
+            if (CHAIN || tb.jtype[k] == DEXR_JOINT_REVOLUTE) {
               real v[3] = {0, 0, 0};
               if (in_t) {
 #pragma unroll
@@ -303,7 +310,7 @@ struct LaneSolver {
                 if ((mu >> cc) & 1u) {
                   real h = cw0 * col[cc][0] + cw1 * col[cc][1] + cw2 * col[cc][2] - ku * u[cc];
                   const bool same = (((mt >> cc) & (mt >> rr)) | ((mo >> cc) & (mo >> rr))) & 1u;
-                  if (newton && same && tb.jtype[cc] == DEXR_JOINT_REVOLUTE)
+                  if (newton && same && (CHAIN || tb.jtype[cc] == DEXR_JOINT_REVOLUTE))
                     h += ax[cc][0] * cf0 + ax[cc][1] * cf1 + ax[cc][2] * cf2;
                   H[hidx(rr, cc)] += h;
                 }
@@ -319,6 +326,7 @@ struct LaneSolver {
   // ---- mimic fold (kinematics_adaptor.py:107-113) applied to g (and H): x_k = m * x_s + b ------------------
   template <bool WITH_H>
   __device__ __forceinline__ void fold_mimic(const dexr_comp_table& tb, int nj) {
+    if (CHAIN) return;
     for (int k = 0; k < nj; ++k) {
       if (tb.src_kind[k] != DEXR_SRC_MIMIC) continue;
       const int s = tb.src_idx[k];
@@ -412,10 +420,10 @@ struct LaneSolver {
 // ------------------------------------------------------------------------------------------------------------
 // Kernel: one wave = 64 items x one component.  blockDim.x = 64 * waves_per_block; dynamic LDS =
 // waves_per_block * 64 * sizeof(real) * (3*lds_frames + 4*lds_terms).
-template <int NMAX, typename real, int MODE>
-__global__ void __launch_bounds__(256) dexr_kernel(const KernelParams kp) {
+template <int NMAX, typename real, int MODE, bool CHAIN = false>
+__global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4) ? DEXR_CHAIN_MINW : 1) dexr_kernel(const KernelParams kp, const dexr_comp_table* __restrict__ comps) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  using LS = LaneSolver<NMAX, real>;
+  using LS = LaneSolver<NMAX, real, CHAIN>;
   using RT = RealTraits<real>;
   const int lane = threadIdx.x & 63;
   // readfirstlane: tell the compiler the wave index (hence the component, every table address and every branch on
@@ -435,8 +443,10 @@ __global__ void __launch_bounds__(256) dexr_kernel(const KernelParams kp) {
   real* T = P + 64 * 3 * kp.lds_frames;
   real* W = T + 64 * 3 * kp.lds_terms;
 
-  const dexr_comp_table& tb = kp.comps[comp];
-  const int nj = tb.n_joint, nt = tb.n_term;
+  // `comps` is a separate __restrict__ kernel argument (not a struct member) so that the compiler may treat the
+  // tables as invariant and read them with scalar loads
+  const dexr_comp_table& tb = comps[comp];
+  const int nj = CHAIN ? NMAX : tb.n_joint, nt = tb.n_term;
 
   LS S;
   uint32_t vmask = 0;   // joints that carry an optimisation variable (directly or as a mimic)
@@ -445,8 +455,8 @@ __global__ void __launch_bounds__(256) dexr_kernel(const KernelParams kp) {
   for (int k = 0; k < NMAX; ++k) {
     S.x[k] = 0;
     S.xl[k] = 0;
-    if (k < nj) {
-      const int sk = tb.src_kind[k];
+    if (CHAIN || k < nj) {
+      const int sk = CHAIN ? DEXR_SRC_OPT : tb.src_kind[k];
       if (sk == DEXR_SRC_OPT) {
         real v;
         if (MODE == MODE_EVAL) v = (real)kp.xin[item * kp.n_opt + tb.api[k]];
@@ -485,6 +495,7 @@ __global__ void __launch_bounds__(256) dexr_kernel(const KernelParams kp) {
   }
 
   // ---- per-term targets (and DexPilot weights / projection state) ------------------------------------------
+  uint32_t nst_out = 0;  // written back at the very end: no global store may precede the (invariant) table loads
   if (kp.kind == DEXR_KIND_DEXPILOT) {
     // optimizer.py:462-508.  Terms are the model's vectors in order: pairs first, then wrist->finger.
     const int F = kp.num_fingers;
@@ -536,7 +547,7 @@ __global__ void __launch_bounds__(256) dexr_kernel(const KernelParams kp) {
       for (int i = 0; i < 3; ++i) T[(t * 3 + i) * 64 + lane] = (real)tv[i];
       W[t * 64 + lane] = (real)wt;
     }
-    if (kp.state && valid && comp == 0) kp.state[item] = nst;
+    nst_out = nst;
   } else {
     const float sc = (kp.kind == DEXR_KIND_VECTOR) ? kp.scaling : 1.f;
     for (int t = 0; t < nt; ++t) {
@@ -553,6 +564,7 @@ __global__ void __launch_bounds__(256) dexr_kernel(const KernelParams kp) {
     const real f = S.template residuals<1>(tb, kp, nt, vmask, P, T, W, lane);
     S.template fold_mimic<false>(tb, nj);
     if (valid) {
+      if (kp.kind == DEXR_KIND_DEXPILOT && kp.state && comp == 0) kp.state[item] = nst_out;
       atomicAdd(&kp.f64out[item], (double)f);
 #pragma unroll
       for (int k = 0; k < NMAX; ++k)
@@ -575,8 +587,117 @@ __global__ void __launch_bounds__(256) dexr_kernel(const KernelParams kp) {
   real sprev = (real)1e30;
   real xo[NMAX];
 
+  real F;
+  if constexpr (NMAX <= 8) {
+    // ---- small components: the accepted quadratic model (Hs, gs) stays in registers, so every iteration costs
+    // ONE forward-kinematics pass + ONE fused value/gradient/Hessian assembly at the trial point + one Cholesky;
+    // a rejected step costs only the re-solve with more damping.
+    real Hs[LS::NH], gs[NMAX];
+    S.fk(tb, nj, P, lane);
+    F = S.template residuals<2>(tb, kp, nt, vmask, P, T, W, lane);
+    S.template fold_mimic<true>(tb, nj);
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+      if ((optmask >> k) & 1u) {
+        const real dx = S.x[k] - S.xl[k];
+        F += delta * dx * dx;
+        gs[k] = S.g[k] + (real)2 * delta * dx;
+      } else {
+        gs[k] = 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < LS::NH; ++i) Hs[i] = S.H[i];
+
+    for (int it = 0; it < kp.max_iter; ++it) {
+      if (__all(done)) break;
+      uint32_t freemask = 0;
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k) {
+        const bool isopt = (optmask >> k) & 1u;
+        const bool act = (S.x[k] <= (real)tb.lo[k] && gs[k] > 0) || (S.x[k] >= (real)tb.hi[k] && gs[k] < 0);
+        if (isopt && !act) freemask |= 1u << k;
+        S.g[k] = (isopt && !act) ? gs[k] : (real)0;
+      }
+#pragma unroll
+      for (int rr = 0; rr < NMAX; ++rr) {
+        const bool fr = (freemask >> rr) & 1u;
+#pragma unroll
+        for (int cc = 0; cc < rr; ++cc) {
+          const bool fc = (freemask >> cc) & 1u;
+          S.H[LS::hidx(rr, cc)] = (fr && fc) ? Hs[LS::hidx(rr, cc)] : (real)0;
+        }
+        S.H[LS::hidx(rr, rr)] = fr ? Hs[LS::hidx(rr, rr)] + (real)2 * delta + lam : (real)1;
+      }
+      real gm[NMAX];
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k) gm[k] = S.g[k];
+      real d[NMAX];
+      const bool ok = S.chol_solve(d);
+      real smax = 0, pred = 0;
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k) {
+        xo[k] = S.x[k];
+        if ((optmask >> k) & 1u) {
+          const real xt = fmin(fmax(S.x[k] + d[k], (real)tb.lo[k]), (real)tb.hi[k]);
+          pred += (real)0.5 * d[k] * (lam * d[k] - gm[k]);
+          smax = fmax(smax, fabs(xt - S.x[k]));
+          if (!done) S.x[k] = xt;
+        }
+      }
+      S.fk(tb, nj, P, lane);
+      real Ft = S.template residuals<2>(tb, kp, nt, vmask, P, T, W, lane);
+      S.template fold_mimic<true>(tb, nj);
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k) {
+        if ((optmask >> k) & 1u) {
+          const real dx = S.x[k] - S.xl[k];
+          Ft += delta * dx * dx;
+          S.g[k] += (real)2 * delta * dx;
+        } else {
+          S.g[k] = 0;
+        }
+      }
+      const real noise = (real)16 * RT::eps() * fabs(F);
+      const bool finite = (Ft == Ft) && (smax == smax) && (fabs(Ft) < (real)1e30);
+      const bool below_floor = ok && finite && (pred <= noise) && (smax < (real)1e-2);
+      const bool accept = !done && ok && finite && ((Ft <= F) || below_floor);
+      if (!done) {
+        ++my_iters;
+        if (accept) {
+          const real rho = (F - Ft) / fmax(pred, (real)1e-30);
+          const real t = (real)2 * rho - (real)1;
+          // below the floor rho is noise: trust the model and relax the damping so the steps become Newton steps
+          lam = fmax(lam * (below_floor ? (real)(1.0 / 3.0) : fmax((real)(1.0 / 3.0), (real)1 - t * t * t)), (real)1e-9);
+          nu = 2;
+          F = Ft;
+          const bool stalled = below_floor && blind >= 2 && smax > (real)0.9 * sprev && smax < (real)20 * (real)kp.tol;
+          blind = below_floor ? blind + 1 : 0;
+          sprev = smax;
+          if (smax < (real)kp.tol || stalled || blind >= kp.max_blind) {
+            done = true;
+            status = ST_CONVERGED;
+          }
+        } else {
+          lam = fmax(lam, (real)1e-6) * nu;
+          nu *= 2;
+          if (lam > (real)1e10) {
+            done = true;
+            status = finite ? ST_CONVERGED : ST_FALLBACK;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k) {
+        S.x[k] = accept ? S.x[k] : xo[k];
+        gs[k] = accept ? S.g[k] : gs[k];
+      }
+#pragma unroll
+      for (int i = 0; i < LS::NH; ++i) Hs[i] = accept ? S.H[i] : Hs[i];
+    }
+  } else {
   S.fk(tb, nj, P, lane);
-  real F = S.template residuals<0>(tb, kp, nt, vmask, P, T, W, lane);
+  F = S.template residuals<0>(tb, kp, nt, vmask, P, T, W, lane);
 #pragma unroll
   for (int k = 0; k < NMAX; ++k)
     if ((optmask >> k) & 1u) F += delta * (S.x[k] - S.xl[k]) * (S.x[k] - S.xl[k]);
@@ -645,7 +766,7 @@ __global__ void __launch_bounds__(256) dexr_kernel(const KernelParams kp) {
         F = Ft;
         // below the floor, progress is judged by the step length alone: stop when it is under tol, when it no
         // longer contracts (rounding noise of the gradient reached), or after max_blind such steps.
-        const bool stalled = below_floor && blind >= 1 && smax > (real)0.9 * sprev;
+        const bool stalled = below_floor && blind >= 2 && smax > (real)0.9 * sprev && smax < (real)20 * (real)kp.tol;
         blind = below_floor ? blind + 1 : 0;
         sprev = smax;
         if (smax < (real)kp.tol || stalled || blind >= kp.max_blind) {
@@ -669,6 +790,8 @@ __global__ void __launch_bounds__(256) dexr_kernel(const KernelParams kp) {
     if (__any(redo)) S.fk(tb, nj, P, lane);  // rejected lanes: bring ax/og/P back to their (unchanged) x
   }
 
+  }
+
   // non-finite guard: hand back last_qpos like the reference's RuntimeError path (optimizer.py:100-102)
   bool bad = false;
 #pragma unroll
@@ -685,6 +808,7 @@ __global__ void __launch_bounds__(256) dexr_kernel(const KernelParams kp) {
         if (kp.qout64) kp.qout64[item * kp.n_opt + tb.api[k]] = (double)v;
       }
     }
+    if (kp.kind == DEXR_KIND_DEXPILOT && kp.state && comp == 0) kp.state[item] = nst_out;
     if (kp.status) atomicMax(&kp.status[item], status);
     if (kp.iters) atomicMax(&kp.iters[item], my_iters);
     if (kp.fval) atomicAdd(&kp.fval[item], (float)F);

@@ -7,8 +7,13 @@
 namespace dexr {
 typedef hipError_t (*launch_fn)(const KernelParams& kp, dim3 grid, dim3 block, size_t lds, hipStream_t st);
 
+#define DEXR_DECL_F32(N) hipError_t launch_##N##_0_0(const KernelParams&, dim3, dim3, size_t, hipStream_t); /* f32 solve */
+DEXR_DECL_F32(4)
+DEXR_DECL_F32(8)
+DEXR_DECL_F32(16)
+DEXR_DECL_F32(24)
+#undef DEXR_DECL_F32
 #define DEXR_DECL(N)                                                                          \
-  hipError_t launch_##N##_0_0(const KernelParams&, dim3, dim3, size_t, hipStream_t); /* f32 solve */ \
   hipError_t launch_##N##_1_0(const KernelParams&, dim3, dim3, size_t, hipStream_t); /* f64 solve */ \
   hipError_t launch_##N##_1_1(const KernelParams&, dim3, dim3, size_t, hipStream_t); /* f64 eval  */ \
   hipError_t launch_##N##_1_2(const KernelParams&, dim3, dim3, size_t, hipStream_t); /* f64 fk    */
@@ -18,13 +23,27 @@ DEXR_DECL(16)
 DEXR_DECL(24)
 DEXR_DECL(32)
 #undef DEXR_DECL
+// serial-chain specialisation (see LaneSolver's CHAIN flag): float32 solve, 4-joint bucket
+hipError_t launch_chain_4_0_0(const KernelParams&, dim3, dim3, size_t, hipStream_t);
 
-static inline launch_fn find_launcher(int bucket, int f64, int mode) {
+static inline launch_fn find_launcher(int bucket, int f64, int mode, bool chain = false) {
+  if (chain && bucket == 4 && !f64 && mode == MODE_SOLVE) return launch_chain_4_0_0;
 #define DEXR_CASE(N)                                                  \
   if (bucket == N) {                                                  \
-    if (mode == MODE_SOLVE) return f64 ? launch_##N##_1_0 : launch_##N##_0_0; \
+    if (mode == MODE_SOLVE && f64) return launch_##N##_1_0;            \
     if (mode == MODE_EVAL) return launch_##N##_1_1;                   \
     if (mode == MODE_FK) return launch_##N##_1_2;                     \
+  }
+  if (mode == MODE_SOLVE && !f64) {
+    // the 32-joint bucket has no float32 instantiation (528-entry Hessian per lane does not fit the register file
+    // in either precision; one kernel is enough there): float32 requests run the float64 kernel
+    switch (bucket) {
+      case 4: return launch_4_0_0;
+      case 8: return launch_8_0_0;
+      case 16: return launch_16_0_0;
+      case 24: return launch_24_0_0;
+      case 32: return launch_32_1_0;
+    }
   }
   DEXR_CASE(4) DEXR_CASE(8) DEXR_CASE(16) DEXR_CASE(24) DEXR_CASE(32)
 #undef DEXR_CASE

@@ -1,0 +1,121 @@
+"""Device-resident batched SeqRetargeting.
+
+B independent sequences advance in lock-step; every piece of per-sequence state the reference keeps on its
+``SeqRetargeting`` / ``LPFilter`` / ``DexPilotOptimizer`` objects lives in HBM as a torch tensor and never visits the
+host between frames:
+
+* ``last_qpos``   (B, n_opt) f32 -- the UNFILTERED previous solution (seq_retarget.py:124), clipped to the joint limits
+  before it is used as start point and regularisation target (seq_retarget.py:118-120);
+* ``filtered``    (B, dof)  f64 -- LPFilter.y (optimizer_utils.py:7-13): first frame passes through, then
+  ``y += alpha (x - y)``;
+* ``state``       (B,) int32  -- DexPilot projection bits (optimizer.py:466-476).
+
+One frame = one ``dexr_retarget_dev`` enqueue on the current torch stream (+ its float64 polish launch for position /
+DexPilot models) and a handful of element-wise torch ops (compose robot qpos, mimic fill, EMA); nothing synchronises,
+so T frames can be captured into one HIP graph (``torch.cuda.CUDAGraph``) and replayed.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from .kinematics_adaptor import MimicJointKinematicAdaptor
+from .optimizer import Optimizer
+
+
+class DeviceSeqRetargeting:
+    def __init__(self, optimizer: Optimizer, batch: int, has_joint_limits: bool = True,
+                 low_pass_alpha: Optional[float] = None, device: str = "cuda:0"):
+        import torch
+
+        self.torch = torch
+        self.optimizer = optimizer
+        self.batch = int(batch)
+        self.device = torch.device(device)
+        robot = optimizer.robot
+        joint_limits = np.ones_like(robot.joint_limits)
+        joint_limits[:, 0], joint_limits[:, 1] = -1e4, 1e4
+        if has_joint_limits:
+            joint_limits[:] = robot.joint_limits[:]
+            optimizer.set_joint_limit(joint_limits[optimizer.idx_pin2target])
+        self.joint_limits = joint_limits[optimizer.idx_pin2target]
+        self.alpha = low_pass_alpha if (low_pass_alpha is not None and 0 <= low_pass_alpha <= 1) else None
+        self.model = optimizer.device_model()
+        self.n_opt = optimizer.opt_dof
+        self.n_fixed = len(optimizer.idx_pin2fixed)
+        self.dexpilot = optimizer.retargeting_type == "DEXPILOT"
+        dev = self.device
+        self._lo = torch.tensor(self.joint_limits[:, 0], dtype=torch.float32, device=dev)
+        self._hi = torch.tensor(self.joint_limits[:, 1], dtype=torch.float32, device=dev)
+        self._idx_t = torch.tensor(optimizer.idx_pin2target, dtype=torch.long, device=dev)
+        self._idx_f = torch.tensor(optimizer.idx_pin2fixed, dtype=torch.long, device=dev)
+        ad = optimizer.adaptor
+        self._mimic = None
+        if isinstance(ad, MimicJointKinematicAdaptor):
+            self._mimic = (torch.tensor(ad.idx_pin2mimic, dtype=torch.long, device=dev),
+                           torch.tensor(ad.idx_pin2source, dtype=torch.long, device=dev),
+                           torch.tensor(ad.multipliers, dtype=torch.float64, device=dev),
+                           torch.tensor(ad.offsets, dtype=torch.float64, device=dev))
+        self._opts = optimizer._options()
+        # persistent buffers (fixed addresses -> graph-capturable)
+        B = self.batch
+        self.last_qpos = torch.empty((B, self.n_opt), dtype=torch.float32, device=dev)
+        self._last_clipped = torch.empty_like(self.last_qpos)
+        self._q = torch.empty_like(self.last_qpos)
+        self._status = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.state = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.robot_qpos = torch.zeros((B, robot.dof), dtype=torch.float64, device=dev)
+        self.filtered = torch.zeros_like(self.robot_qpos)
+        self._no_fixed = torch.zeros((B, max(self.n_fixed, 1)), dtype=torch.float32, device=dev)
+        self.reset()
+
+    def reset(self):
+        mid = self.torch.tensor(self.joint_limits.mean(1).astype(np.float32), device=self.device)
+        self.last_qpos.copy_(mid[None].expand(self.batch, -1))
+        self.state.zero_()
+        self._filter_init = False
+        self.num_retargeting = 0
+
+    def set_qpos(self, target_qpos):
+        """(B, n_opt) start point for the next frame (== SeqRetargeting.set_qpos per sequence)."""
+        self.last_qpos.copy_(self.torch.as_tensor(target_qpos, dtype=self.torch.float32, device=self.device))
+
+    def retarget(self, ref_value, fixed_qpos=None):
+        """ref_value: (B, n_ref, 3) float32 CUDA tensor (contiguous).  Returns the (B, dof) float64 CUDA tensor of
+        filtered robot qpos in pinocchio dof order (a view of an internal buffer, overwritten by the next call)."""
+        torch = self.torch
+        B = self.batch
+        if ref_value.dtype != torch.float32 or not ref_value.is_contiguous() or ref_value.device != self.device:
+            ref_value = ref_value.to(device=self.device, dtype=torch.float32).contiguous()
+        fixed = self._no_fixed
+        if self.n_fixed:
+            if fixed_qpos is None:
+                raise ValueError(f"Optimizer has {self.n_fixed} joints but non_target_qpos None is given")
+            fixed = fixed_qpos.to(device=self.device, dtype=torch.float32).contiguous()
+        torch.clamp(self.last_qpos, min=self._lo, max=self._hi, out=self._last_clipped)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.model.retarget_dev(B, ref_value.data_ptr(), fixed.data_ptr() if self.n_fixed else 0,
+                                self._last_clipped.data_ptr(), self.state.data_ptr() if self.dexpilot else 0,
+                                self._q.data_ptr(), status_ptr=self._status.data_ptr(), opts=self._opts, stream=stream)
+        # non-finite solve -> keep last_qpos, like the reference's RuntimeError branch (optimizer.py:100-102)
+        bad = (self._status == 2).unsqueeze(1)
+        self.last_qpos.copy_(torch.where(bad, self._last_clipped, self._q))
+        rq = self.robot_qpos
+        rq.zero_()
+        if self.n_fixed:
+            rq.index_copy_(1, self._idx_f, fixed.to(torch.float64))
+        rq.index_copy_(1, self._idx_t, self.last_qpos.to(torch.float64))
+        if self._mimic is not None:  # kinematics_adaptor.py:102-105
+            im, isrc, mul, off = self._mimic
+            rq.index_copy_(1, im, rq.index_select(1, isrc) * mul + off)
+        self.num_retargeting += 1
+        if self.alpha is None:
+            return rq
+        if not self._filter_init:
+            self.filtered.copy_(rq)
+            self._filter_init = True
+        else:
+            self.filtered.add_(rq - self.filtered, alpha=float(self.alpha))
+        return self.filtered

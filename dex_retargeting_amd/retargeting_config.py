@@ -159,6 +159,16 @@ class RetargetingConfig:
         return BatchedSeqRetargeting(optimizer, batch, has_joint_limits=self.has_joint_limits, low_pass_alpha=alpha)
 
 
+    def build_device(self, batch: int, device: str = "cuda:0"):
+        """B lock-step sequences with all per-sequence state resident on the GPU (torch tensors in / out)."""
+        from .device_seq import DeviceSeqRetargeting
+
+        optimizer = self._build_optimizer()
+        alpha = self.low_pass_alpha if 0 <= self.low_pass_alpha <= 1 else None
+        return DeviceSeqRetargeting(optimizer, batch, has_joint_limits=self.has_joint_limits, low_pass_alpha=alpha,
+                                    device=device)
+
+
 def get_retargeting_config(config_path: Union[str, Path]) -> RetargetingConfig:
     return RetargetingConfig.load_from_file(config_path)
 

@@ -83,8 +83,9 @@ def reachable_set(prob: OracleProblem, B: int, sigma: float, seed: int = SEED, d
     ref = fk_reference_values(prob, q)
     if prob.kind != "position" and divide_scaling:
         ref = ref / prob.scaling
-    return dict(ref=ref.astype(np.float32), fixed=q[:, prob.idx_pin2fixed].astype(np.float32),
-                last=init[:, prob.idx_pin2target].astype(np.float32), q_star=q[:, prob.idx_pin2target])
+    c = np.ascontiguousarray  # fancy indexing may hand back F-ordered memory; device pointers need C order
+    return dict(ref=c(ref, dtype=np.float32), fixed=c(q[:, prob.idx_pin2fixed], dtype=np.float32),
+                last=c(init[:, prob.idx_pin2target], dtype=np.float32), q_star=c(q[:, prob.idx_pin2target]))
 
 
 def human_keypoints(B: int, seed: int = SEED, noise: float = 2e-3) -> np.ndarray:
@@ -117,4 +118,5 @@ def human_set(prob: OracleProblem, B: int, seed: int = SEED, sigma: float = 0.05
         mid = lim.mean(1)[None].repeat(B, 0)
         last = np.clip(mid + sigma * rng.standard_normal(mid.shape), lim[:, 0], lim[:, 1])
     fixed = np.zeros((B, len(prob.idx_pin2fixed)), dtype=np.float32)
-    return dict(ref=ref.astype(np.float32), fixed=fixed, last=last.astype(np.float32), kp=kp)
+    return dict(ref=np.ascontiguousarray(ref, dtype=np.float32), fixed=fixed,
+                last=np.ascontiguousarray(last, dtype=np.float32), kp=kp)

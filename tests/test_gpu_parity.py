@@ -317,3 +317,23 @@ def test_device_pointer_entry_point_matches_host_path():
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), want)
     assert int(status.max()) == 0
+
+
+@pytest.mark.parametrize("rel", ["teleop/inspire_hand_right_dexpilot.yml", "teleop/allegro_hand_right.yml",
+                                 "offline/ability_hand_right.yml"])
+def test_device_resident_sequences_equal_host_batched(rel):
+    """DeviceSeqRetargeting (state in HBM, torch tensors in/out) == BatchedSeqRetargeting (host numpy state): the
+    carried solver state bitwise, the low-pass output to an ulp (the device EMA is one fused multiply-add)."""
+    torch = pytest.importorskip("torch")
+    cfg_path = os.path.join(cases.CONFIG_DIR, rel)
+    prob = cases.problem_from_config(rel)
+    B, T = 96, 6
+    kp = cases.human_keypoints(B * T).reshape(T, B, 21, 3)
+    host = RetargetingConfig.load_from_file(cfg_path).build_batched(B)
+    dev = RetargetingConfig.load_from_file(cfg_path).build_device(B)
+    for t in range(T):
+        ref = np.ascontiguousarray(cases.ref_from_keypoints(prob, kp[t]), dtype=np.float32)
+        a = host.retarget(ref)
+        b = dev.retarget(torch.from_numpy(ref).cuda()).cpu().numpy()
+        assert np.allclose(a, b, rtol=1e-13, atol=1e-15), t
+        assert np.array_equal(host.last_qpos, dev.last_qpos.cpu().numpy()), t
