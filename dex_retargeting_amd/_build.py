@@ -10,14 +10,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(REPO, "include")
-BUILD = os.path.join(REPO, "build")
-LIB = os.path.join(HERE, "libdexr.so")
+BUILD = os.environ.get("DEXR_BUILD_DIR") or os.path.join(REPO, "build")
+LIB = os.environ.get("DEXR_LIB_OUT") or os.path.join(HERE, "libdexr.so")
 BUCKETS = (4, 8, 16, 24, 32)
 CHAIN_BUCKETS = (4,)
 VARIANTS = ((0, 0), (1, 0), (1, 1), (1, 2))  # (float64?, mode): f32 solve, f64 solve, f64 eval, f64 fk
 HEADERS = [os.path.join(CSRC, "dexr_kernel.hpp"), os.path.join(CSRC, "dexr_launch.hpp"),
            os.path.join(INCLUDE, "dexr.h"), os.path.join(INCLUDE, "dexr_tables.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"] + \
+    os.environ.get("DEXR_EXTRA_FLAGS", "").split()
 
 
 def _hipcc() -> str:

@@ -9,7 +9,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdexr.so")
+LIB_PATH = os.environ.get("DEXR_LIB") or os.path.join(_HERE, "libdexr.so")  # DEXR_LIB: developer override
 
 _lib: Optional[C.CDLL] = None
 
@@ -25,7 +25,7 @@ class SolveOptions(C.Structure):
 
 EXPORTS = ["dexr_last_error", "dexr_version", "dexr_device_count", "dexr_default_options", "dexr_model_create",
            "dexr_model_destroy", "dexr_model_info", "dexr_retarget_dev", "dexr_retarget", "dexr_retarget_f64",
-           "dexr_eval", "dexr_fk"]
+           "dexr_retarget_kp_dev", "dexr_retarget_kp", "dexr_eval", "dexr_fk"]
 
 
 def load() -> C.CDLL:
@@ -58,6 +58,8 @@ def load() -> C.CDLL:
     lib.dexr_model_info.argtypes = [vp, C.c_void_p]
     lib.dexr_retarget_dev.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, optp, vp]
     lib.dexr_retarget.argtypes = [vp, i64, f32p, f32p, f32p, u32p, f32p, i32p, i32p, f32p, optp]
+    lib.dexr_retarget_kp_dev.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, optp, vp]
+    lib.dexr_retarget_kp.argtypes = [vp, i64, f32p, f32p, f32p, u32p, f32p, i32p, i32p, f32p, optp]
     lib.dexr_retarget_f64.argtypes = [vp, i64, f32p, f32p, f32p, u32p, f64p, i32p, i32p, optp]
     lib.dexr_eval.argtypes = [vp, i64, f32p, f32p, f32p, f64p, u32p, f64p, f64p]
     lib.dexr_fk.argtypes = [vp, i64, f64p, f64p]
@@ -105,7 +107,9 @@ class Model:
         return self._h
 
     # host-pointer entry points -------------------------------------------------------------------
-    def retarget(self, ref, fixed, last, state=None, opts: Optional[SolveOptions] = None, want_info=False):
+    def retarget(self, ref, fixed, last, state=None, opts: Optional[SolveOptions] = None, want_info=False,
+                 keypoints: bool = False):
+        """ref: (B,n_ref,3) ref_value rows, or with keypoints=True the raw (B,n_keypoints,3) hand keypoints."""
         lib = load()
         ref = np.ascontiguousarray(ref, dtype=np.float32)
         last = np.ascontiguousarray(last, dtype=np.float32)
@@ -115,10 +119,10 @@ class Model:
         status = np.zeros(B, dtype=np.int32)
         iters = np.zeros(B, dtype=np.int32)
         fval = np.zeros(B, dtype=np.float32)
-        check(lib.dexr_retarget(self._h, B, _ptr(ref, C.c_float), _ptr(fixed, C.c_float), _ptr(last, C.c_float),
-                                _ptr(state, C.c_uint32), _ptr(q, C.c_float), _ptr(status, C.c_int32),
-                                _ptr(iters, C.c_int32), _ptr(fval, C.c_float),
-                                C.byref(opts) if opts is not None else None))
+        fn = lib.dexr_retarget_kp if keypoints else lib.dexr_retarget
+        check(fn(self._h, B, _ptr(ref, C.c_float), _ptr(fixed, C.c_float), _ptr(last, C.c_float),
+                 _ptr(state, C.c_uint32), _ptr(q, C.c_float), _ptr(status, C.c_int32),
+                 _ptr(iters, C.c_int32), _ptr(fval, C.c_float), C.byref(opts) if opts is not None else None))
         if want_info:
             return q, dict(status=status, iters=iters, fval=fval)
         return q
@@ -163,8 +167,10 @@ class Model:
     # device-pointer entry point (torch tensors on the current device) ------------------------------
     def retarget_dev(self, B: int, ref_ptr: int, fixed_ptr: int, last_ptr: int, state_ptr: int, q_ptr: int,
                      status_ptr: int = 0, iters_ptr: int = 0, fval_ptr: int = 0,
-                     opts: Optional[SolveOptions] = None, stream: int = 0):
-        check(load().dexr_retarget_dev(self._h, B, ref_ptr or None, fixed_ptr or None, last_ptr or None,
-                                       state_ptr or None, q_ptr or None, status_ptr or None, iters_ptr or None,
-                                       fval_ptr or None, C.byref(opts) if opts is not None else None,
-                                       stream or None))
+                     opts: Optional[SolveOptions] = None, stream: int = 0, keypoints: bool = False):
+        """Enqueue on `stream`; all pointers are device addresses of C-contiguous arrays.  With keypoints=True
+        `ref_ptr` addresses raw (B,n_keypoints,3) hand keypoints instead of ref_value rows."""
+        fn = load().dexr_retarget_kp_dev if keypoints else load().dexr_retarget_dev
+        check(fn(self._h, B, ref_ptr or None, fixed_ptr or None, last_ptr or None,
+                 state_ptr or None, q_ptr or None, status_ptr or None, iters_ptr or None,
+                 fval_ptr or None, C.byref(opts) if opts is not None else None, stream or None))

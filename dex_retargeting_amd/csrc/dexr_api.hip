@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <new>
 #include <string>
@@ -52,6 +53,12 @@ struct dexr_model {
   int lds_frames = 1;  // max n_frame over components
   int lds_terms = 1;   // max n_term over components
   bool chain = false;  // every component is a plain serial chain filling its bucket (CHAIN kernel applies)
+  // work-queue heads for the persistent-lane kernels: QSLOTS independent sets of n_comp counters handed out
+  // round-robin, so launches in flight on different streams never share a queue
+  static constexpr int QSLOTS = 64;
+  unsigned* d_queue = nullptr;
+  mutable std::atomic<unsigned> qnext{0};
+  int n_cu = 256;
 };
 
 namespace {
@@ -85,11 +92,16 @@ void fill_params(const dexr_model* m, dexr::KernelParams& kp, int64_t B) {
   kp.eta2 = h.eta2;
   kp.lds_frames = m->lds_frames;
   kp.lds_terms = m->lds_terms;
+  kp.n_kp = h.n_keypoints;
+  for (int i = 0; i < DEXR_MAXT; ++i) {
+    kp.h_origin[i] = h.human_origin[i];
+    kp.h_task[i] = h.human_task[i];
+  }
 }
 
 // launch geometry: one wave per (64-item tile, component); waves of a block sit on consecutive components so
 // that the rows of ref/last they share are fetched by one CU.
-int launch(const dexr_model* m, int mode, int f64, const dexr::KernelParams& kp, hipStream_t st) {
+int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStream_t st) {
   if (kp.B <= 0) return DEXR_OK;
   if (m->bucket == 32 && mode == dexr::MODE_SOLVE) f64 = 1;  // see find_launcher: bucket 32 is float64 only
   const size_t real_sz = f64 ? 8 : 4;
@@ -98,7 +110,28 @@ int launch(const dexr_model* m, int mode, int f64, const dexr::KernelParams& kp,
   while (wpb > 1 && per_wave * wpb > 48 * 1024) wpb >>= 1;
   if (per_wave > 64 * 1024) return fail(DEXR_ERR_UNSUPPORTED, "component needs %zu B of LDS per wave", per_wave);
   const int64_t tiles = (kp.B + 63) / 64;
-  const int64_t waves = tiles * kp.n_comp;
+  int64_t waves = tiles * kp.n_comp;
+  if (mode == dexr::MODE_SOLVE && m->bucket <= 8) {
+    // persistent lanes (small components): a resident set of waves pulls frames from per-component queues
+    int occ = m->chain ? 3 : 2;  // waves per SIMD the kernels' register budgets allow
+    if (const char* e = std::getenv("DEXR_PERSIST_OCC")) occ = std::atoi(e) > 0 ? std::atoi(e) : occ;
+    const int64_t resident = (int64_t)m->n_cu * 4 * occ;
+    const int64_t per_comp = (resident + kp.n_comp - 1) / kp.n_comp;
+    // Few frames per lane: one 64-frame tile per wave (the queue then just numbers the tiles).  Many frames per
+    // lane: a resident set of waves drains the queue in larger chunks, which evens out the very different iteration
+    // counts of individual frames (measured: 1.0x at 65 536 Allegro frames, 2.4x at 1 M).
+    int64_t persist_from = 3;
+    if (const char* e = std::getenv("DEXR_PERSIST_FROM")) persist_from = std::atoi(e);
+    kp.qchunk = 0;  // tile mode: no queue traffic at all
+    if (tiles >= persist_from * per_comp) {
+      waves = per_comp * kp.n_comp;
+      kp.qchunk = 256;
+    }
+    const unsigned slot = m->qnext.fetch_add(1u) % dexr_model::QSLOTS;
+    kp.queue = m->d_queue + (size_t)slot * kp.n_comp;
+    hipError_t qe = hipMemsetAsync(kp.queue, 0, (size_t)kp.n_comp * sizeof(unsigned), st);
+    if (qe != hipSuccess) return fail(DEXR_ERR_HIP, "queue reset failed: %s", hipGetErrorString(qe));
+  }
   const int64_t blocks = (waves + wpb - 1) / wpb;
   if (blocks > 0x7fffffffLL) return fail(DEXR_ERR_INVALID, "batch too large for one launch");
   dexr::launch_fn fn = dexr::find_launcher(m->bucket, f64, mode, m->chain);
@@ -117,7 +150,9 @@ void apply_options(dexr::KernelParams& kp, const dexr_solve_options* opt) {
   kp.lam0 = o.lambda0 > 0 ? o.lambda0 : 1e-4f;
   kp.newton = o.newton;
   kp.max_blind = 8;
-  if (const char* e = std::getenv("DEXR_MAX_BLIND")) kp.max_blind = std::atoi(e);  // developer knob
+  if (const char* e = std::getenv("DEXR_MAX_BLIND")) kp.max_blind = std::atoi(e);  // developer knobs
+  if (const char* e = std::getenv("DEXR_MAX_ITER")) kp.max_iter = std::atoi(e);
+  if (const char* e = std::getenv("DEXR_NEWTON")) kp.newton = std::atoi(e);
 }
 
 // Optional float64 polish: same kernel in double precision, started at the float32 answer (x0 = qout, in place),
@@ -227,7 +262,15 @@ int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out) {
   }
   hipError_t e = hipMalloc((void**)&m->d_comps, m->comps.size() * sizeof(dexr_comp_table));
   if (e == hipSuccess) e = hipMemcpy(m->d_comps, m->comps.data(), m->comps.size() * sizeof(dexr_comp_table), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&m->d_queue, (size_t)dexr_model::QSLOTS * h.n_comp * sizeof(unsigned));
+  if (e == hipSuccess) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+      m->n_cu = cus;
+  }
   if (e != hipSuccess) {
+    if (m->d_queue) (void)hipFree(m->d_queue);
     if (m->d_comps) (void)hipFree(m->d_comps);
     delete m;
     return fail(DEXR_ERR_HIP, "uploading tables failed: %s", hipGetErrorString(e));
@@ -239,6 +282,7 @@ int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out) {
 void dexr_model_destroy(dexr_model* m) {
   if (!m) return;
   if (m->d_comps) (void)hipFree(m->d_comps);
+  if (m->d_queue) (void)hipFree(m->d_queue);
   delete m;
 }
 
@@ -248,11 +292,13 @@ int dexr_model_info(const dexr_model* m, dexr_model_header* header_out) {
   return DEXR_OK;
 }
 
-int dexr_retarget_dev(const dexr_model* m, int64_t B, const float* ref, const float* fixed, const float* last,
-                      uint32_t* state, float* qpos_out, int32_t* status_out, int32_t* iters_out, float* fval_out,
-                      const dexr_solve_options* opt, void* stream) {
+static int retarget_dev_impl(const dexr_model* m, int64_t B, const float* ref, bool ref_is_keypoints, const float* fixed,
+                             const float* last, uint32_t* state, float* qpos_out, int32_t* status_out,
+                             int32_t* iters_out, float* fval_out, const dexr_solve_options* opt, void* stream) {
   if (!m || !ref || !last || !qpos_out) return fail(DEXR_ERR_INVALID, "null argument");
   if (m->h.kind == DEXR_KIND_FKONLY) return fail(DEXR_ERR_INVALID, "model is an FK-only table");
+  if (ref_is_keypoints && m->h.n_keypoints <= 0)
+    return fail(DEXR_ERR_INVALID, "model carries no target_link_human_indices: keypoint input not available");
   if (m->h.n_fixed > 0 && !fixed) return fail(DEXR_ERR_INVALID, "model has %d fixed joints but fixed_qpos is NULL", m->h.n_fixed);
   if (B < 0) return fail(DEXR_ERR_INVALID, "negative batch");
   if (B == 0) return DEXR_OK;
@@ -261,7 +307,8 @@ int dexr_retarget_dev(const dexr_model* m, int64_t B, const float* ref, const fl
   dexr::KernelParams kp;
   fill_params(m, kp, B);
   apply_options(kp, opt);
-  kp.ref = ref;
+  if (ref_is_keypoints) kp.kpts = ref;
+  else kp.ref = ref;
   kp.fixed = fixed;
   kp.last = last;
   kp.state = state;
@@ -277,16 +324,31 @@ int dexr_retarget_dev(const dexr_model* m, int64_t B, const float* ref, const fl
   return polish_launch(m, kp, opt, st);
 }
 
+int dexr_retarget_dev(const dexr_model* m, int64_t B, const float* ref, const float* fixed, const float* last,
+                      uint32_t* state, float* qpos_out, int32_t* status_out, int32_t* iters_out, float* fval_out,
+                      const dexr_solve_options* opt, void* stream) {
+  return retarget_dev_impl(m, B, ref, false, fixed, last, state, qpos_out, status_out, iters_out, fval_out, opt, stream);
+}
+
+int dexr_retarget_kp_dev(const dexr_model* m, int64_t B, const float* keypoints, const float* fixed, const float* last,
+                         uint32_t* state, float* qpos_out, int32_t* status_out, int32_t* iters_out, float* fval_out,
+                         const dexr_solve_options* opt, void* stream) {
+  return retarget_dev_impl(m, B, keypoints, true, fixed, last, state, qpos_out, status_out, iters_out, fval_out, opt, stream);
+}
+
 static int retarget_host(const dexr_model* m, int64_t B, const float* ref, const float* fixed, const float* last,
                          uint32_t* state, float* q32, double* q64, int32_t* status_out, int32_t* iters_out,
-                         float* fval_out, const dexr_solve_options* opt, int f64) {
+                         float* fval_out, const dexr_solve_options* opt, int f64, bool ref_is_keypoints = false) {
   if (!m || !ref || !last || (!q32 && !q64)) return fail(DEXR_ERR_INVALID, "null argument");
   if (m->h.kind == DEXR_KIND_FKONLY) return fail(DEXR_ERR_INVALID, "model is an FK-only table");
+  if (ref_is_keypoints && m->h.n_keypoints <= 0)
+    return fail(DEXR_ERR_INVALID, "model carries no target_link_human_indices: keypoint input not available");
   if (m->h.n_fixed > 0 && !fixed) return fail(DEXR_ERR_INVALID, "model has %d fixed joints but fixed_qpos is NULL", m->h.n_fixed);
   if (B < 0) return fail(DEXR_ERR_INVALID, "negative batch");
   if (B == 0) return DEXR_OK;
   const size_t nb = (size_t)B;
-  const size_t ref_b = nb * m->h.n_ref * 3 * sizeof(float), fix_b = nb * m->h.n_fixed * sizeof(float);
+  const size_t ref_b = nb * (ref_is_keypoints ? m->h.n_keypoints : m->h.n_ref) * 3 * sizeof(float);
+  const size_t fix_b = nb * m->h.n_fixed * sizeof(float);
   const size_t q_b = nb * m->h.n_opt * sizeof(float);
   DevBuf d_ref, d_fix, d_last, d_state, d_q, d_q64, d_status, d_iters, d_fval;
   HIP_TRY(d_ref.alloc(ref_b));
@@ -309,7 +371,8 @@ static int retarget_host(const dexr_model* m, int64_t B, const float* ref, const
   dexr::KernelParams kp;
   fill_params(m, kp, B);
   apply_options(kp, opt);
-  kp.ref = d_ref.as<float>();
+  if (ref_is_keypoints) kp.kpts = d_ref.as<float>();
+  else kp.ref = d_ref.as<float>();
   kp.fixed = d_fix.as<float>();
   kp.last = d_last.as<float>();
   kp.state = d_state.as<uint32_t>();
@@ -339,6 +402,13 @@ int dexr_retarget(const dexr_model* m, int64_t B, const float* ref, const float*
                   const dexr_solve_options* opt) {
   if (opt && opt->precision != 0) return fail(DEXR_ERR_INVALID, "use dexr_retarget_f64 for float64 arithmetic");
   return retarget_host(m, B, ref, fixed, last, state, qpos_out, nullptr, status_out, iters_out, fval_out, opt, 0);
+}
+
+int dexr_retarget_kp(const dexr_model* m, int64_t B, const float* keypoints, const float* fixed, const float* last,
+                     uint32_t* state, float* qpos_out, int32_t* status_out, int32_t* iters_out, float* fval_out,
+                     const dexr_solve_options* opt) {
+  if (opt && opt->precision != 0) return fail(DEXR_ERR_INVALID, "keypoint entry point is float32 (+polish) only");
+  return retarget_host(m, B, keypoints, fixed, last, state, qpos_out, nullptr, status_out, iters_out, fval_out, opt, 0, true);
 }
 
 int dexr_retarget_f64(const dexr_model* m, int64_t B, const float* ref, const float* fixed, const float* last,

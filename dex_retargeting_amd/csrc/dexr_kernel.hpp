@@ -32,6 +32,8 @@ struct KernelParams {
   const float* __restrict__ fixed;  // B x n_fixed
   const float* __restrict__ last;   // B x n_opt
   const float* x0;                  // B x n_opt start point (NULL: start from `last`); may alias qout
+  const float* __restrict__ kpts;   // B x n_kp x 3 raw hand keypoints (NULL: `ref` holds ready-made ref_value rows)
+  unsigned* queue;                  // n_comp work-queue heads (persistent-lane kernels), zeroed before the launch
   const double* __restrict__ xin;   // eval: B x n_opt ; fk: B x n_q
   uint32_t* state;                  // B
   float* qout;                      // B x n_opt
@@ -49,6 +51,11 @@ struct KernelParams {
   int32_t newton;
   int32_t max_blind;  // accepted steps below the rounding floor of F before giving up on further progress
   int32_t lds_frames, lds_terms;  // per-wave LDS rows: max frames / max terms over the model's components
+  uint32_t qchunk;                // frames a wave takes from its component's queue per atomicAdd; 0 = tile mode
+                                  // (wave w owns frames [64*tile, 64*tile+64), no queue traffic)
+  int32_t n_kp;                   // keypoints per frame (21 for MediaPipe/MANO hands)
+  int32_t h_origin[DEXR_MAXT];    // target_link_human_indices[0] per ref row (-1: position row = kp[h_task])
+  int32_t h_task[DEXR_MAXT];      // target_link_human_indices[1] per ref row
 };
 
 enum { MODE_SOLVE = 0, MODE_EVAL = 1, MODE_FK = 2 };
@@ -62,6 +69,9 @@ template <> struct RealTraits<float> {
   // polynomials on [-pi/4, pi/4]; ~1 ulp, no scratch, no slow path (ocml's sincosf carries a Payne-Hanek
   // fallback that costs ~100 VGPRs and private memory inside this kernel).
   static __device__ __forceinline__ void sincos(float a, float* s, float* c) {
+#ifdef DEXR_EXP_FASTSINCOS
+    *s = __sinf(a); *c = __cosf(a); return;
+#endif
     const float kf = rintf(a * 0.63661977236758134f);
     float r = fmaf(-kf, 1.5707962513e+00f, a);
     r = fmaf(-kf, 7.5497894159e-08f, r);
@@ -83,6 +93,47 @@ template <> struct RealTraits<double> {
   static __device__ __forceinline__ void sincos(double a, double* s, double* c) { ::sincos(a, s, c); }
   static __device__ __forceinline__ double eps() { return 1.1102230246251565e-16; }
 };
+
+// Register-resident copy of one component's tables for small serial chains: every field is read with a compile-time
+// index inside fully unrolled loops, so the values live in SGPRs (or SGPRs spilled to VGPR lanes) for the whole
+// kernel instead of being re-fetched with s_load + s_waitcnt in every solver iteration (measured: 53 % of the wave
+// cycles of the first persistent kernel were spent parked on those waits).
+template <int NMAX>
+struct LocalTab {
+  static constexpr int LF = 4;  // frames kept locally
+  static constexpr int LT = 4;  // terms kept locally
+  int32_t n_joint, n_frame, n_term, n_base_frame;
+  float X[NMAX][12];
+  float lo[NMAX], hi[NMAX];
+  int32_t api[NMAX], fbeg[NMAX], fend[NMAX];
+  float frame_off[LF][3];
+  int32_t term_task[LT], term_origin[LT], term_ref[LT];
+  uint32_t term_mt[LT], term_mo[LT];  // ancestor masks of the task / origin frame of each term
+
+  __device__ __forceinline__ void load(const dexr_comp_table& tb) {
+    n_joint = tb.n_joint; n_frame = tb.n_frame; n_term = tb.n_term; n_base_frame = tb.n_base_frame;
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) X[k][i] = tb.X[k][i];
+      lo[k] = tb.lo[k]; hi[k] = tb.hi[k];
+      api[k] = tb.api[k]; fbeg[k] = tb.fbeg[k]; fend[k] = tb.fend[k];
+    }
+#pragma unroll
+    for (int f = 0; f < LF; ++f) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) frame_off[f][i] = tb.frame_off[f][i];
+    }
+#pragma unroll
+    for (int t = 0; t < LT; ++t) {
+      term_task[t] = tb.term_task[t]; term_origin[t] = tb.term_origin[t]; term_ref[t] = tb.term_ref[t];
+      term_mt[t] = (t < tb.n_term) ? tb.frame_anc[tb.term_task[t]] : 0u;
+      term_mo[t] = (t < tb.n_term && tb.term_origin[t] >= 0) ? tb.frame_anc[tb.term_origin[t]] : 0u;
+    }
+  }
+};
+template <typename TB> struct TabTraits { static constexpr bool LOCAL = false; };
+template <int N> struct TabTraits<LocalTab<N>> { static constexpr bool LOCAL = true; };
 
 // CHAIN = true prunes, at compile time, everything a plain serial chain does not need: the component is one
 // unbranched chain of exactly NMAX revolute joints hanging off the base, every joint is an optimised variable (no
@@ -114,7 +165,9 @@ struct LaneSolver {
 
   // ---- forward kinematics of the component's joint list ---------------------------------------------------
   // Writes ax/og for every joint and the world position of every frame to LDS  P[(f*3+c)*64 + lane].
-  __device__ __forceinline__ void fk(const dexr_comp_table& tb, int nj, real* P, int lane) {
+  template <typename TB>
+  __device__ __forceinline__ void fk(const TB& tb, int nj, real* P, int lane) {
+    constexpr bool LOCAL = TabTraits<TB>::LOCAL;  // LOCAL tables exist only for CHAIN kernels
     real R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     real p[3] = {0, 0, 0};
     real sR[DEXR_NSLOT][9];
@@ -129,7 +182,9 @@ struct LaneSolver {
 #pragma unroll
     for (int k = 0; k < NMAX; ++k) {
       if (CHAIN || k < nj) {
-        const int rs = CHAIN ? (k == 0 ? -2 : -1) : tb.restore[k];
+        int rs;
+        if constexpr (CHAIN) rs = (k == 0 ? -2 : -1);
+        else rs = tb.restore[k];
         if (rs == -2) {
           R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
           p[0] = 0; p[1] = 0; p[2] = 0;
@@ -154,11 +209,15 @@ struct LaneSolver {
           for (int j = 0; j < 3; ++j)
             Rn[3 * i + j] = R[3 * i] * (real)X[j] + R[3 * i + 1] * (real)X[3 + j] + R[3 * i + 2] * (real)X[6 + j];
         real q = x[k];
-        if (!CHAIN && tb.src_kind[k] == DEXR_SRC_MIMIC) {  // kinematics_adaptor.py:102-105
-          q = (real)tb.mult[k] * pick(x, tb.src_idx[k]) + (real)tb.off[k];
-          x[k] = q;
+        bool revolute = true;
+        if constexpr (!CHAIN) {
+          if (tb.src_kind[k] == DEXR_SRC_MIMIC) {  // kinematics_adaptor.py:102-105
+            q = (real)tb.mult[k] * pick(x, tb.src_idx[k]) + (real)tb.off[k];
+            x[k] = q;
+          }
+          revolute = tb.jtype[k] == DEXR_JOINT_REVOLUTE;
         }
-        if (CHAIN || tb.jtype[k] == DEXR_JOINT_REVOLUTE) {
+        if (revolute) {
           real s, c;
           RT::sincos(q, &s, &c);
 #pragma unroll
@@ -179,7 +238,8 @@ struct LaneSolver {
           ax[k][i] = R[3 * i + 2];
           og[k][i] = p[i];
         }
-        const int sv = CHAIN ? -1 : tb.save[k];
+        int sv = -1;
+        if constexpr (!CHAIN) sv = tb.save[k];
         if (sv >= 0) {
 #pragma unroll
           for (int s = 0; s < DEXR_NSLOT; ++s)
@@ -191,11 +251,24 @@ struct LaneSolver {
             }
         }
         const int fb = tb.fbeg[k], fe = tb.fend[k];
-        for (int f = fb; f < fe; ++f) {
-          const real o0 = (real)tb.frame_off[f][0], o1 = (real)tb.frame_off[f][1], o2 = (real)tb.frame_off[f][2];
+        if constexpr (LOCAL) {
 #pragma unroll
-          for (int i = 0; i < 3; ++i)
-            P[(f * 3 + i) * 64 + lane] = p[i] + R[3 * i] * o0 + R[3 * i + 1] * o1 + R[3 * i + 2] * o2;
+          for (int f = 0; f < TB::LF; ++f) {
+            if (f >= fb && f < fe) {
+              const real o0 = (real)tb.frame_off[f][0], o1 = (real)tb.frame_off[f][1], o2 = (real)tb.frame_off[f][2];
+#pragma unroll
+              for (int i = 0; i < 3; ++i)
+                P[(f * 3 + i) * 64 + lane] = p[i] + R[3 * i] * o0 + R[3 * i + 1] * o1 + R[3 * i + 2] * o2;
+            }
+          }
+        } else {
+#pragma clang loop unroll(disable) vectorize(disable)
+          for (int f = fb; f < fe; ++f) {
+            const real o0 = (real)tb.frame_off[f][0], o1 = (real)tb.frame_off[f][1], o2 = (real)tb.frame_off[f][2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+              P[(f * 3 + i) * 64 + lane] = p[i] + R[3 * i] * o0 + R[3 * i + 1] * o1 + R[3 * i + 2] * o2;
+          }
         }
       }
     }
@@ -204,9 +277,10 @@ struct LaneSolver {
   // ---- residuals (+ optional gradient / Hessian assembly) --------------------------------------------------
   // Returns the data term f(x) (reference "huber_distance", no regulariser).
   // ASM = 0: value only.  ASM = 1: value + g (data term only).  ASM = 2: value + g + H (data term only).
-  template <int ASM>
-  __device__ __forceinline__ real residuals(const dexr_comp_table& tb, const KernelParams& kp, int nt, uint32_t vmask,
+  template <int ASM, typename TB>
+  __device__ __forceinline__ real residuals(const TB& tb, const KernelParams& kp, int nt, uint32_t vmask,
                                             const real* P, const real* T, const real* W, int lane) {
+    constexpr bool LOCAL = TabTraits<TB>::LOCAL;
     const bool per_coord = (kp.kind == DEXR_KIND_POSITION);
     const bool weighted = (kp.kind == DEXR_KIND_DEXPILOT);
     const real beta = (real)kp.huber_delta;
@@ -220,8 +294,7 @@ struct LaneSolver {
 #pragma unroll
       for (int i = 0; i < NH; ++i) H[i] = 0;
     }
-    for (int t = 0; t < nt; ++t) {
-      const int ft = tb.term_task[t], fo = tb.term_origin[t];
+    auto term = [&](int t, int ft, int fo, uint32_t mt_in, uint32_t mo_in) {
       real pt[3], po[3] = {0, 0, 0}, r[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) pt[i] = P[(ft * 3 + i) * 64 + lane];
@@ -261,8 +334,8 @@ struct LaneSolver {
         kap = quad ? (real)0 : psi * id * id;
       }
       if (ASM >= 1) {
-        const uint32_t mt = tb.frame_anc[ft];
-        const uint32_t mo = (fo >= 0) ? tb.frame_anc[fo] : 0u;
+        const uint32_t mt = mt_in;
+        const uint32_t mo = mo_in;
         const uint32_t mu = (mt | mo) & vmask;
         real col[NMAX][3];
         real u[NMAX];
@@ -270,7 +343,9 @@ struct LaneSolver {
         for (int k = 0; k < NMAX; ++k) {
           if ((mu >> k) & 1u) {
             const bool in_t = (mt >> k) & 1u, in_o = (mo >> k) & 1u;
-            if (CHAIN || tb.jtype[k] == DEXR_JOINT_REVOLUTE) {
+            bool revolute = true;
+            if constexpr (!CHAIN) revolute = tb.jtype[k] == DEXR_JOINT_REVOLUTE;
+            if (revolute) {
               real v[3] = {0, 0, 0};
               if (in_t) {
 #pragma unroll
@@ -310,7 +385,9 @@ struct LaneSolver {
                 if ((mu >> cc) & 1u) {
                   real h = cw0 * col[cc][0] + cw1 * col[cc][1] + cw2 * col[cc][2] - ku * u[cc];
                   const bool same = (((mt >> cc) & (mt >> rr)) | ((mo >> cc) & (mo >> rr))) & 1u;
-                  if (newton && same && (CHAIN || tb.jtype[cc] == DEXR_JOINT_REVOLUTE))
+                  bool rev_c = true;
+                  if constexpr (!CHAIN) rev_c = tb.jtype[cc] == DEXR_JOINT_REVOLUTE;
+                  if (newton && same && rev_c)
                     h += ax[cc][0] * cf0 + ax[cc][1] * cf1 + ax[cc][2] * cf2;
                   H[hidx(rr, cc)] += h;
                 }
@@ -319,14 +396,26 @@ struct LaneSolver {
           }
         }
       }
+    };
+    if constexpr (LOCAL) {
+#pragma unroll
+      for (int t = 0; t < TB::LT; ++t)
+        if (t < nt) term(t, tb.term_task[t], tb.term_origin[t], tb.term_mt[t], tb.term_mo[t]);
+    } else {
+#pragma clang loop unroll(disable) vectorize(disable)
+      for (int t = 0; t < nt; ++t) {
+        const int ft = tb.term_task[t], fo = tb.term_origin[t];
+        term(t, ft, fo, tb.frame_anc[ft], (fo >= 0) ? tb.frame_anc[fo] : 0u);
+      }
     }
     return F;
   }
 
   // ---- mimic fold (kinematics_adaptor.py:107-113) applied to g (and H): x_k = m * x_s + b ------------------
-  template <bool WITH_H>
-  __device__ __forceinline__ void fold_mimic(const dexr_comp_table& tb, int nj) {
-    if (CHAIN) return;
+  template <bool WITH_H, typename TB>
+  __device__ __forceinline__ void fold_mimic(const TB& tb, int nj) {
+    if constexpr (CHAIN) return;
+    else {
     for (int k = 0; k < nj; ++k) {
       if (tb.src_kind[k] != DEXR_SRC_MIMIC) continue;
       const int s = tb.src_idx[k];
@@ -369,6 +458,7 @@ struct LaneSolver {
             }
           }
       }
+    }
     }
   }
 
@@ -433,7 +523,8 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
   const int64_t wave_global = (int64_t)blockIdx.x * waves_per_block + wave_in_block;
   const int comp = (int)(wave_global % kp.n_comp);
   const int64_t tile = wave_global / kp.n_comp;
-  if (tile * 64 >= kp.B) return;
+  constexpr bool PERSISTENT = (MODE == MODE_SOLVE && NMAX <= 8);  // lanes pull frames from a queue (see below)
+  if (!PERSISTENT && tile * 64 >= kp.B) return;
   const int64_t item_raw = tile * 64 + lane;
   const bool valid = item_raw < kp.B;
   const int64_t item = valid ? item_raw : kp.B - 1;
@@ -453,34 +544,138 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
   uint32_t optmask = 0; // joints that ARE an optimisation variable
 #pragma unroll
   for (int k = 0; k < NMAX; ++k) {
-    S.x[k] = 0;
-    S.xl[k] = 0;
     if (CHAIN || k < nj) {
       const int sk = CHAIN ? DEXR_SRC_OPT : tb.src_kind[k];
       if (sk == DEXR_SRC_OPT) {
-        real v;
-        if (MODE == MODE_EVAL) v = (real)kp.xin[item * kp.n_opt + tb.api[k]];
-        else if (kp.x0) v = (real)kp.x0[item * kp.n_opt + tb.api[k]];
-        else v = (real)kp.last[item * kp.n_opt + tb.api[k]];
-        S.xl[k] = (real)kp.last[item * kp.n_opt + tb.api[k]];
-        S.x[k] = v;
         vmask |= 1u << k;
         optmask |= 1u << k;
-      } else if (sk == DEXR_SRC_FIXED) {
-        S.x[k] = (real)tb.mult[k] * (real)kp.fixed[item * kp.n_fixed + tb.src_idx[k]] + (real)tb.off[k];
       } else if (sk == DEXR_SRC_MIMIC) {
         vmask |= 1u << k;
-      } else {
-        S.x[k] = (real)kp.xin[item * kp.n_q + tb.src_idx[k]];
       }
     }
   }
 
-  // base frames
+  // one row of ref_value for frame `it`: either handed in directly or formed from raw hand keypoints as the callers
+  // of the reference do (joint_pos[task] - joint_pos[origin] / joint_pos[idx], profile_online_retargeting.py:24-30)
+  auto ref_row = [&](int64_t it, int row, float (&rv)[3]) {
+    if (kp.kpts) {
+      const float* a = kp.kpts + (it * kp.n_kp + kp.h_task[row]) * 3;
+      const int o = kp.h_origin[row];
+      if (o >= 0) {
+        const float* b = kp.kpts + (it * kp.n_kp + o) * 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rv[i] = a[i] - b[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rv[i] = a[i];
+      }
+    } else {
+      const float* r = kp.ref + (it * kp.n_ref + row) * 3;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) rv[i] = r[i];
+    }
+  };
+
+  // Loads everything frame `it` needs into this lane: joint values (start point, regularisation target, fixed
+  // joints) into registers, per-term targets / DexPilot weights into the lane's LDS column.  Returns the updated
+  // DexPilot projection bits.
+  auto load_item = [&](int64_t it) -> uint32_t {
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+      S.x[k] = 0;
+      S.xl[k] = 0;
+      if (CHAIN || k < nj) {
+        const int sk = CHAIN ? DEXR_SRC_OPT : tb.src_kind[k];
+        if (sk == DEXR_SRC_OPT) {
+          real v;
+          if (MODE == MODE_EVAL) v = (real)kp.xin[it * kp.n_opt + tb.api[k]];
+          else if (kp.x0) v = (real)kp.x0[it * kp.n_opt + tb.api[k]];
+          else v = (real)kp.last[it * kp.n_opt + tb.api[k]];
+          S.xl[k] = (real)kp.last[it * kp.n_opt + tb.api[k]];
+          S.x[k] = v;
+        } else if (sk == DEXR_SRC_FIXED) {
+          S.x[k] = (real)tb.mult[k] * (real)kp.fixed[it * kp.n_fixed + tb.src_idx[k]] + (real)tb.off[k];
+        } else if (sk == DEXR_SRC_DIRECT) {
+          S.x[k] = (real)kp.xin[it * kp.n_q + tb.src_idx[k]];
+        }
+      }
+    }
+    if (MODE == MODE_FK) return 0u;
+    uint32_t nst = 0;
+    if (kp.kind == DEXR_KIND_DEXPILOT) {
+      // optimizer.py:462-508.  Terms are the model's vectors in order: pairs first, then wrist->finger.
+      const int F = kp.num_fingers;
+      const int n_pair = F * (F - 1) / 2, len_s1 = F - 1;
+      const uint32_t st = kp.state ? kp.state[it] : 0u;
+      for (int i = 0; i < len_s1; ++i) {
+        float rv[3];
+        ref_row(it, i, rv);
+        const float dist = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+        bool b = (st >> i) & 1u;
+        if (dist < kp.project_dist) b = true;
+        if (dist > kp.escape_dist) b = false;
+        nst |= (b ? 1u : 0u) << i;
+      }
+      int idx = len_s1;
+      for (int a = 0; a < F - 2; ++a)
+        for (int b2 = a + 1; b2 < F - 1; ++b2) {
+          float rv[3];
+          ref_row(it, idx, rv);
+          const float dist = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+          const bool b = ((nst >> b2) & 1u) && ((nst >> a) & 1u) && (dist <= 0.03f);
+          nst |= (b ? 1u : 0u) << idx;
+          ++idx;
+        }
+      for (int t = 0; t < nt; ++t) {
+        const int row = tb.term_ref[t];
+        float rv[3];
+        ref_row(it, row, rv);
+        float tv[3];
+        float wt;
+        if (row < n_pair) {
+          const bool pr = (nst >> row) & 1u;
+          if (pr) {
+            const float dist = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+            const float eta = row < len_s1 ? kp.eta1 : kp.eta2;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) tv[i] = (rv[i] / (dist + 1e-6f)) * eta;
+            wt = row < len_s1 ? 200.f : 400.f;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) tv[i] = rv[i] * kp.scaling;
+            wt = 1.f;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) tv[i] = rv[i] * kp.scaling;
+          wt = (float)(n_pair + F);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) T[(t * 3 + i) * 64 + lane] = (real)tv[i];
+        W[t * 64 + lane] = (real)wt;
+      }
+    } else {
+      const float sc = (kp.kind == DEXR_KIND_VECTOR) ? kp.scaling : 1.f;
+#pragma clang loop unroll(disable) vectorize(disable)
+      for (int t = 0; t < nt; ++t) {
+        float rv[3];
+        ref_row(it, tb.term_ref[t], rv);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) T[(t * 3 + i) * 64 + lane] = (real)(rv[i] * sc);  // f32 multiply: optimizer.py:246
+      }
+    }
+    return nst;
+  };
+
+  // base frames never move
+#pragma clang loop unroll(disable) vectorize(disable)
   for (int f = 0; f < tb.n_base_frame; ++f) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) P[(f * 3 + i) * 64 + lane] = (real)tb.frame_off[f][i];
   }
+
+  uint32_t nst_out = 0;  // written back at the very end: no global store may precede the (invariant) table loads
+  if (!PERSISTENT) nst_out = load_item(item);
 
   if (MODE == MODE_FK) {
     S.fk(tb, nj, P, lane);
@@ -492,69 +687,6 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
       }
     }
     return;
-  }
-
-  // ---- per-term targets (and DexPilot weights / projection state) ------------------------------------------
-  uint32_t nst_out = 0;  // written back at the very end: no global store may precede the (invariant) table loads
-  if (kp.kind == DEXR_KIND_DEXPILOT) {
-    // optimizer.py:462-508.  Terms are the model's vectors in order: pairs first, then wrist->finger.
-    const int F = kp.num_fingers;
-    const int n_pair = F * (F - 1) / 2, len_s1 = F - 1;
-    uint32_t st = kp.state ? kp.state[item] : 0u;
-    uint32_t nst = 0;
-    // S1 bits
-    for (int i = 0; i < len_s1; ++i) {
-      const float* rv = kp.ref + (item * kp.n_ref + i) * 3;
-      const float dist = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
-      bool b = (st >> i) & 1u;
-      if (dist < kp.project_dist) b = true;
-      if (dist > kp.escape_dist) b = false;
-      nst |= (b ? 1u : 0u) << i;
-    }
-    int idx = len_s1;
-    for (int a = 0; a < F - 2; ++a)
-      for (int b2 = a + 1; b2 < F - 1; ++b2) {
-        const float* rv = kp.ref + (item * kp.n_ref + idx) * 3;
-        const float dist = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
-        const bool b = ((nst >> b2) & 1u) && ((nst >> a) & 1u) && (dist <= 0.03f);
-        nst |= (b ? 1u : 0u) << idx;
-        ++idx;
-      }
-    for (int t = 0; t < nt; ++t) {
-      const int row = tb.term_ref[t];
-      const float* rv = kp.ref + (item * kp.n_ref + row) * 3;
-      float tv[3];
-      float wt;
-      if (row < n_pair) {
-        const bool pr = (nst >> row) & 1u;
-        if (pr) {
-          const float dist = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
-          const float eta = row < len_s1 ? kp.eta1 : kp.eta2;
-#pragma unroll
-          for (int i = 0; i < 3; ++i) tv[i] = (rv[i] / (dist + 1e-6f)) * eta;
-          wt = row < len_s1 ? 200.f : 400.f;
-        } else {
-#pragma unroll
-          for (int i = 0; i < 3; ++i) tv[i] = rv[i] * kp.scaling;
-          wt = 1.f;
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) tv[i] = rv[i] * kp.scaling;
-        wt = (float)(n_pair + F);
-      }
-#pragma unroll
-      for (int i = 0; i < 3; ++i) T[(t * 3 + i) * 64 + lane] = (real)tv[i];
-      W[t * 64 + lane] = (real)wt;
-    }
-    nst_out = nst;
-  } else {
-    const float sc = (kp.kind == DEXR_KIND_VECTOR) ? kp.scaling : 1.f;
-    for (int t = 0; t < nt; ++t) {
-      const float* rv = kp.ref + (item * kp.n_ref + tb.term_ref[t]) * 3;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) T[(t * 3 + i) * 64 + lane] = (real)(rv[i] * sc);  // f32 multiply: optimizer.py:246
-    }
   }
 
   const real delta = (real)kp.norm_delta;
@@ -575,76 +707,115 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
   }
 
   // ---- MODE_SOLVE: projected Levenberg-Marquardt / Newton --------------------------------------------------
-  // start point: last_qpos clipped into the box (nlopt requires lb <= x0 <= ub; seq_retarget.py:118-120 clips)
-#pragma unroll
-  for (int k = 0; k < NMAX; ++k)
-    if ((optmask >> k) & 1u) S.x[k] = fmin(fmax(S.x[k], (real)tb.lo[k]), (real)tb.hi[k]);
-
-  real lam = (real)kp.lam0, nu = 2;
-  bool done = false;
-  int status = ST_MAXITER;
-  int my_iters = 0, blind = 0;
-  real sprev = (real)1e30;
-  real xo[NMAX];
-
-  real F;
   if constexpr (NMAX <= 8) {
-    // ---- small components: the accepted quadratic model (Hs, gs) stays in registers, so every iteration costs
-    // ONE forward-kinematics pass + ONE fused value/gradient/Hessian assembly at the trial point + one Cholesky;
-    // a rejected step costs only the re-solve with more damping.
-    real Hs[LS::NH], gs[NMAX];
-    S.fk(tb, nj, P, lane);
-    F = S.template residuals<2>(tb, kp, nt, vmask, P, T, W, lane);
-    S.template fold_mimic<true>(tb, nj);
-#pragma unroll
-    for (int k = 0; k < NMAX; ++k) {
-      if ((optmask >> k) & 1u) {
-        const real dx = S.x[k] - S.xl[k];
-        F += delta * dx * dx;
-        gs[k] = S.g[k] + (real)2 * delta * dx;
-      } else {
-        gs[k] = 0;
-      }
+    // ---- small components: PERSISTENT LANES.  Frames need different iteration counts (warm starts: 3-5, a few
+    // need 15+), so a wave that owns a fixed tile of 64 frames idles most lanes most of the time.  Here a lane that
+    // finishes a frame immediately pulls the next one from a per-component work queue (wave-local pool refilled by
+    // one atomicAdd per QCHUNK frames), so every lane does useful iterations until the queue is dry.
+    // Per iteration: ONE forward-kinematics pass + ONE fused value/gradient/Hessian assembly at the trial point +
+    // one Cholesky.  The accepted quadratic model (Hs, gs) stays in registers, so a rejected step costs only the
+    // re-solve with more damping.
+    auto run = [&](const auto& tbl) {
+    const unsigned QCHUNK = kp.qchunk;
+    real Hs[LS::NH], gs[NMAX], xo[NMAX];
+    real F = 0, lam = (real)kp.lam0, nu = 2, sprev = (real)1e30;
+    int my_iters = 0, blind = 0;
+    bool has = false, fresh = false;
+    int64_t my_item = 0;
+    uint32_t my_nst = 0;
+    unsigned pool_next = 0, pool_end = 0;  // wave-uniform
+    bool dry = false;                      // wave-uniform: the queue has been exhausted
+    if (QCHUNK == 0) {  // tile mode: this wave owns frames [64*tile, 64*tile+64) and never touches the queue
+      pool_next = (unsigned)(tile * 64);
+      pool_end = (unsigned)((tile * 64 + 64 < kp.B) ? tile * 64 + 64 : kp.B);
+      if ((int64_t)pool_next >= kp.B) return;
     }
-#pragma unroll
-    for (int i = 0; i < LS::NH; ++i) Hs[i] = S.H[i];
+    unsigned* queue = kp.queue + comp;
 
-    for (int it = 0; it < kp.max_iter; ++it) {
-      if (__all(done)) break;
-      uint32_t freemask = 0;
-#pragma unroll
-      for (int k = 0; k < NMAX; ++k) {
-        const bool isopt = (optmask >> k) & 1u;
-        const bool act = (S.x[k] <= (real)tb.lo[k] && gs[k] > 0) || (S.x[k] >= (real)tb.hi[k] && gs[k] < 0);
-        if (isopt && !act) freemask |= 1u << k;
-        S.g[k] = (isopt && !act) ? gs[k] : (real)0;
-      }
-#pragma unroll
-      for (int rr = 0; rr < NMAX; ++rr) {
-        const bool fr = (freemask >> rr) & 1u;
-#pragma unroll
-        for (int cc = 0; cc < rr; ++cc) {
-          const bool fc = (freemask >> cc) & 1u;
-          S.H[LS::hidx(rr, cc)] = (fr && fc) ? Hs[LS::hidx(rr, cc)] : (real)0;
+    for (;;) {
+      // (1) hand new frames to idle lanes
+      const unsigned long long want = __ballot(!has);
+      if (want != 0ull && !dry) {
+        if (pool_next >= pool_end && QCHUNK == 0) dry = true;
+        if (pool_next >= pool_end && !dry) {
+          unsigned base = 0;
+          if (lane == 0) base = atomicAdd(queue, QCHUNK);
+          base = __builtin_amdgcn_readfirstlane(base);
+          if ((int64_t)base >= kp.B) {
+            dry = true;
+          } else {
+            pool_next = base;
+            pool_end = (unsigned)(((int64_t)base + QCHUNK < kp.B) ? base + QCHUNK : kp.B);
+          }
         }
-        S.H[LS::hidx(rr, rr)] = fr ? Hs[LS::hidx(rr, rr)] + (real)2 * delta + lam : (real)1;
-      }
-      real gm[NMAX];
+        if (!dry) {
+          const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
+          const unsigned cand = pool_next + rank;
+          const bool got = !has && cand < pool_end;
+          const unsigned taken = (unsigned)__popcll(__ballot(got));
+          pool_next += taken;
+          if (got) {
+            my_item = (int64_t)cand;
+            my_nst = load_item(my_item);
 #pragma unroll
-      for (int k = 0; k < NMAX; ++k) gm[k] = S.g[k];
-      real d[NMAX];
-      const bool ok = S.chol_solve(d);
+            for (int k = 0; k < NMAX; ++k)
+              if ((optmask >> k) & 1u) S.x[k] = fmin(fmax(S.x[k], (real)tbl.lo[k]), (real)tbl.hi[k]);
+            has = true;
+            fresh = true;
+            lam = (real)kp.lam0;
+            nu = 2;
+            sprev = (real)1e30;
+            my_iters = 0;
+            blind = 0;
+          }
+        }
+      }
+      if (!__any(has)) {
+        if (dry) break;
+        continue;
+      }
+
+      // (2) step from the accepted model (lanes holding a fresh frame evaluate their start point instead)
       real smax = 0, pred = 0;
+      bool ok = true;
+      if (__any(has && !fresh)) {
+        uint32_t freemask = 0;
 #pragma unroll
-      for (int k = 0; k < NMAX; ++k) {
-        xo[k] = S.x[k];
-        if ((optmask >> k) & 1u) {
-          const real xt = fmin(fmax(S.x[k] + d[k], (real)tb.lo[k]), (real)tb.hi[k]);
-          pred += (real)0.5 * d[k] * (lam * d[k] - gm[k]);
-          smax = fmax(smax, fabs(xt - S.x[k]));
-          if (!done) S.x[k] = xt;
+        for (int k = 0; k < NMAX; ++k) {
+          const bool isopt = (optmask >> k) & 1u;
+          const bool act = (S.x[k] <= (real)tbl.lo[k] && gs[k] > 0) || (S.x[k] >= (real)tbl.hi[k] && gs[k] < 0);
+          if (isopt && !act) freemask |= 1u << k;
+          S.g[k] = (isopt && !act) ? gs[k] : (real)0;
+        }
+#pragma unroll
+        for (int rr = 0; rr < NMAX; ++rr) {
+          const bool fr = (freemask >> rr) & 1u;
+#pragma unroll
+          for (int cc = 0; cc < rr; ++cc) {
+            const bool fc = (freemask >> cc) & 1u;
+            S.H[LS::hidx(rr, cc)] = (fr && fc) ? Hs[LS::hidx(rr, cc)] : (real)0;
+          }
+          S.H[LS::hidx(rr, rr)] = fr ? Hs[LS::hidx(rr, rr)] + (real)2 * delta + lam : (real)1;
+        }
+        real gm[NMAX];
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k) gm[k] = S.g[k];
+        real d[NMAX];
+        ok = S.chol_solve(d);
+        const bool stepping = has && !fresh;
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k) {
+          xo[k] = S.x[k];
+          if ((optmask >> k) & 1u) {
+            const real xt = fmin(fmax(S.x[k] + d[k], (real)tbl.lo[k]), (real)tbl.hi[k]);
+            pred += (real)0.5 * d[k] * (lam * d[k] - gm[k]);
+            smax = fmax(smax, fabs(xt - S.x[k]));
+            if (stepping) S.x[k] = xt;
+          }
         }
       }
+
+      // (3) forward kinematics + fused value / gradient / Hessian at S.x
       S.fk(tb, nj, P, lane);
       real Ft = S.template residuals<2>(tb, kp, nt, vmask, P, T, W, lane);
       S.template fold_mimic<true>(tb, nj);
@@ -658,33 +829,48 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
           S.g[k] = 0;
         }
       }
-      const real noise = (real)16 * RT::eps() * fabs(F);
-      const bool finite = (Ft == Ft) && (smax == smax) && (fabs(Ft) < (real)1e30);
-      const bool below_floor = ok && finite && (pred <= noise) && (smax < (real)1e-2);
-      const bool accept = !done && ok && finite && ((Ft <= F) || below_floor);
-      if (!done) {
-        ++my_iters;
-        if (accept) {
-          const real rho = (F - Ft) / fmax(pred, (real)1e-30);
-          const real t = (real)2 * rho - (real)1;
-          // below the floor rho is noise: trust the model and relax the damping so the steps become Newton steps
-          lam = fmax(lam * (below_floor ? (real)(1.0 / 3.0) : fmax((real)(1.0 / 3.0), (real)1 - t * t * t)), (real)1e-9);
-          nu = 2;
+
+      // (4) accept / reject, damping update, termination
+      bool accept = false, finished = false;
+      int status = ST_MAXITER;
+      if (has) {
+        const bool finite = (Ft == Ft) && (smax == smax) && (fabs(Ft) < (real)1e30);
+        if (fresh) {
+          accept = true;  // start point: adopt its model unconditionally
+          fresh = false;
           F = Ft;
-          const bool stalled = below_floor && blind >= 2 && smax > (real)0.9 * sprev && smax < (real)20 * (real)kp.tol;
-          blind = below_floor ? blind + 1 : 0;
-          sprev = smax;
-          if (smax < (real)kp.tol || stalled || blind >= kp.max_blind) {
-            done = true;
-            status = ST_CONVERGED;
+          if (!finite) {
+            finished = true;
+            status = ST_FALLBACK;
           }
         } else {
-          lam = fmax(lam, (real)1e-6) * nu;
-          nu *= 2;
-          if (lam > (real)1e10) {
-            done = true;
-            status = finite ? ST_CONVERGED : ST_FALLBACK;
+          const real noise = (real)16 * RT::eps() * fabs(F);
+          // below the rounding floor of F the decrease test is meaningless: trust the (small) Newton step
+          const bool below_floor = ok && finite && (pred <= noise) && (smax < (real)1e-2);
+          accept = ok && finite && ((Ft <= F) || below_floor);
+          ++my_iters;
+          if (accept) {
+            const real rho = (F - Ft) / fmax(pred, (real)1e-30);
+            const real t = (real)2 * rho - (real)1;
+            lam = fmax(lam * (below_floor ? (real)(1.0 / 3.0) : fmax((real)(1.0 / 3.0), (real)1 - t * t * t)), (real)1e-9);
+            nu = 2;
+            F = Ft;
+            const bool stalled = below_floor && blind >= 2 && smax > (real)0.9 * sprev && smax < (real)20 * (real)kp.tol;
+            blind = below_floor ? blind + 1 : 0;
+            sprev = smax;
+            if (smax < (real)kp.tol || stalled || blind >= kp.max_blind) {
+              finished = true;
+              status = ST_CONVERGED;
+            }
+          } else {
+            lam = fmax(lam, (real)1e-6) * nu;
+            nu *= 2;
+            if (lam > (real)1e10) {  // no descent direction resolvable any more
+              finished = true;
+              status = finite ? ST_CONVERGED : ST_FALLBACK;
+            }
           }
+          if (!finished && my_iters >= kp.max_iter) finished = true;  // status stays ST_MAXITER
         }
       }
 #pragma unroll
@@ -694,8 +880,52 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
       }
 #pragma unroll
       for (int i = 0; i < LS::NH; ++i) Hs[i] = accept ? S.H[i] : Hs[i];
+
+      // (5) retire finished frames
+      if (finished) {
+        bool bad = (status == ST_FALLBACK);
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k)
+          if ((optmask >> k) & 1u) bad = bad || !(S.x[k] == S.x[k]);
+        if (bad) status = ST_FALLBACK;
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k) {
+          if ((optmask >> k) & 1u) {
+            const real v = bad ? S.xl[k] : S.x[k];
+            kp.qout[my_item * kp.n_opt + tbl.api[k]] = (float)v;
+            if (kp.qout64) kp.qout64[my_item * kp.n_opt + tbl.api[k]] = (double)v;
+          }
+        }
+        if (kp.kind == DEXR_KIND_DEXPILOT && kp.state && comp == 0) kp.state[my_item] = my_nst;
+        if (kp.status) atomicMax(&kp.status[my_item], status);
+        if (kp.iters) atomicMax(&kp.iters[my_item], my_iters);
+        if (kp.fval) atomicAdd(&kp.fval[my_item], (float)F);
+        has = false;
+      }
     }
+    };
+    if constexpr (CHAIN) {
+      LocalTab<NMAX> lt;  // tables in registers for the whole kernel (see LocalTab)
+      lt.load(tb);
+      run(lt);
+    } else {
+      run(tb);
+    }
+    return;
   } else {
+  // ---- large components: one tile of 64 frames per wave; the Hessian (up to 300 registers) is rebuilt after a
+  // rejected step instead of being kept twice.
+  // start point: last_qpos clipped into the box (nlopt requires lb <= x0 <= ub; seq_retarget.py:118-120 clips)
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k)
+    if ((optmask >> k) & 1u) S.x[k] = fmin(fmax(S.x[k], (real)tb.lo[k]), (real)tb.hi[k]);
+  real lam = (real)kp.lam0, nu = 2;
+  bool done = false;
+  int status = ST_MAXITER;
+  int my_iters = 0, blind = 0;
+  real sprev = (real)1e30;
+  real xo[NMAX];
+  real F;
   S.fk(tb, nj, P, lane);
   F = S.template residuals<0>(tb, kp, nt, vmask, P, T, W, lane);
 #pragma unroll
@@ -761,7 +991,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
       if (accept) {
         const real rho = (F - Ft) / fmax(pred, (real)1e-30);
         const real t = (real)2 * rho - (real)1;
-        if (!below_floor) lam = fmax(lam * fmax((real)(1.0 / 3.0), (real)1 - t * t * t), (real)1e-9);
+        lam = fmax(lam * (below_floor ? (real)(1.0 / 3.0) : fmax((real)(1.0 / 3.0), (real)1 - t * t * t)), (real)1e-9);
         nu = 2;
         F = Ft;
         // below the floor, progress is judged by the step length alone: stop when it is under tol, when it no
@@ -790,8 +1020,6 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
     if (__any(redo)) S.fk(tb, nj, P, lane);  // rejected lanes: bring ax/og/P back to their (unchanged) x
   }
 
-  }
-
   // non-finite guard: hand back last_qpos like the reference's RuntimeError path (optimizer.py:100-102)
   bool bad = false;
 #pragma unroll
@@ -813,6 +1041,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
     if (kp.iters) atomicMax(&kp.iters[item], my_iters);
     if (kp.fval) atomicAdd(&kp.fval[item], (float)F);
   }
+  }  // large components
 }
 
 }  // namespace dexr

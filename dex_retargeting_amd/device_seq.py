@@ -82,7 +82,11 @@ class DeviceSeqRetargeting:
         """(B, n_opt) start point for the next frame (== SeqRetargeting.set_qpos per sequence)."""
         self.last_qpos.copy_(self.torch.as_tensor(target_qpos, dtype=self.torch.float32, device=self.device))
 
-    def retarget(self, ref_value, fixed_qpos=None):
+    def retarget_keypoints(self, keypoints, fixed_qpos=None):
+        """Same as retarget() but fed with raw (B, 21, 3) hand keypoints; ref_value is formed inside the kernel."""
+        return self.retarget(keypoints, fixed_qpos, _keypoints=True)
+
+    def retarget(self, ref_value, fixed_qpos=None, _keypoints=False):
         """ref_value: (B, n_ref, 3) float32 CUDA tensor (contiguous).  Returns the (B, dof) float64 CUDA tensor of
         filtered robot qpos in pinocchio dof order (a view of an internal buffer, overwritten by the next call)."""
         torch = self.torch
@@ -98,7 +102,8 @@ class DeviceSeqRetargeting:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         self.model.retarget_dev(B, ref_value.data_ptr(), fixed.data_ptr() if self.n_fixed else 0,
                                 self._last_clipped.data_ptr(), self.state.data_ptr() if self.dexpilot else 0,
-                                self._q.data_ptr(), status_ptr=self._status.data_ptr(), opts=self._opts, stream=stream)
+                                self._q.data_ptr(), status_ptr=self._status.data_ptr(), opts=self._opts, stream=stream,
+                                keypoints=_keypoints)
         # non-finite solve -> keep last_qpos, like the reference's RuntimeError branch (optimizer.py:100-102)
         bad = (self._status == 2).unsqueeze(1)
         self.last_qpos.copy_(torch.where(bad, self._last_clipped, self._q))

@@ -25,7 +25,7 @@ import numpy as np
 from .urdf import KinematicModel
 
 MAXJ, MAXF, MAXT, NSLOT = 32, 16, 16, 3
-MAGIC, VERSION = 0x52584544, 3
+MAGIC, VERSION = 0x52584544, 4
 KIND_VECTOR, KIND_POSITION, KIND_DEXPILOT, KIND_FKONLY = 0, 1, 2, 3
 SRC_OPT, SRC_FIXED, SRC_MIMIC, SRC_DIRECT = 0, 1, 2, 3
 
@@ -44,6 +44,7 @@ HEADER_DTYPE = np.dtype([
     ("n_ref", "<i4"), ("n_comp", "<i4"), ("num_fingers", "<i4"), ("n_q", "<i4"), ("comp_bytes", "<i4"),
     ("huber_delta", "<f4"), ("norm_delta", "<f4"), ("scaling", "<f4"), ("inv_norm", "<f4"),
     ("project_dist", "<f4"), ("escape_dist", "<f4"), ("eta1", "<f4"), ("eta2", "<f4"),
+    ("n_keypoints", "<i4"), ("human_origin", "<i4", (MAXT,)), ("human_task", "<i4", (MAXT,)),
 ])
 
 
@@ -224,7 +225,8 @@ def compile_model(model: KinematicModel, kind: int, idx_pin2target: Sequence[int
                   mimic: Sequence[Tuple[int, int, float, float]] = (), huber_delta: float = 0.02,
                   norm_delta: float = 4e-3, scaling: float = 1.0, num_fingers: int = 0,
                   project_dist: float = 0.03, escape_dist: float = 0.05, eta1: float = 1e-4,
-                  eta2: float = 3e-2) -> CompiledModel:
+                  eta2: float = 3e-2, human_indices: Optional[np.ndarray] = None,
+                  n_keypoints: int = 21) -> CompiledModel:
     """mimic: (mimic pin idx, source pin idx, multiplier, offset).  lower/upper: optimiser box per target joint
     (already widened; +-inf allowed)."""
     n_opt, n_fixed = len(idx_pin2target), len(idx_pin2fixed)
@@ -349,6 +351,19 @@ def compile_model(model: KinematicModel, kind: int, idx_pin2target: Sequence[int
     header["huber_delta"], header["norm_delta"], header["scaling"] = huber_delta, norm_delta, scaling
     header["inv_norm"] = inv_norm
     header["project_dist"], header["escape_dist"], header["eta1"], header["eta2"] = project_dist, escape_dist, eta1, eta2
+    if human_indices is not None:  # target_link_human_indices: (2, n_ref) for vector/dexpilot, (n_ref,) for position
+        hi = np.asarray(human_indices, dtype=np.int64)
+        if hi.ndim == 1:
+            origin, task = np.full(hi.shape[0], -1), hi
+        else:
+            origin, task = hi[0], hi[1]
+        if task.shape[0] != n_ref:
+            raise ValueError("target_link_human_indices does not match the number of reference rows")
+        if task.max(initial=0) >= n_keypoints or origin.max(initial=-1) >= n_keypoints:
+            raise ValueError("target_link_human_indices exceeds the keypoint count")
+        header["n_keypoints"] = n_keypoints
+        header["human_origin"][:n_ref] = origin
+        header["human_task"][:n_ref] = task
     return CompiledModel(kind, n_opt, n_fixed, n_ref, model.dof, header,
                          np.array(comps, dtype=COMP_DTYPE).reshape(-1), comp_vars)
 

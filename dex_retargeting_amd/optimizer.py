@@ -121,7 +121,8 @@ class Optimizer:
                          zip(a.idx_pin2mimic, a.idx_pin2source, a.multipliers, a.offsets)]
             self._compiled = mc.compile_model(
                 self.robot.kin, self._kind(), self.idx_pin2target.tolist(), self.idx_pin2fixed.tolist(), self._terms(),
-                lower=self._lower, upper=self._upper, mimic=mimic, **self._compile_kwargs())
+                lower=self._lower, upper=self._upper, mimic=mimic,
+                human_indices=self.target_link_human_indices, **self._compile_kwargs())
         return self._compiled
 
     def device_model(self) -> _lib.Model:
@@ -161,6 +162,22 @@ class Optimizer:
         model = self.device_model()
         ref = np.ascontiguousarray(ref_value, dtype=np.float32).reshape(B, self._compiled.n_ref, 3)
         q, info = model.retarget(ref, fixed, last, state=state, opts=self._options(), want_info=True)
+        self.last_info = info
+        return q
+
+    def retarget_keypoints_batch(self, keypoints: np.ndarray, fixed_qpos: Optional[np.ndarray], last_qpos: np.ndarray,
+                                 state: Optional[np.ndarray] = None) -> np.ndarray:
+        """Like retarget_batch but fed with raw hand keypoints (B, 21, 3): the kernel forms ref_value itself from
+        ``target_link_human_indices`` (joint_pos[task] - joint_pos[origin] for vector/DexPilot, joint_pos[idx] for
+        position -- what every caller of the reference does first, profile_online_retargeting.py:24-30)."""
+        last = np.ascontiguousarray(last_qpos, dtype=np.float32)
+        B = last.shape[0]
+        fixed = None if fixed_qpos is None else np.ascontiguousarray(fixed_qpos, dtype=np.float32).reshape(B, -1)
+        if (0 if fixed is None else fixed.shape[1]) != len(self.idx_pin2fixed):
+            raise ValueError(f"Optimizer has {len(self.idx_pin2fixed)} joints but non_target_qpos {fixed_qpos} is given")
+        model = self.device_model()
+        kp = np.ascontiguousarray(keypoints, dtype=np.float32).reshape(B, -1, 3)
+        q, info = model.retarget(kp, fixed, last, state=state, opts=self._options(), want_info=True, keypoints=True)
         self.last_info = info
         return q
 

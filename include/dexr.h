@@ -75,6 +75,16 @@ int dexr_retarget_dev(const dexr_model* m, int64_t B, const float* ref, const fl
 int dexr_retarget(const dexr_model* m, int64_t B, const float* ref, const float* fixed, const float* last,
                   uint32_t* state, float* qpos_out, int32_t* status_out, int32_t* iters_out, float* fval_out,
                   const dexr_solve_options* opt);
+/* Same solve fed with RAW hand keypoints: keypoints B x n_keypoints x 3 float32 (21 MediaPipe/MANO points); each
+ * ref_value row is formed on the fly as kp[task] - kp[origin] (vector, DexPilot) or kp[idx] (position), i.e. the
+ * gather/subtract every caller of the reference performs before retarget()
+ * (/root/reference/example/profiling/profile_online_retargeting.py:24-30, example/vector_retargeting/detect_from_video.py:45-55). */
+int dexr_retarget_kp_dev(const dexr_model* m, int64_t B, const float* keypoints, const float* fixed, const float* last,
+                         uint32_t* state, float* qpos_out, int32_t* status_out, int32_t* iters_out, float* fval_out,
+                         const dexr_solve_options* opt, void* stream);
+int dexr_retarget_kp(const dexr_model* m, int64_t B, const float* keypoints, const float* fixed, const float* last,
+                     uint32_t* state, float* qpos_out, int32_t* status_out, int32_t* iters_out, float* fval_out,
+                     const dexr_solve_options* opt);
 /* same, float64 arithmetic and float64 result (validation aid; host pointers) */
 int dexr_retarget_f64(const dexr_model* m, int64_t B, const float* ref, const float* fixed, const float* last,
                       uint32_t* state, double* qpos_out, int32_t* status_out, int32_t* iters_out,

@@ -22,7 +22,7 @@
 #include <stdint.h>
 
 #define DEXR_MAGIC 0x52584544u /* "DEXR" */
-#define DEXR_TABLE_VERSION 3u
+#define DEXR_TABLE_VERSION 4u
 
 #define DEXR_MAXJ 32  /* joints per component (bitmask width) */
 #define DEXR_MAXF 16  /* frames (target links) per component  */
@@ -77,6 +77,12 @@ typedef struct dexr_model_header {
   float scaling;       /* vector / dexpilot target scaling                            */
   float inv_norm;      /* 1/V (vector, dexpilot) or 1/(3P) (position): 'mean' factor  */
   float project_dist, escape_dist, eta1, eta2; /* DexPilot constants optimizer.py:344-347 */
+  /* target_link_human_indices (retargeting_config.py:27-29): how a ref_value row is formed from raw hand keypoints,
+   * ref[r] = kp[human_task[r]] - kp[human_origin[r]]  (human_origin[r] = -1: ref[r] = kp[human_task[r]]).
+   * n_keypoints = 0 when the model carries no such mapping (keypoint entry points then refuse it). */
+  int32_t n_keypoints;
+  int32_t human_origin[DEXR_MAXT];
+  int32_t human_task[DEXR_MAXT];
 } dexr_model_header;
 
 #endif /* DEXR_TABLES_H */

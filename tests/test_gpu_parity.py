@@ -337,3 +337,23 @@ def test_device_resident_sequences_equal_host_batched(rel):
         b = dev.retarget(torch.from_numpy(ref).cuda()).cpu().numpy()
         assert np.allclose(a, b, rtol=1e-13, atol=1e-15), t
         assert np.array_equal(host.last_qpos, dev.last_qpos.cpu().numpy()), t
+
+
+@pytest.mark.parametrize("rel", ["teleop/allegro_hand_right.yml", "teleop/shadow_hand_right_dexpilot.yml",
+                                 "offline/leap_hand_right.yml", "teleop/panda_gripper.yml"])
+def test_keypoint_entry_point_equals_ref_value_path(rel):
+    """dexr_retarget_kp (raw 21 keypoints, gather/subtract fused into the kernel) == forming ref_value on the host as
+    profile_online_retargeting.py:24-30 does and calling dexr_retarget: bitwise."""
+    seq, prob = build(rel)
+    opt = seq.optimizer
+    B = 300
+    kp = cases.human_keypoints(B, seed=5)
+    ref = np.ascontiguousarray(cases.ref_from_keypoints(prob, kp), dtype=np.float32)
+    last = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
+    s1 = np.zeros(B, np.uint32) if prob.kind == "dexpilot" else None
+    s2 = np.zeros(B, np.uint32) if prob.kind == "dexpilot" else None
+    a = opt.retarget_batch(ref, None, last, state=s1)
+    b = opt.retarget_keypoints_batch(kp, None, last, state=s2)
+    assert np.array_equal(a, b)
+    if s1 is not None:
+        assert np.array_equal(s1, s2)

@@ -50,7 +50,7 @@ def test_table_struct_sizes_match_header():
     assert int(re.search(r"#define DEXR_TABLE_VERSION (\d+)u", h).group(1)) == mc.VERSION
     words = 4 + mc.MAXJ * 12 + 8 * mc.MAXJ + 4 * mc.MAXJ + mc.MAXF * 5 + 3 * mc.MAXT
     assert mc.COMP_DTYPE.itemsize == 4 * words
-    assert mc.HEADER_DTYPE.itemsize == 4 * 18
+    assert mc.HEADER_DTYPE.itemsize == 4 * (18 + 1 + 2 * mc.MAXT)
 
 
 def test_model_create_rejects_malformed_blobs():
