@@ -82,6 +82,21 @@ class DeviceSeqRetargeting:
         """(B, n_opt) start point for the next frame (== SeqRetargeting.set_qpos per sequence)."""
         self.last_qpos.copy_(self.torch.as_tensor(target_qpos, dtype=self.torch.float32, device=self.device))
 
+    def warm_start(self, wrist_pos, wrist_quat, hand_type=None, is_mano_convention: bool = False):
+        """Per-sequence analytic wrist initialisation (seq_retarget.py:45-110): wrist_pos (B,3), wrist_quat (B,4)."""
+        from .constants import HandType
+        from .seq_retarget import _DUMMY_NAMES, warm_start_pose_vec
+
+        pose = warm_start_pose_vec(self.optimizer, np.asarray(wrist_pos), np.asarray(wrist_quat),
+                                   hand_type or HandType.right, is_mano_convention)
+        if pose.shape[0] != self.batch:
+            raise ValueError(f"expected {self.batch} wrist poses, got {pose.shape[0]}")
+        last = self.last_qpos.cpu().numpy()
+        for num, joint_name in enumerate(self.optimizer.target_joint_names):
+            if joint_name in _DUMMY_NAMES:
+                last[:, num] = pose[:, _DUMMY_NAMES.index(joint_name)]
+        self.last_qpos.copy_(self.torch.from_numpy(last))
+
     def retarget_keypoints(self, keypoints, fixed_qpos=None):
         """Same as retarget() but fed with raw (B, 21, 3) hand keypoints; ref_value is formed inside the kernel."""
         return self.retarget(keypoints, fixed_qpos, _keypoints=True)

@@ -92,6 +92,32 @@ class CompiledModel:
     def to_blob(self) -> bytes:
         return self.header.tobytes() + self.comps.tobytes()
 
+    def save(self, path: str) -> None:
+        """Write the table blob (the on-disk format of include/dexr_tables.h) so a deployment can create models
+        without the URDF / YAML / this compiler: ``_lib.Model(open(path, 'rb').read())``."""
+        with open(path, "wb") as f:
+            f.write(self.to_blob())
+
+    @staticmethod
+    def from_blob(blob: bytes) -> "CompiledModel":
+        if len(blob) < HEADER_DTYPE.itemsize:
+            raise ValueError("blob shorter than the header")
+        header = np.frombuffer(blob[:HEADER_DTYPE.itemsize], dtype=HEADER_DTYPE)[0].copy()
+        if int(header["magic"]) != MAGIC or int(header["version"]) != VERSION:
+            raise ValueError("not a dexr table blob of this version")
+        n = int(header["n_comp"])
+        body = blob[HEADER_DTYPE.itemsize:]
+        if int(header["comp_bytes"]) != COMP_DTYPE.itemsize or len(body) != n * COMP_DTYPE.itemsize:
+            raise ValueError("blob size does not match its header")
+        comps = np.frombuffer(body, dtype=COMP_DTYPE).copy()
+        return CompiledModel(int(header["kind"]), int(header["n_opt"]), int(header["n_fixed"]), int(header["n_ref"]),
+                             int(header["n_q"]), header, comps, [])
+
+    @staticmethod
+    def load(path: str) -> "CompiledModel":
+        with open(path, "rb") as f:
+            return CompiledModel.from_blob(f.read())
+
 
 def _build_component(model: KinematicModel, joint_set: Sequence[int], frames: List[Tuple[str, int, np.ndarray]],
                      terms: List[Tuple[int, int, int]], src: Dict[int, tuple], lo: np.ndarray, hi: np.ndarray,

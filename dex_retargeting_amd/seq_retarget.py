@@ -29,6 +29,38 @@ def _intrinsic_xyz_euler(R: np.ndarray) -> np.ndarray:
     return np.array([a, b, c])
 
 
+_DUMMY_NAMES = ["dummy_x_translation_joint", "dummy_y_translation_joint", "dummy_z_translation_joint",
+                "dummy_x_rotation_joint", "dummy_y_rotation_joint", "dummy_z_rotation_joint"]
+
+
+def warm_start_pose_vec(optimizer: Optimizer, wrist_pos: np.ndarray, wrist_quat: np.ndarray,
+                        hand_type: HandType = HandType.right, is_mano_convention: bool = False) -> np.ndarray:
+    """Batched analytic 6-DoF initialisation of the dummy free joints (seq_retarget.py:45-110):
+    wrist_pos (B,3), wrist_quat (B,4) (w,x,y,z) -> (B,6) values for the x/y/z translation and the intrinsic-xyz
+    rotation dummy joints that put the hand's root link at the given wrist pose."""
+    wrist_pos = np.atleast_2d(np.asarray(wrist_pos, dtype=np.float64))
+    wrist_quat = np.atleast_2d(np.asarray(wrist_quat, dtype=np.float64))
+    if wrist_pos.shape[1] != 3:
+        raise ValueError(f"Wrist pos: {wrist_pos} is not a 3-dim vector.")
+    if wrist_quat.shape[1] != 4:
+        raise ValueError(f"Wrist quat: {wrist_quat} is not a 4-dim vector.")
+    operator2mano = OPERATOR2MANO[hand_type] if is_mano_convention else np.eye(3)
+    robot = optimizer.robot
+    urdf_joint = robot.kin.urdf.joint_map[_DUMMY_NAMES[5]]  # its child link is the hand's original root link
+    wrist_link_id = robot.get_link_index(urdf_joint.child)
+    robot.compute_forward_kinematics(robot.q0.copy())  # dummy joints at zero (seq_retarget.py:84-93)
+    root2wrist = robot.get_link_pose_inv(wrist_link_id)
+    out = np.zeros((wrist_pos.shape[0], 6))
+    for b in range(wrist_pos.shape[0]):
+        target = np.eye(4)
+        target[:3, :3] = _matrix_from_quaternion(wrist_quat[b]) @ operator2mano.T
+        target[:3, 3] = wrist_pos[b]
+        root = target @ root2wrist
+        out[b, :3] = root[:3, 3]
+        out[b, 3:] = _intrinsic_xyz_euler(root[:3, :3])
+    return out
+
+
 class SeqRetargeting:
     def __init__(self, optimizer: Optimizer, has_joint_limits=True, lp_filter: Optional[LPFilter] = None):
         self.optimizer = optimizer
@@ -58,36 +90,10 @@ class SeqRetargeting:
             raise ValueError(f"Wrist pos: {wrist_pos} is not a 3-dim vector.")
         if len(wrist_quat) != 4:
             raise ValueError(f"Wrist quat: {wrist_quat} is not a 4-dim vector.")
-
-        operator2mano = OPERATOR2MANO[hand_type] if is_mano_convention else np.eye(3)
-        robot = self.optimizer.robot
-        target_wrist_pose = np.eye(4)
-        target_wrist_pose[:3, :3] = _matrix_from_quaternion(wrist_quat) @ operator2mano.T
-        target_wrist_pose[:3, 3] = wrist_pos
-
-        name_list = ["dummy_x_translation_joint", "dummy_y_translation_joint", "dummy_z_translation_joint",
-                     "dummy_x_rotation_joint", "dummy_y_rotation_joint", "dummy_z_rotation_joint"]
-        # child link of the last dummy joint = the hand's original root link
-        urdf_joint = robot.kin.urdf.joint_map[name_list[5]]
-        wrist_link_id = robot.get_link_index(urdf_joint.child)
-
-        old_qpos = robot.q0
-        new_qpos = old_qpos.copy()
+        pose_vec = warm_start_pose_vec(self.optimizer, wrist_pos, wrist_quat, hand_type, is_mano_convention)[0]
         for num, joint_name in enumerate(self.optimizer.target_joint_names):
-            if joint_name in name_list:
-                new_qpos[num] = 0
-
-        robot.compute_forward_kinematics(new_qpos)
-        root2wrist = robot.get_link_pose_inv(wrist_link_id)
-        target_root_pose = target_wrist_pose @ root2wrist
-
-        euler = _intrinsic_xyz_euler(target_root_pose[:3, :3])
-        pose_vec = np.concatenate([target_root_pose[:3, 3], euler])
-
-        for num, joint_name in enumerate(self.optimizer.target_joint_names):
-            if joint_name in name_list:
-                index = name_list.index(joint_name)
-                self.last_qpos[num] = pose_vec[index]
+            if joint_name in _DUMMY_NAMES:
+                self.last_qpos[num] = pose_vec[_DUMMY_NAMES.index(joint_name)]
 
         self.is_warm_started = True
 
@@ -164,6 +170,16 @@ class BatchedSeqRetargeting:
         st = self.optimizer._state_in(self.batch)
         self.state = None if st is None else np.zeros(self.batch, dtype=np.uint32)
         self.num_retargeting = 0
+
+    def warm_start(self, wrist_pos: np.ndarray, wrist_quat: np.ndarray, hand_type: HandType = HandType.right,
+                   is_mano_convention: bool = False):
+        """Per-sequence analytic wrist initialisation: wrist_pos (B,3), wrist_quat (B,4)."""
+        pose = warm_start_pose_vec(self.optimizer, wrist_pos, wrist_quat, hand_type, is_mano_convention)
+        if pose.shape[0] != self.batch:
+            raise ValueError(f"expected {self.batch} wrist poses, got {pose.shape[0]}")
+        for num, joint_name in enumerate(self.optimizer.target_joint_names):
+            if joint_name in _DUMMY_NAMES:
+                self.last_qpos[:, num] = pose[:, _DUMMY_NAMES.index(joint_name)]
 
     def retarget(self, ref_value: np.ndarray, fixed_qpos: Optional[np.ndarray] = None) -> np.ndarray:
         """ref_value (B,n_ref,3); returns float64 (B, robot.dof) in pinocchio dof order."""

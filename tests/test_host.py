@@ -274,3 +274,18 @@ def test_seq_retargeting_wrapper_bookkeeping(monkeypatch):
     assert seq.num_retargeting == 2
     seq.reset()
     assert np.allclose(seq.last_qpos, seq.joint_limits.mean(1))
+
+
+def test_table_blob_round_trip(tmp_path):
+    cfg = RetargetingConfig.load_from_file(get_default_config_path(RobotName.shadow, RetargetingType.dexpilot, HandType.right))
+    opt = cfg._build_optimizer()
+    opt.set_joint_limit(opt.robot.joint_limits[opt.idx_pin2target])
+    cm = opt.compiled_model()
+    path = str(tmp_path / "shadow_dexpilot.dexr")
+    cm.save(path)
+    back = mc.CompiledModel.load(path)
+    assert back.to_blob() == cm.to_blob()
+    assert (back.kind, back.n_opt, back.n_ref, back.n_comp) == (cm.kind, cm.n_opt, cm.n_ref, cm.n_comp)
+    assert int(back.header["n_keypoints"]) == 21 and back.header["human_task"][:3].tolist() == [4, 4, 4]
+    with pytest.raises(ValueError):
+        mc.CompiledModel.from_blob(cm.to_blob()[:-4])
