@@ -14,7 +14,9 @@ BUILD = os.environ.get("DEXR_BUILD_DIR") or os.path.join(REPO, "build")
 LIB = os.environ.get("DEXR_LIB_OUT") or os.path.join(HERE, "libdexr.so")
 BUCKETS = (4, 8, 16, 24, 32)
 CHAIN_BUCKETS = (4,)
+BIG_BUCKETS = (16, 24, 32)
 VARIANTS = ((0, 0), (1, 0), (1, 1), (1, 2))  # (float64?, mode): f32 solve, f64 solve, f64 eval, f64 fk
+BIG_HEADER = os.path.join(CSRC, "dexr_big.hpp")
 HEADERS = [os.path.join(CSRC, "dexr_kernel.hpp"), os.path.join(CSRC, "dexr_launch.hpp"),
            os.path.join(INCLUDE, "dexr.h"), os.path.join(INCLUDE, "dexr_tables.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"] + \
@@ -60,6 +62,14 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
                 continue
             if force or _stale(o, [inst_s] + HEADERS):
                 jobs.append((inst_s, o, [f"-DDEXR_NMAX={n}", f"-DDEXR_F64={f64}", f"-DDEXR_MODE={mode}"]))
+    big_s = os.path.join(CSRC, "dexr_big_inst.hip")
+    for n in BIG_BUCKETS:  # large-component kernel (Hessian in LDS, float64 kinematics)
+        o = os.path.join(BUILD, f"dexr_big_{n}.o")
+        objs.append(o)
+        if only is not None and n not in only and os.path.exists(o):
+            continue
+        if force or _stale(o, [big_s, BIG_HEADER] + HEADERS):
+            jobs.append((big_s, o, [f"-DDEXR_NMAX={n}"]))
     for n in CHAIN_BUCKETS:  # serial-chain specialisation, float32 solve only
         o = os.path.join(BUILD, f"dexr_inst_chain_{n}_0_0.o")
         objs.append(o)

@@ -53,6 +53,8 @@ struct dexr_model {
   int lds_frames = 1;  // max n_frame over components
   int lds_terms = 1;   // max n_term over components
   bool chain = false;  // every component is a plain serial chain filling its bucket (CHAIN kernel applies)
+  bool big = false;    // components of 9+ joints solved by dexr_big_kernel (Hessian in LDS, float64 kinematics)
+  int big_nh_rows = 0; // n_max (n_max + 1) / 2
   // work-queue heads for the persistent-lane kernels: QSLOTS independent sets of n_comp counters handed out
   // round-robin, so launches in flight on different streams never share a queue
   static constexpr int QSLOTS = 64;
@@ -101,8 +103,22 @@ void fill_params(const dexr_model* m, dexr::KernelParams& kp, int64_t B) {
 
 // launch geometry: one wave per (64-item tile, component); waves of a block sit on consecutive components so
 // that the rows of ref/last they share are fetched by one CU.
+int launch_big(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
+  const size_t lds = (size_t)64 * (4 * (size_t)m->big_nh_rows + 8 * 3 * (size_t)m->lds_frames);
+  kp.big_nh_rows = m->big_nh_rows;
+  const int64_t tiles = (kp.B + 63) / 64;
+  const int64_t blocks = tiles * kp.n_comp;
+  if (blocks > 0x7fffffffLL) return fail(DEXR_ERR_INVALID, "batch too large for one launch");
+  dexr::launch_fn fn = dexr::find_big_launcher(m->bucket);
+  if (!fn) return fail(DEXR_ERR_UNSUPPORTED, "no large-component kernel for bucket %d", m->bucket);
+  hipError_t e = fn(kp, dim3((unsigned)blocks), dim3(64), lds, st);
+  if (e != hipSuccess) return fail(DEXR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return DEXR_OK;
+}
+
 int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStream_t st) {
   if (kp.B <= 0) return DEXR_OK;
+  if (mode == dexr::MODE_SOLVE && !f64 && m->big) return launch_big(m, kp, st);
   if (m->bucket == 32 && mode == dexr::MODE_SOLVE) f64 = 1;  // see find_launcher: bucket 32 is float64 only
   const size_t real_sz = f64 ? 8 : 4;
   const size_t per_wave = 64 * real_sz * (size_t)(3 * m->lds_frames + 4 * m->lds_terms);
@@ -160,7 +176,7 @@ void apply_options(dexr::KernelParams& kp, const dexr_solve_options* opt) {
 int polish_launch(const dexr_model* m, dexr::KernelParams kp, const dexr_solve_options* opt, hipStream_t st) {
   int polish = opt ? opt->polish : -1;
   if (polish < 0) polish = (m->h.kind == DEXR_KIND_POSITION || m->h.kind == DEXR_KIND_DEXPILOT) ? 12 : 0;
-  if (polish == 0 || m->bucket == 32) return DEXR_OK;  // bucket 32 already ran in float64
+  if (polish == 0 || m->bucket == 32 || m->big) return DEXR_OK;  // those already ran with float64 kinematics
   kp.x0 = kp.qout;
   kp.max_iter = polish;
   kp.tol *= 0.25f;
@@ -248,6 +264,20 @@ int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out) {
     if (c.n_term > m->lds_terms) m->lds_terms = c.n_term;
   }
   m->bucket = pick_bucket(maxj > 0 ? maxj : 1);
+  {
+    int max_slot = -1;
+    for (const dexr_comp_table& c : m->comps)
+      for (int k = 0; k < c.n_joint; ++k) max_slot = c.save[k] > max_slot ? c.save[k] : max_slot;
+    m->big_nh_rows = maxj * (maxj + 1) / 2;
+    const size_t lds = (size_t)64 * (4 * (size_t)m->big_nh_rows + 8 * 3 * (size_t)m->lds_frames);
+    // Measured on MI355X (65 536 frames, tools/cmp_big.py): the LDS kernel wins where the register kernel needs
+    // its float64 polish launch on a large component (position models: LEAP 9.9 vs 22 ms, Inspire 8.7 vs 27 ms,
+    // Shadow+free 57 vs 170 ms) and loses where it does not (Shadow vector 20 vs 3.8 ms) or where the component is
+    // dense and 24 wide (Shadow DexPilot 51 vs 36 ms: 1 wave/CU and a code footprint beyond the instruction cache).
+    const bool wanted = (h.kind == DEXR_KIND_POSITION || m->bucket == 32) ? !std::getenv("DEXR_NO_BIG")
+                                                                          : std::getenv("DEXR_FORCE_BIG") != nullptr;
+    m->big = wanted && m->bucket >= 16 && h.kind != DEXR_KIND_FKONLY && max_slot < 2 && lds <= 160 * 1024;
+  }
   m->chain = (h.kind == DEXR_KIND_VECTOR || h.kind == DEXR_KIND_POSITION) && !std::getenv("DEXR_NO_CHAIN");
   for (const dexr_comp_table& c : m->comps) {
     if (c.n_joint != m->bucket) m->chain = false;

@@ -1,0 +1,609 @@
+// dexr_big.hpp -- solve kernel for LARGE components (16..32 joints per lane): DexPilot hands, hands with a shared
+// wrist or 6 free joints.
+//
+// Why a second kernel: a dense 24 x 24 Hessian is 300 floats per lane; together with the chain's axes/origins and the
+// Jacobian columns that is > 512 live values, and the register-resident kernel (dexr_kernel.hpp) spills 1.4 KB per
+// lane to scratch memory (15 ms per 65 536 Shadow-DexPilot frames).  Here
+//   * the Hessian / Cholesky factor lives in the lane's LDS column ([entry][lane]: conflict-free ds ops, one
+//     ds_add_f32 per accumulated entry), the factorisation is a rolled right-looking Cholesky whose pivot column is
+//     cached in registers, and its work scales with the component's real joint count n, not the bucket size;
+//   * forward kinematics, frame positions, residuals and the objective value are computed in FLOAT64 (the residual of a
+//     vector term is a difference of positions ~0.2 m that nearly cancels; in float32 that rounding puts a ~1e-4 rad
+//     floor under DexPilot/position solves), while Jacobian columns, gradient, Hessian and the linear solve stay in
+//     FLOAT32 -- so no float64 polish launch is needed for these models;
+//   * per-term targets / DexPilot weights are recomputed from ref_value (L1/L2 hits) instead of occupying LDS.
+// MI355X: 160 KB LDS/CU, so 2 waves/CU at n = 22 (LEAP/Allegro + free joints), 1 wave/CU at n >= 24.
+#pragma once
+
+#include "dexr_kernel.hpp"
+
+namespace dexr {
+
+// float64 sin/cos for joint angles: Cody-Waite reduction by pi/2 (fdlibm constants) + fdlibm kernel polynomials
+static __device__ __forceinline__ void sincos_f64(double a, double* s, double* c) {
+  const double kf = rint(a * 6.36619772367581382433e-01);
+  double r = fma(-kf, 1.57079632673412561417e+00, a);
+  r = fma(-kf, 6.07710050650619224932e-11, r);
+  r = fma(-kf, 2.02226624879595063154e-21, r);
+  const double z = r * r;
+  const double sp = r + r * z * (-1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                    z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)))));
+  const double cp = 1.0 - 0.5 * z + z * z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const int k = (int)kf;
+  const double ss = (k & 1) ? cp : sp;
+  const double cc = (k & 1) ? sp : cp;
+  *s = (k & 2) ? -ss : ss;
+  *c = ((k + 1) & 2) ? -cc : cc;
+}
+
+constexpr int BIG_NSLOT = 2;  // saved transforms kept in registers (float64); deeper forks use the generic kernel
+
+// blockDim.x = 64 (one wave per block); dynamic LDS = 64 * (4 * nh_rows + 8 * 3 * lds_frames) bytes where
+// nh_rows = n_max (n_max + 1) / 2 for the model's largest component.
+template <int NMAX>
+__global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, const dexr_comp_table* __restrict__ comps) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_global = blockIdx.x;
+  const int comp = (int)(wave_global % kp.n_comp);
+  const int64_t tile = wave_global / kp.n_comp;
+  if (tile * 64 >= kp.B) return;
+  const int64_t item_raw = tile * 64 + lane;
+  const bool valid = item_raw < kp.B;
+  const int64_t item = valid ? item_raw : kp.B - 1;
+
+  float* Hl = reinterpret_cast<float*>(lds_raw) + lane;                                 // H(r,c) at Hl[hidx(r,c)*64]
+  double* Pl = reinterpret_cast<double*>(lds_raw + (size_t)kp.big_nh_rows * 64 * 4) + lane;  // frame f at Pl[(3f+i)*64]
+  auto hidx = [](int r, int c) { return r * (r + 1) / 2 + c; };
+
+  const dexr_comp_table& tb = comps[comp];
+  const int nj = tb.n_joint, nt = tb.n_term;
+  const float delta = kp.norm_delta;
+
+  uint32_t vmask = 0, optmask = 0;
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k) {
+    if (k < nj) {
+      const int sk = tb.src_kind[k];
+      if (sk == DEXR_SRC_OPT) { vmask |= 1u << k; optmask |= 1u << k; }
+      else if (sk == DEXR_SRC_MIMIC) vmask |= 1u << k;
+    }
+  }
+
+  // ---- per-lane register state -----------------------------------------------------------------------------
+  float x[NMAX], xo[NMAX], g[NMAX], d[NMAX];
+  float ax[NMAX][3], og[NMAX][3];
+
+  auto ref_row = [&](int row, float (&rv)[3]) {
+    if (kp.kpts) {
+      const float* a = kp.kpts + (item * kp.n_kp + kp.h_task[row]) * 3;
+      const int o = kp.h_origin[row];
+      if (o >= 0) {
+        const float* b = kp.kpts + (item * kp.n_kp + o) * 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rv[i] = a[i] - b[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rv[i] = a[i];
+      }
+    } else {
+      const float* r = kp.ref + (item * kp.n_ref + row) * 3;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) rv[i] = r[i];
+    }
+  };
+  auto xl = [&](int k) -> float { return kp.last[item * kp.n_opt + tb.api[k]]; };  // regularisation target (L1/L2 hit)
+
+  // ---- load the frame ----------------------------------------------------------------------------------------
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k) {
+    x[k] = 0;
+    if (k < nj) {
+      const int sk = tb.src_kind[k];
+      if (sk == DEXR_SRC_OPT) {
+        const float v = kp.x0 ? kp.x0[item * kp.n_opt + tb.api[k]] : kp.last[item * kp.n_opt + tb.api[k]];
+        x[k] = fminf(fmaxf(v, tb.lo[k]), tb.hi[k]);
+      } else if (sk == DEXR_SRC_FIXED) {
+        x[k] = tb.mult[k] * kp.fixed[item * kp.n_fixed + tb.src_idx[k]] + tb.off[k];
+      }
+    }
+  }
+  // DexPilot projection bits (optimizer.py:466-476)
+  uint32_t nst = 0;
+  const bool dexpilot = kp.kind == DEXR_KIND_DEXPILOT;
+  const int F_ = kp.num_fingers, n_pair = F_ * (F_ - 1) / 2, len_s1 = F_ - 1;
+  if (dexpilot) {
+    const uint32_t st = kp.state ? kp.state[item] : 0u;
+    for (int i = 0; i < len_s1; ++i) {
+      float rv[3];
+      ref_row(i, rv);
+      const float dist = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+      bool b = (st >> i) & 1u;
+      if (dist < kp.project_dist) b = true;
+      if (dist > kp.escape_dist) b = false;
+      nst |= (b ? 1u : 0u) << i;
+    }
+    int idx = len_s1;
+    for (int a = 0; a < F_ - 2; ++a)
+      for (int b2 = a + 1; b2 < F_ - 1; ++b2) {
+        float rv[3];
+        ref_row(idx, rv);
+        const float dist = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+        const bool b = ((nst >> b2) & 1u) && ((nst >> a) & 1u) && (dist <= 0.03f);
+        nst |= (b ? 1u : 0u) << idx;
+        ++idx;
+      }
+  }
+  // target vector and weight of one term (optimizer.py:246, 479-507), recomputed on demand
+  auto term_target = [&](int row, float (&tv)[3], float& wt) {
+    float rv[3];
+    ref_row(row, rv);
+    wt = 1.f;
+    if (dexpilot) {
+      if (row < n_pair) {
+        if ((nst >> row) & 1u) {
+          const float dist = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+          const float eta = row < len_s1 ? kp.eta1 : kp.eta2;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) tv[i] = (rv[i] / (dist + 1e-6f)) * eta;
+          wt = row < len_s1 ? 200.f : 400.f;
+          return;
+        }
+      } else {
+        wt = (float)(n_pair + F_);
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) tv[i] = rv[i] * kp.scaling;
+    } else {
+      const float sc = (kp.kind == DEXR_KIND_VECTOR) ? kp.scaling : 1.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) tv[i] = rv[i] * sc;
+    }
+  };
+
+  // base frames never move
+#pragma clang loop unroll(disable) vectorize(disable)
+  for (int f = 0; f < tb.n_base_frame; ++f) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Pl[(f * 3 + i) * 64] = (double)tb.frame_off[f][i];
+  }
+
+  // ---- float64 forward kinematics ------------------------------------------------------------------------------
+  auto fk = [&]() {
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+    double sR[BIG_NSLOT][9], sp[BIG_NSLOT][3];
+#pragma unroll
+    for (int s = 0; s < BIG_NSLOT; ++s) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) sR[s][i] = 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) sp[s][i] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+      if (k < nj) {
+        const int rs = tb.restore[k];
+        if (rs == -2) {
+          R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+          p[0] = 0; p[1] = 0; p[2] = 0;
+        } else if (rs >= 0) {
+#pragma unroll
+          for (int s = 0; s < BIG_NSLOT; ++s)
+            if (rs == s) {
+#pragma unroll
+              for (int i = 0; i < 9; ++i) R[i] = sR[s][i];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) p[i] = sp[s][i];
+            }
+        }
+        const float* Xk = tb.X[k];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) p[i] += R[3 * i] * (double)Xk[9] + R[3 * i + 1] * (double)Xk[10] + R[3 * i + 2] * (double)Xk[11];
+        double Rn[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            Rn[3 * i + j] = R[3 * i] * (double)Xk[j] + R[3 * i + 1] * (double)Xk[3 + j] + R[3 * i + 2] * (double)Xk[6 + j];
+        float qf = x[k];
+        if (tb.src_kind[k] == DEXR_SRC_MIMIC) {  // kinematics_adaptor.py:102-105
+          const int si = tb.src_idx[k];
+          float v = 0;
+#pragma unroll
+          for (int s = 0; s < NMAX; ++s) v += (s == si ? 1.f : 0.f) * x[s];
+          qf = tb.mult[k] * v + tb.off[k];
+          x[k] = qf;
+        }
+        const double q = (double)qf;
+        if (tb.jtype[k] == DEXR_JOINT_REVOLUTE) {
+          double s, c;
+          sincos_f64(q, &s, &c);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const double c0 = Rn[3 * i], c1 = Rn[3 * i + 1];
+            R[3 * i] = c * c0 + s * c1;
+            R[3 * i + 1] = c * c1 - s * c0;
+            R[3 * i + 2] = Rn[3 * i + 2];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) p[i] += q * Rn[3 * i + 2];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          ax[k][i] = (float)R[3 * i + 2];
+          og[k][i] = (float)p[i];
+        }
+        const int sv = tb.save[k];
+        if (sv >= 0) {
+#pragma unroll
+          for (int s = 0; s < BIG_NSLOT; ++s)
+            if (sv == s) {
+#pragma unroll
+              for (int i = 0; i < 9; ++i) sR[s][i] = R[i];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) sp[s][i] = p[i];
+            }
+        }
+        const int fb = tb.fbeg[k], fe = tb.fend[k];
+#pragma clang loop unroll(disable) vectorize(disable)
+        for (int f = fb; f < fe; ++f) {
+          const double o0 = tb.frame_off[f][0], o1 = tb.frame_off[f][1], o2 = tb.frame_off[f][2];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) Pl[(f * 3 + i) * 64] = p[i] + R[3 * i] * o0 + R[3 * i + 1] * o1 + R[3 * i + 2] * o2;
+        }
+      }
+    }
+  };
+
+  const bool per_coord = kp.kind == DEXR_KIND_POSITION;
+  const double beta = (double)kp.huber_delta, ibeta = 1.0 / beta;
+
+  // residual of term t in float64, plus (float32) force, curvature weights and the float32 copies the Jacobian needs
+  struct TermEval { double val; float fvec[3], hw[3], kap, r[3], pt[3], po[3]; };
+  auto eval_term = [&](int t, TermEval& e) {
+    const int ft = tb.term_task[t], fo = tb.term_origin[t];
+    float tv[3], wt;
+    term_target(tb.term_ref[t], tv, wt);
+    double pt[3], po[3] = {0, 0, 0}, r[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pt[i] = Pl[(ft * 3 + i) * 64];
+    if (fo >= 0) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) po[i] = Pl[(fo * 3 + i) * 64];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      r[i] = pt[i] - po[i] - (double)tv[i];
+      e.r[i] = (float)r[i];
+      e.pt[i] = (float)pt[i];
+      e.po[i] = (float)po[i];
+    }
+    const double w = (double)kp.inv_norm * (double)wt;
+    e.kap = 0;
+    if (per_coord) {  // SmoothL1 per coordinate (optimizer.py:130,166)
+      double v = 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double ee = r[i], ae = fabs(ee);
+        const bool quad = ae < beta;
+        v += w * (quad ? 0.5 * ee * ee * ibeta : ae - 0.5 * beta);
+        e.fvec[i] = (float)(w * (quad ? ee * ibeta : (ee > 0 ? 1.0 : -1.0)));
+        e.hw[i] = (float)(w * (quad ? ibeta : 1.0 / ae));
+      }
+      e.val = v;
+    } else {  // SmoothL1 of the vector norm (optimizer.py:272-273, 534-541)
+      const double d2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+      const double dd = sqrt(d2);
+      const bool quad = dd < beta;
+      e.val = w * (quad ? 0.5 * d2 * ibeta : dd - 0.5 * beta);
+      const double id = quad ? ibeta : 1.0 / dd;
+      const double psi = w * id;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        e.fvec[i] = (float)(psi * r[i]);
+        e.hw[i] = (float)psi;
+      }
+      e.kap = quad ? 0.f : (float)(psi * id * id);
+    }
+  };
+
+  const int nh = nj * (nj + 1) / 2;
+  // value F (returned), gradient g (registers) and Hessian H (LDS) of the data term at the FK state, Newton term
+  // included; the regulariser's value is added here, its gradient / curvature by the caller.
+  auto assemble = [&]() -> double {
+    double Fv = 0;
+#pragma clang loop unroll(disable) vectorize(disable)
+    for (int i = 0; i < nh; ++i) Hl[i * 64] = 0.f;
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) g[k] = 0;
+    const bool newton = kp.newton != 0;
+#pragma clang loop unroll(disable) vectorize(disable)
+    for (int t = 0; t < nt; ++t) {
+      TermEval e;
+      eval_term(t, e);
+      Fv += e.val;
+      const int ft = tb.term_task[t], fo = tb.term_origin[t];
+      const uint32_t mt = tb.frame_anc[ft];
+      const uint32_t mo = (fo >= 0) ? tb.frame_anc[fo] : 0u;
+      const uint32_t mu = (mt | mo) & vmask;
+      float col[NMAX][3];
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k) {
+        if ((mu >> k) & 1u) {
+          const bool in_t = (mt >> k) & 1u, in_o = (mo >> k) & 1u;
+          if (tb.jtype[k] == DEXR_JOINT_REVOLUTE) {
+            float v[3] = {0, 0, 0};
+            if (in_t) {
+#pragma unroll
+              for (int i = 0; i < 3; ++i) v[i] += e.pt[i] - og[k][i];
+            }
+            if (in_o) {
+#pragma unroll
+              for (int i = 0; i < 3; ++i) v[i] -= e.po[i] - og[k][i];
+            }
+            col[k][0] = ax[k][1] * v[2] - ax[k][2] * v[1];
+            col[k][1] = ax[k][2] * v[0] - ax[k][0] * v[2];
+            col[k][2] = ax[k][0] * v[1] - ax[k][1] * v[0];
+          } else {
+            const float sg = (in_t ? 1.f : 0.f) - (in_o ? 1.f : 0.f);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) col[k][i] = sg * ax[k][i];
+          }
+          g[k] += col[k][0] * e.fvec[0] + col[k][1] * e.fvec[1] + col[k][2] * e.fvec[2];
+        } else {
+          col[k][0] = 0; col[k][1] = 0; col[k][2] = 0;
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < NMAX; ++rr) {
+        if ((mu >> rr) & 1u) {
+          const float ku = e.kap * (col[rr][0] * e.r[0] + col[rr][1] * e.r[1] + col[rr][2] * e.r[2]);
+          const float cw0 = e.hw[0] * col[rr][0] - ku * e.r[0], cw1 = e.hw[1] * col[rr][1] - ku * e.r[1],
+                      cw2 = e.hw[2] * col[rr][2] - ku * e.r[2];
+          const float cf0 = col[rr][1] * e.fvec[2] - col[rr][2] * e.fvec[1];
+          const float cf1 = col[rr][2] * e.fvec[0] - col[rr][0] * e.fvec[2];
+          const float cf2 = col[rr][0] * e.fvec[1] - col[rr][1] * e.fvec[0];
+          // row rr of H: read the whole row segment with independent ds_reads (one wait), update, write back.
+          // col[cc] is zero for joints outside the term's chain, so no per-entry guard is needed.
+          float hrow[NMAX];
+#pragma unroll
+          for (int cc = 0; cc <= rr; ++cc) hrow[cc] = Hl[(rr * (rr + 1) / 2 + cc) * 64];
+#pragma unroll
+          for (int cc = 0; cc <= rr; ++cc) {
+            float h = cw0 * col[cc][0] + cw1 * col[cc][1] + cw2 * col[cc][2];
+            const bool same = (((mt >> cc) & (mt >> rr)) | ((mo >> cc) & (mo >> rr))) & 1u;
+            if (newton && same && ((mu >> cc) & 1u) && tb.jtype[cc] == DEXR_JOINT_REVOLUTE)
+              h += ax[cc][0] * cf0 + ax[cc][1] * cf1 + ax[cc][2] * cf2;
+            hrow[cc] += h;
+          }
+#pragma unroll
+          for (int cc = 0; cc <= rr; ++cc) Hl[(rr * (rr + 1) / 2 + cc) * 64] = hrow[cc];
+        }
+      }
+    }
+    // mimic fold (kinematics_adaptor.py:107-113): x_k = m x_s + b  =>  congruence on H, fold on g
+#pragma clang loop unroll(disable) vectorize(disable)
+    for (int k = 0; k < nj; ++k) {
+      if (tb.src_kind[k] != DEXR_SRC_MIMIC) continue;
+      const int s = tb.src_idx[k];
+      const float m = tb.mult[k];
+      float gk = 0;
+#pragma unroll
+      for (int j = 0; j < NMAX; ++j)
+        if (j == k) { gk = g[j]; g[j] = 0; }
+#pragma unroll
+      for (int j = 0; j < NMAX; ++j)
+        if (j == s) g[j] += m * gk;
+      auto H = [&](int r, int c) -> float& { return r >= c ? Hl[hidx(r, c) * 64] : Hl[hidx(c, r) * 64]; };
+      const float hkk = H(k, k), hks = H(k, s);
+      for (int j = 0; j < nj; ++j) {
+        if (j == k || j == s) continue;
+        H(j, s) += m * H(j, k);
+      }
+      H(s, s) += 2.f * m * hks + m * m * hkk;
+      for (int j = 0; j < nj; ++j) H(j, k) = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k)
+      if ((optmask >> k) & 1u) {
+        const double dx = (double)x[k] - (double)xl(k);
+        Fv += (double)delta * dx * dx;
+      }
+    return Fv;
+  };
+
+  // ---- in-place Cholesky in LDS (rolled, right-looking) + solve (H + mask/damping) dvec = -g ---------------------
+  // freemask: lane-varying set of optimised joints not held at a bound.  Returns false if a pivot is not positive.
+  auto factor_and_solve = [&](uint32_t freemask, float lam) -> bool {
+    bool ok = true;
+    // reduced, damped system: rows/cols of held or non-variable joints become identity
+#pragma clang loop unroll(disable) vectorize(disable)
+    for (int r = 0; r < nj; ++r) {
+      const bool fr = (freemask >> r) & 1u;
+      for (int c = 0; c < r; ++c) {
+        const bool fc = (freemask >> c) & 1u;
+        if (!(fr && fc)) Hl[hidx(r, c) * 64] = 0.f;
+      }
+      float& hrr = Hl[hidx(r, r) * 64];
+      hrr = fr ? hrr + 2.f * delta + lam : 1.f;
+    }
+    // Right-looking Cholesky, one column per (runtime) j.  The body is branch-light on purpose: the pivot column is read
+    // with 24 independent ds_reads (inactive rows read the pivot itself), scaled in registers and written back
+    // unconditionally; the trailing update is issued as ds_add_f32 (no read, hence no LDS round trip on the critical
+    // path) -- entries left of the pivot receive +-0.
+    float Lj[NMAX];
+#pragma clang loop unroll(disable) vectorize(disable)
+    for (int j = 0; j < nj; ++j) {
+      const int pj = hidx(j, j);
+      float cj[NMAX];
+#pragma unroll
+      for (int i = 0; i < NMAX; ++i) {
+        const bool act = (i > j) && (i < nj);
+        cj[i] = Hl[(act ? hidx(i, j) : pj) * 64];
+      }
+      float dj = Hl[pj * 64];
+      if (!(dj > 1e-30f)) { ok = false; dj = 1.f; }
+      const float iv = __frsqrt_rn(dj);
+      const float sq = dj * iv;
+#pragma unroll
+      for (int i = 0; i < NMAX; ++i) {
+        const bool act = (i > j) && (i < nj);
+        Lj[i] = act ? cj[i] * iv : 0.f;
+        Hl[(act ? hidx(i, j) : pj) * 64] = act ? Lj[i] : sq;
+      }
+#pragma unroll
+      for (int i = 1; i < NMAX; ++i) {
+        if (i > j && i < nj) {  // row i: batched read, rank-one update (Lj[k] = 0 for k <= j), batched write
+          const float li = Lj[i];
+          float hrow[NMAX];
+#pragma unroll
+          for (int k = 1; k <= i; ++k) hrow[k] = Hl[hidx(i, k) * 64];
+#pragma unroll
+          for (int k = 1; k <= i; ++k) Hl[hidx(i, k) * 64] = hrow[k] - li * Lj[k];
+        }
+      }
+    }
+    // forward: L y = -g ; backward: L^T dvec = y   (static indices into d[], dynamic guards on n)
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) {
+      if (i < nj) {
+        float s = ((freemask >> i) & 1u) ? -g[i] : 0.f;
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= Hl[hidx(i, k) * 64] * d[k];
+        d[i] = s * __frcp_rn(Hl[hidx(i, i) * 64]);
+      } else {
+        d[i] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = NMAX - 1; i >= 0; --i) {
+      if (i < nj) {
+        float s = d[i];
+#pragma unroll
+        for (int k = i + 1; k < NMAX; ++k)
+          if (k < nj) s -= Hl[hidx(k, i) * 64] * d[k];
+        d[i] = s * __frcp_rn(Hl[hidx(i, i) * 64]);
+      }
+    }
+    return ok;
+  };
+
+  // ---- projected Levenberg-Marquardt / Newton ------------------------------------------------------------------
+  // One pass of the loop = forward kinematics + fused value/gradient/Hessian at the point under evaluation
+  // (x itself, or the pending trial point) + one factorisation.  FK, assembly and factorisation each appear ONCE in
+  // the instruction stream (the unrolled bodies are tens of KB; the 64 KB instruction cache is the scarce resource).
+  // A rejected trial costs one extra pass (the model at the old x is rebuilt), like the register kernel's re-run.
+  float lam = kp.lam0, nu = 2.f, sprev = 1e30f;
+  bool done = false, pending = false;  // pending: x holds an untested trial point, xo the accepted point
+  int status = ST_MAXITER, my_iters = 0, blind = 0;
+  double F = 0;
+  float smax = 0, pred = 0;
+  bool ok = true;
+  const int max_pass = 2 * kp.max_iter + 2;
+  for (int pass = 0; pass < max_pass; ++pass) {
+    if (__all(done)) break;
+    fk();
+    const double Fe = assemble();
+    bool rebuild = false;  // this lane rejected its trial: its model must be rebuilt at xo before it can step again
+    if (!done) {
+      if (!pending) {
+        F = Fe;  // model (re)built at the accepted point
+      } else {
+        const double noise = 64.0 * 1.1102230246251565e-16 * fabs(F);
+        const bool finite = (Fe == Fe) && (smax == smax) && (fabs(Fe) < 1e30);
+        const bool below_floor = ok && finite && ((double)pred <= noise) && (smax < 1e-2f);
+        const bool accept = ok && finite && ((Fe <= F) || below_floor);
+        ++my_iters;
+        pending = false;
+        if (accept) {
+          const float rho = (float)((F - Fe) / fmax((double)pred, 1e-30));
+          const float tt = 2.f * rho - 1.f;
+          lam = fmaxf(lam * (below_floor ? (1.f / 3.f) : fmaxf(1.f / 3.f, 1.f - tt * tt * tt)), 1e-9f);
+          nu = 2.f;
+          F = Fe;
+          const bool stalled = below_floor && blind >= 2 && smax > 0.9f * sprev && smax < 20.f * kp.tol;
+          blind = below_floor ? blind + 1 : 0;
+          sprev = smax;
+          if (smax < kp.tol || stalled || blind >= kp.max_blind) {
+            done = true;
+            status = ST_CONVERGED;
+          }
+        } else {
+          lam = fmaxf(lam, 1e-6f) * nu;
+          nu *= 2.f;
+#pragma unroll
+          for (int k = 0; k < NMAX; ++k) x[k] = xo[k];
+          if (lam > 1e10f) {
+            done = true;
+            status = finite ? ST_CONVERGED : ST_FALLBACK;
+          }
+          rebuild = true;  // the model in g/H belongs to the rejected point: rebuilt at xo in the next pass
+        }
+        if (!done && my_iters >= kp.max_iter) done = true;
+      }
+    }
+    if (__all(done)) break;
+    // step from the model at x
+    uint32_t freemask = 0;
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+      if ((optmask >> k) & 1u) {
+        g[k] += 2.f * delta * (x[k] - xl(k));
+        const bool act = (x[k] <= tb.lo[k] && g[k] > 0) || (x[k] >= tb.hi[k] && g[k] < 0);
+        if (!act) freemask |= 1u << k;
+      } else {
+        g[k] = 0;
+      }
+    }
+    const bool okf = factor_and_solve(freemask, lam);
+    const bool stepping = !done && !rebuild;
+    if (stepping) {
+      ok = okf;
+      smax = 0;
+      pred = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+      if (stepping) {
+        xo[k] = x[k];
+        if ((freemask >> k) & 1u) {
+          const float xt = fminf(fmaxf(x[k] + d[k], tb.lo[k]), tb.hi[k]);
+          pred += 0.5f * d[k] * (lam * d[k] - g[k]);
+          smax = fmaxf(smax, fabsf(xt - x[k]));
+          x[k] = xt;
+        }
+      }
+    }
+    pending = stepping;
+  }
+  if (pending) {  // pass budget exhausted with an untested trial: hand back the accepted point
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) x[k] = xo[k];
+  }
+
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k)
+    if ((optmask >> k) & 1u) bad = bad || !(x[k] == x[k]);
+  if (bad) status = ST_FALLBACK;
+  if (valid) {
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+      if ((optmask >> k) & 1u) {
+        const float v = bad ? xl(k) : x[k];
+        kp.qout[item * kp.n_opt + tb.api[k]] = v;
+        if (kp.qout64) kp.qout64[item * kp.n_opt + tb.api[k]] = (double)v;
+      }
+    }
+    if (dexpilot && kp.state && comp == 0) kp.state[item] = nst;
+    if (kp.status) atomicMax(&kp.status[item], status);
+    if (kp.iters) atomicMax(&kp.iters[item], my_iters);
+    if (kp.fval) atomicAdd(&kp.fval[item], (float)F);
+  }
+}
+
+}  // namespace dexr

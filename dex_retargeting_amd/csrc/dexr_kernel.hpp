@@ -51,6 +51,7 @@ struct KernelParams {
   int32_t newton;
   int32_t max_blind;  // accepted steps below the rounding floor of F before giving up on further progress
   int32_t lds_frames, lds_terms;  // per-wave LDS rows: max frames / max terms over the model's components
+  int32_t big_nh_rows;            // dexr_big_kernel: LDS rows reserved for the Hessian (n_max (n_max + 1) / 2)
   uint32_t qchunk;                // frames a wave takes from its component's queue per atomicAdd; 0 = tile mode
                                   // (wave w owns frames [64*tile, 64*tile+64), no queue traffic)
   int32_t n_kp;                   // keypoints per frame (21 for MediaPipe/MANO hands)

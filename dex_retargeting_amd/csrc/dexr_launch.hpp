@@ -26,6 +26,14 @@ DEXR_DECL(32)
 // serial-chain specialisation (see LaneSolver's CHAIN flag): float32 solve, 4-joint bucket
 hipError_t launch_chain_4_0_0(const KernelParams&, dim3, dim3, size_t, hipStream_t);
 
+// large-component kernel (dexr_big.hpp): float64 kinematics + float32 Hessian in LDS
+hipError_t launch_big_16(const KernelParams&, dim3, dim3, size_t, hipStream_t);
+hipError_t launch_big_24(const KernelParams&, dim3, dim3, size_t, hipStream_t);
+hipError_t launch_big_32(const KernelParams&, dim3, dim3, size_t, hipStream_t);
+static inline launch_fn find_big_launcher(int bucket) {
+  return bucket == 16 ? launch_big_16 : bucket == 24 ? launch_big_24 : bucket == 32 ? launch_big_32 : nullptr;
+}
+
 static inline launch_fn find_launcher(int bucket, int f64, int mode, bool chain = false) {
   if (chain && bucket == 4 && !f64 && mode == MODE_SOLVE) return launch_chain_4_0_0;
 #define DEXR_CASE(N)                                                  \
