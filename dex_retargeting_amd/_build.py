@@ -17,6 +17,8 @@ CHAIN_BUCKETS = (4,)
 BIG_BUCKETS = (16, 24, 32)
 VARIANTS = ((0, 0), (1, 0), (1, 1), (1, 2))  # (float64?, mode): f32 solve, f64 solve, f64 eval, f64 fk
 BIG_HEADER = os.path.join(CSRC, "dexr_big.hpp")
+QUAD_HEADER = os.path.join(CSRC, "dexr_quad.hpp")
+QUAD_BUCKETS = (16, 24)
 HEADERS = [os.path.join(CSRC, "dexr_kernel.hpp"), os.path.join(CSRC, "dexr_launch.hpp"),
            os.path.join(INCLUDE, "dexr.h"), os.path.join(INCLUDE, "dexr_tables.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"] + \
@@ -70,6 +72,14 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             continue
         if force or _stale(o, [big_s, BIG_HEADER] + HEADERS):
             jobs.append((big_s, o, [f"-DDEXR_NMAX={n}"]))
+    quad_s = os.path.join(CSRC, "dexr_quad_inst.hip")
+    for n in QUAD_BUCKETS:  # four-lanes-per-frame kernel for dense components
+        o = os.path.join(BUILD, f"dexr_quad_{n}.o")
+        objs.append(o)
+        if only is not None and n not in only and os.path.exists(o):
+            continue
+        if force or _stale(o, [quad_s, QUAD_HEADER, BIG_HEADER] + HEADERS):
+            jobs.append((quad_s, o, [f"-DDEXR_NMAX={n}"]))
     for n in CHAIN_BUCKETS:  # serial-chain specialisation, float32 solve only
         o = os.path.join(BUILD, f"dexr_inst_chain_{n}_0_0.o")
         objs.append(o)

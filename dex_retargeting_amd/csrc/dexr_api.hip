@@ -53,6 +53,7 @@ struct dexr_model {
   int lds_frames = 1;  // max n_frame over components
   int lds_terms = 1;   // max n_term over components
   bool chain = false;  // every component is a plain serial chain filling its bucket (CHAIN kernel applies)
+  bool quad = false;   // dense 9..24-joint components solved four lanes per frame (dexr_quad_kernel)
   bool big = false;    // components of 9+ joints solved by dexr_big_kernel (Hessian in LDS, float64 kinematics)
   int big_nh_rows = 0; // n_max (n_max + 1) / 2
   // work-queue heads for the persistent-lane kernels: QSLOTS independent sets of n_comp counters handed out
@@ -116,8 +117,24 @@ int launch_big(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
   return DEXR_OK;
 }
 
+int launch_quad(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
+  const size_t per_wave = (size_t)64 * (8 * 3 * (size_t)m->lds_frames + 4 * 3 * (size_t)m->bucket);
+  int wpb = 4;
+  while (wpb > 1 && per_wave * wpb > 150 * 1024) wpb >>= 1;
+  const int64_t tiles = (kp.B + 15) / 16;  // 16 frames per wave
+  const int64_t waves = tiles * kp.n_comp;
+  const int64_t blocks = (waves + wpb - 1) / wpb;
+  if (blocks > 0x7fffffffLL) return fail(DEXR_ERR_INVALID, "batch too large for one launch");
+  dexr::launch_fn fn = dexr::find_quad_launcher(m->bucket);
+  if (!fn) return fail(DEXR_ERR_UNSUPPORTED, "no quad kernel for bucket %d", m->bucket);
+  hipError_t e = fn(kp, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, st);
+  if (e != hipSuccess) return fail(DEXR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return DEXR_OK;
+}
+
 int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStream_t st) {
   if (kp.B <= 0) return DEXR_OK;
+  if (mode == dexr::MODE_SOLVE && !f64 && m->quad) return launch_quad(m, kp, st);
   if (mode == dexr::MODE_SOLVE && !f64 && m->big) return launch_big(m, kp, st);
   if (m->bucket == 32 && mode == dexr::MODE_SOLVE) f64 = 1;  // see find_launcher: bucket 32 is float64 only
   const size_t real_sz = f64 ? 8 : 4;
@@ -176,7 +193,7 @@ void apply_options(dexr::KernelParams& kp, const dexr_solve_options* opt) {
 int polish_launch(const dexr_model* m, dexr::KernelParams kp, const dexr_solve_options* opt, hipStream_t st) {
   int polish = opt ? opt->polish : -1;
   if (polish < 0) polish = (m->h.kind == DEXR_KIND_POSITION || m->h.kind == DEXR_KIND_DEXPILOT) ? 12 : 0;
-  if (polish == 0 || m->bucket == 32 || m->big) return DEXR_OK;  // those already ran with float64 kinematics
+  if (polish == 0 || m->bucket == 32 || m->big || m->quad) return DEXR_OK;  // those ran with float64 kinematics
   kp.x0 = kp.qout;
   kp.max_iter = polish;
   kp.tol *= 0.25f;
@@ -277,6 +294,17 @@ int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out) {
     const bool wanted = (h.kind == DEXR_KIND_POSITION || m->bucket == 32) ? !std::getenv("DEXR_NO_BIG")
                                                                           : std::getenv("DEXR_FORCE_BIG") != nullptr;
     m->big = wanted && m->bucket >= 16 && h.kind != DEXR_KIND_FKONLY && max_slot < 2 && lds <= 160 * 1024;
+    // four lanes per frame: dense vector / DexPilot components of 9..24 joints without mimic joints, one fork level
+    bool has_mimic = false;
+    for (const dexr_comp_table& c : m->comps)
+      for (int k = 0; k < c.n_joint; ++k) has_mimic = has_mimic || c.src_kind[k] == DEXR_SRC_MIMIC;
+    // Measured (65 536 frames, tools/cmp_big.py): Shadow DexPilot (24 joints, dense) 19.6 ms vs 35.8 ms for the register
+    // kernel + float64 polish; but slower for 16-joint DexPilot hands (8.9 vs 6.8 ms) and for Shadow vector (6.9 vs
+    // 3.8 ms, which needs no polish): used where it wins, DEXR_FORCE_QUAD=1 selects it for every eligible model.
+    const bool quad_ok = !m->big && (m->bucket == 16 || m->bucket == 24) && !has_mimic && max_slot < 1 &&
+                         (h.kind == DEXR_KIND_VECTOR || h.kind == DEXR_KIND_DEXPILOT);
+    m->quad = quad_ok && !std::getenv("DEXR_NO_QUAD") &&
+              ((m->bucket == 24 && h.kind == DEXR_KIND_DEXPILOT) || std::getenv("DEXR_FORCE_QUAD"));
   }
   m->chain = (h.kind == DEXR_KIND_VECTOR || h.kind == DEXR_KIND_POSITION) && !std::getenv("DEXR_NO_CHAIN");
   for (const dexr_comp_table& c : m->comps) {

@@ -34,6 +34,13 @@ static inline launch_fn find_big_launcher(int bucket) {
   return bucket == 16 ? launch_big_16 : bucket == 24 ? launch_big_24 : bucket == 32 ? launch_big_32 : nullptr;
 }
 
+// four-lanes-per-frame kernel for dense 9..24-joint components (dexr_quad.hpp)
+hipError_t launch_quad_16(const KernelParams&, dim3, dim3, size_t, hipStream_t);
+hipError_t launch_quad_24(const KernelParams&, dim3, dim3, size_t, hipStream_t);
+static inline launch_fn find_quad_launcher(int bucket) {
+  return bucket == 16 ? launch_quad_16 : bucket == 24 ? launch_quad_24 : nullptr;
+}
+
 static inline launch_fn find_launcher(int bucket, int f64, int mode, bool chain = false) {
   if (chain && bucket == 4 && !f64 && mode == MODE_SOLVE) return launch_chain_4_0_0;
 #define DEXR_CASE(N)                                                  \
