@@ -204,6 +204,19 @@ def main():
                                "sample": f"first {done} frames of the same workload, oracle restatement of the reference "
                                          f"objective + scipy SLSQP (ftol {prob.ftol:g}) standing in for nlopt, one process",
                                "host_cpus": os.cpu_count()}
+        # the same solve fanned over host processes (frames are independent): what the reference could do on this box
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        procs = int(os.environ.get("DEXR_CPU_PROCS", min(avail, 64)))
+        if procs > 1:
+            from oracle import cpu_worker
+
+            per_proc = max(8, int(out["cpu_baseline"]["value"] * 6.0))  # ~6 s of work per process
+            res = cpu_worker.run_all_cores(rel, ref_now, last, procs, per_proc)
+            if res is not None:
+                out["cpu_baseline_all_cores"] = {
+                    "value": res[0] / res[1], "unit": "frames/s", "cores": procs, "kind": "port",
+                    "sample": f"first {res[0]} frames, {procs} processes x {per_proc} frames started together, same "
+                              f"solver as cpu_baseline; {avail} CPUs available to the process"}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

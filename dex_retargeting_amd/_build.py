@@ -48,6 +48,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     objs.append(api_o)
     if force or _stale(api_o, [api_s] + HEADERS):
         jobs.append((api_s, api_o, []))
+    prep_s, prep_o = os.path.join(CSRC, "dexr_prep.hip"), os.path.join(BUILD, "dexr_prep.o")
+    objs.append(prep_o)
+    if force or _stale(prep_o, [prep_s, os.path.join(INCLUDE, "dexr.h")]):
+        jobs.append((prep_s, prep_o, []))
     inst_s = os.path.join(CSRC, "dexr_inst.hip")
     # developer shortcut: DEXR_BUILD_ONLY="4,8" rebuilds only those buckets and reuses the other objects as they are
     # (only valid while KernelParams / the launcher signature are unchanged)

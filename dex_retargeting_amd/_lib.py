@@ -25,7 +25,8 @@ class SolveOptions(C.Structure):
 
 EXPORTS = ["dexr_last_error", "dexr_version", "dexr_device_count", "dexr_default_options", "dexr_model_create",
            "dexr_model_destroy", "dexr_model_info", "dexr_retarget_dev", "dexr_retarget", "dexr_retarget_f64",
-           "dexr_retarget_kp_dev", "dexr_retarget_kp", "dexr_eval", "dexr_fk"]
+           "dexr_retarget_kp_dev", "dexr_retarget_kp", "dexr_eval", "dexr_fk", "dexr_mano_keypoints_dev",
+           "dexr_mano_keypoints"]
 
 
 def load() -> C.CDLL:
@@ -63,6 +64,8 @@ def load() -> C.CDLL:
     lib.dexr_retarget_f64.argtypes = [vp, i64, f32p, f32p, f32p, u32p, f64p, i32p, i32p, optp]
     lib.dexr_eval.argtypes = [vp, i64, f32p, f32p, f32p, f64p, u32p, f64p, f64p]
     lib.dexr_fk.argtypes = [vp, i64, f64p, f64p]
+    lib.dexr_mano_keypoints_dev.argtypes = [i64, vp, f32p, vp, vp, vp]
+    lib.dexr_mano_keypoints.argtypes = [i64, f32p, f32p, f32p, f32p]
     _lib = lib
     return lib
 

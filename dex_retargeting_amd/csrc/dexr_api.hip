@@ -79,6 +79,12 @@ void fill_params(const dexr_model* m, dexr::KernelParams& kp, int64_t B) {
   kp.comps = m->d_comps;
   kp.B = B;
   kp.n_comp = h.n_comp;
+  // damping dynamics (measured, tools/term_sweep.py): a rejected step raises lambda at least to lam_jump x the mean
+  // curvature instead of creeping up by x2, x4, ...; small components also drop it by 10x (not 3x) after a step the
+  // model predicted well.  Allegro vector, 65 536 frames: 0.143 -> 0.119 ms; Shadow DexPilot: 19.4 -> 15.4 ms.
+  kp.lam_jump = m->bucket <= 8 ? 1.0f : 0.3f;
+  kp.lam_fastdec = m->bucket <= 8 ? 0.1f : 0.f;
+  kp.floor_scale = 1e-12f;
   kp.n_opt = h.n_opt;
   kp.n_fixed = h.n_fixed;
   kp.n_ref = h.n_ref;
@@ -134,7 +140,11 @@ int launch_quad(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
 
 int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStream_t st) {
   if (kp.B <= 0) return DEXR_OK;
-  if (mode == dexr::MODE_SOLVE && !f64 && m->quad) return launch_quad(m, kp, st);
+  if (mode == dexr::MODE_SOLVE && !f64 && m->quad) {
+    // the quad kernel scales its damping jump by the curvature along the failed step (not by mean diag H)
+    if (!std::getenv("DEXR_LAM_JUMP")) kp.lam_jump = 1.0f;
+    return launch_quad(m, kp, st);
+  }
   if (mode == dexr::MODE_SOLVE && !f64 && m->big) return launch_big(m, kp, st);
   if (m->bucket == 32 && mode == dexr::MODE_SOLVE) f64 = 1;  // see find_launcher: bucket 32 is float64 only
   const size_t real_sz = f64 ? 8 : 4;
@@ -158,12 +168,16 @@ int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStr
     kp.qchunk = 0;  // tile mode: no queue traffic at all
     if (tiles >= persist_from * per_comp) {
       waves = per_comp * kp.n_comp;
+      kp.q0 = (uint32_t)(per_comp * 64);
       kp.qchunk = 256;
+      if (const char* e = std::getenv("DEXR_QCHUNK")) kp.qchunk = std::atoi(e) > 0 ? std::atoi(e) : 256;
     }
-    const unsigned slot = m->qnext.fetch_add(1u) % dexr_model::QSLOTS;
-    kp.queue = m->d_queue + (size_t)slot * kp.n_comp;
-    hipError_t qe = hipMemsetAsync(kp.queue, 0, (size_t)kp.n_comp * sizeof(unsigned), st);
-    if (qe != hipSuccess) return fail(DEXR_ERR_HIP, "queue reset failed: %s", hipGetErrorString(qe));
+    if (kp.qchunk) {
+      const unsigned slot = m->qnext.fetch_add(1u) % dexr_model::QSLOTS;
+      kp.queue = m->d_queue + (size_t)slot * kp.n_comp;
+      hipError_t qe = hipMemsetAsync(kp.queue, 0, (size_t)kp.n_comp * sizeof(unsigned), st);
+      if (qe != hipSuccess) return fail(DEXR_ERR_HIP, "queue reset failed: %s", hipGetErrorString(qe));
+    }
   }
   const int64_t blocks = (waves + wpb - 1) / wpb;
   if (blocks > 0x7fffffffLL) return fail(DEXR_ERR_INVALID, "batch too large for one launch");
@@ -183,6 +197,15 @@ void apply_options(dexr::KernelParams& kp, const dexr_solve_options* opt) {
   kp.lam0 = o.lambda0 > 0 ? o.lambda0 : 1e-4f;
   kp.newton = o.newton;
   kp.max_blind = 8;
+  if (const char* e = std::getenv("DEXR_LAM_JUMP")) kp.lam_jump = (float)std::atof(e);
+  if (const char* e = std::getenv("DEXR_LAM_FASTDEC")) kp.lam_fastdec = (float)std::atof(e);
+  if (const char* e = std::getenv("DEXR_FLOOR")) kp.floor_scale = (float)std::atof(e);
+  kp.stall_from = 2;
+  kp.stall_ratio = 0.9f;
+  kp.stall_cap = 20.f;
+  if (const char* e = std::getenv("DEXR_STALL_FROM")) kp.stall_from = std::atoi(e);
+  if (const char* e = std::getenv("DEXR_STALL_RATIO")) kp.stall_ratio = (float)std::atof(e);
+  if (const char* e = std::getenv("DEXR_STALL_CAP")) kp.stall_cap = (float)std::atof(e);
   if (const char* e = std::getenv("DEXR_MAX_BLIND")) kp.max_blind = std::atoi(e);  // developer knobs
   if (const char* e = std::getenv("DEXR_MAX_ITER")) kp.max_iter = std::atoi(e);
   if (const char* e = std::getenv("DEXR_NEWTON")) kp.newton = std::atoi(e);
@@ -204,11 +227,14 @@ int polish_launch(const dexr_model* m, dexr::KernelParams kp, const dexr_solve_o
 
 }  // namespace
 
+// dexr_prep.hip
+int dexr_prep_launch(int64_t B, const float* kp, const float* op9, float* out, float* rot, hipStream_t st);
+
 extern "C" {
 
 const char* dexr_last_error(void) { return g_err.c_str(); }
 
-const char* dexr_version(void) { return "dexr 0.1 (gfx950; table v3)"; }
+const char* dexr_version(void) { return "dexr 0.1 (gfx950; table v4)"; }
 
 int dexr_device_count(void) {
   int n = 0;
@@ -539,6 +565,36 @@ int dexr_fk(const dexr_model* m, int64_t B, const double* q, double* pos_out) {
   if (rc != DEXR_OK) return rc;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(pos_out, d_p.p, p_b, hipMemcpyDeviceToHost));
+  return DEXR_OK;
+}
+
+int dexr_mano_keypoints_dev(int64_t B, const float* keypoints, const float* operator2mano, float* joint_pos_out,
+                            float* wrist_rot_out, void* stream) {
+  if (!keypoints || !operator2mano || !joint_pos_out) return fail(DEXR_ERR_INVALID, "null argument");
+  if (B < 0) return fail(DEXR_ERR_INVALID, "negative batch");
+  if (B == 0) return DEXR_OK;
+  const int rc = dexr_prep_launch(B, keypoints, operator2mano, joint_pos_out, wrist_rot_out, static_cast<hipStream_t>(stream));
+  if (rc != 0) return fail(DEXR_ERR_HIP, "keypoint kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+  return DEXR_OK;
+}
+
+int dexr_mano_keypoints(int64_t B, const float* keypoints, const float* operator2mano, float* joint_pos_out,
+                        float* wrist_rot_out) {
+  if (!keypoints || !operator2mano || !joint_pos_out) return fail(DEXR_ERR_INVALID, "null argument");
+  if (B < 0) return fail(DEXR_ERR_INVALID, "negative batch");
+  if (B == 0) return DEXR_OK;
+  const size_t kp_b = (size_t)B * 21 * 3 * sizeof(float), r_b = (size_t)B * 9 * sizeof(float);
+  DevBuf d_in, d_out, d_rot;
+  HIP_TRY(d_in.alloc(kp_b));
+  HIP_TRY(d_out.alloc(kp_b));
+  HIP_TRY(d_rot.alloc(wrist_rot_out ? r_b : 0));
+  HIP_TRY(hipMemcpy(d_in.p, keypoints, kp_b, hipMemcpyHostToDevice));
+  const int rc = dexr_mano_keypoints_dev(B, d_in.as<float>(), operator2mano, d_out.as<float>(),
+                                         wrist_rot_out ? d_rot.as<float>() : nullptr, nullptr);
+  if (rc != DEXR_OK) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(joint_pos_out, d_out.p, kp_b, hipMemcpyDeviceToHost));
+  if (wrist_rot_out) HIP_TRY(hipMemcpy(wrist_rot_out, d_rot.p, r_b, hipMemcpyDeviceToHost));
   return DEXR_OK;
 }
 

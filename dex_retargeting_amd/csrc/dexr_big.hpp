@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
         const bool quad = ae < beta;
         v += w * (quad ? 0.5 * ee * ee * ibeta : ae - 0.5 * beta);
         e.fvec[i] = (float)(w * (quad ? ee * ibeta : (ee > 0 ? 1.0 : -1.0)));
-        e.hw[i] = (float)(w * (quad ? ibeta : 1.0 / ae));
+        e.hw[i] = (float)(w * (quad ? ibeta : (kp.newton != 0 ? 0.0 : 1.0 / ae)));  // exact curvature in Newton mode
       }
       e.val = v;
     } else {  // SmoothL1 of the vector norm (optimizer.py:272-273, 534-541)
@@ -418,9 +418,11 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
 
   // ---- in-place Cholesky in LDS (rolled, right-looking) + solve (H + mask/damping) dvec = -g ---------------------
   // freemask: lane-varying set of optimised joints not held at a bound.  Returns false if a pivot is not positive.
+  float hdmean = 0.f;  // mean diagonal of the free block of the last factored model (scale for the damping jump)
   auto factor_and_solve = [&](uint32_t freemask, float lam) -> bool {
     bool ok = true;
     // reduced, damped system: rows/cols of held or non-variable joints become identity
+    float hds = 0.f;
 #pragma clang loop unroll(disable) vectorize(disable)
     for (int r = 0; r < nj; ++r) {
       const bool fr = (freemask >> r) & 1u;
@@ -429,8 +431,11 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
         if (!(fr && fc)) Hl[hidx(r, c) * 64] = 0.f;
       }
       float& hrr = Hl[hidx(r, r) * 64];
+      hds += fr ? hrr : 0.f;
       hrr = fr ? hrr + 2.f * delta + lam : 1.f;
     }
+    const int hdn = __popc(freemask);
+    hdmean = hds / (float)(hdn > 0 ? hdn : 1);
     // Right-looking Cholesky, one column per (runtime) j.  The body is branch-light on purpose: the pivot column is read
     // with 24 independent ds_reads (inactive rows read the pivot itself), scaled in registers and written back
     // unconditionally; the trailing update is issued as ds_add_f32 (no read, hence no LDS round trip on the critical
@@ -513,7 +518,7 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
       if (!pending) {
         F = Fe;  // model (re)built at the accepted point
       } else {
-        const double noise = 64.0 * 1.1102230246251565e-16 * fabs(F);
+        const double noise = (double)kp.floor_scale * fabs(F);
         const bool finite = (Fe == Fe) && (smax == smax) && (fabs(Fe) < 1e30);
         const bool below_floor = ok && finite && ((double)pred <= noise) && (smax < 1e-2f);
         const bool accept = ok && finite && ((Fe <= F) || below_floor);
@@ -522,10 +527,12 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
         if (accept) {
           const float rho = (float)((F - Fe) / fmax((double)pred, 1e-30));
           const float tt = 2.f * rho - 1.f;
-          lam = fmaxf(lam * (below_floor ? (1.f / 3.f) : fmaxf(1.f / 3.f, 1.f - tt * tt * tt)), 1e-9f);
+          float shrink = below_floor ? (1.f / 3.f) : fmaxf(1.f / 3.f, 1.f - tt * tt * tt);
+          if (kp.lam_fastdec > 0 && rho > 0.9f) shrink = kp.lam_fastdec;
+          lam = fmaxf(lam * shrink, 1e-9f);
           nu = 2.f;
           F = Fe;
-          const bool stalled = below_floor && blind >= 2 && smax > 0.9f * sprev && smax < 20.f * kp.tol;
+          const bool stalled = below_floor && blind >= kp.stall_from && smax > kp.stall_ratio * sprev && smax < kp.stall_cap * kp.tol;
           blind = below_floor ? blind + 1 : 0;
           sprev = smax;
           if (smax < kp.tol || stalled || blind >= kp.max_blind) {
@@ -534,6 +541,7 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
           }
         } else {
           lam = fmaxf(lam, 1e-6f) * nu;
+          if (kp.lam_jump > 0) lam = fmaxf(lam, kp.lam_jump * hdmean);
           nu *= 2.f;
 #pragma unroll
           for (int k = 0; k < NMAX; ++k) x[k] = xo[k];

@@ -52,6 +52,14 @@ struct KernelParams {
   int32_t max_blind;  // accepted steps below the rounding floor of F before giving up on further progress
   int32_t lds_frames, lds_terms;  // per-wave LDS rows: max frames / max terms over the model's components
   int32_t big_nh_rows;            // dexr_big_kernel: LDS rows reserved for the Hessian (n_max (n_max + 1) / 2)
+  float lam_jump;                 // on a rejected step lambda becomes at least lam_jump x mean diag(H) (0: plain x nu)
+  float lam_fastdec;              // on an accepted step with rho > 0.9 lambda shrinks by this factor (0: Nielsen's 1/3)
+  float floor_scale;              // mixed-precision kernels: value differences below floor_scale x |F| are unverifiable
+  int32_t stall_from;             // termination at the float rounding floor (see "stalled" in the kernels): from this
+  float stall_ratio;              // many unverifiable ("blind") steps on, a step that is not < stall_ratio x the
+  float stall_cap;                // previous one and is < stall_cap x tol ends the solve
+  uint32_t q0;                    // queue mode: frames [0, q0) are handed out statically (wave w starts with tile w),
+                                  // the queue counter numbers the frames from q0 on
   uint32_t qchunk;                // frames a wave takes from its component's queue per atomicAdd; 0 = tile mode
                                   // (wave w owns frames [64*tile, 64*tile+64), no queue traffic)
   int32_t n_kp;                   // keypoints per frame (21 for MediaPipe/MANO hands)
@@ -318,7 +326,9 @@ struct LaneSolver {
           const bool quad = ae < beta;
           F += w * (quad ? (real)0.5 * e * e * ibeta : ae - (real)0.5 * beta);
           fvec[i] = w * (quad ? e * ibeta : (e > 0 ? (real)1 : (real)-1));
-          hw[i] = w * (quad ? ibeta : (real)1 / ae);  // IRLS majoriser in the linear region
+          // linear region: true curvature (0) when the second-order kinematic term is on (Newton), the IRLS
+          // majoriser 1/|e| for Gauss-Newton (the majoriser costs ~3x the iterations on human targets)
+          hw[i] = w * (quad ? ibeta : (kp.newton != 0 ? (real)0 : (real)1 / ae));
         }
       } else {  // SmoothL1 of the vector norm (optimizer.py:272-273, 534-541)
         const real d2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
@@ -730,6 +740,9 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
       pool_next = (unsigned)(tile * 64);
       pool_end = (unsigned)((tile * 64 + 64 < kp.B) ? tile * 64 + 64 : kp.B);
       if ((int64_t)pool_next >= kp.B) return;
+    } else {  // queue mode: the first tile is static as well (no start-up stampede on the counter)
+      pool_next = (unsigned)((tile * 64 < kp.B) ? tile * 64 : kp.B);
+      pool_end = (unsigned)((tile * 64 + 64 < kp.B) ? tile * 64 + 64 : kp.B);
     }
     unsigned* queue = kp.queue + comp;
 
@@ -741,7 +754,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
         if (pool_next >= pool_end && !dry) {
           unsigned base = 0;
           if (lane == 0) base = atomicAdd(queue, QCHUNK);
-          base = __builtin_amdgcn_readfirstlane(base);
+          base = __builtin_amdgcn_readfirstlane(base) + kp.q0;
           if ((int64_t)base >= kp.B) {
             dry = true;
           } else {
@@ -853,10 +866,12 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
           if (accept) {
             const real rho = (F - Ft) / fmax(pred, (real)1e-30);
             const real t = (real)2 * rho - (real)1;
-            lam = fmax(lam * (below_floor ? (real)(1.0 / 3.0) : fmax((real)(1.0 / 3.0), (real)1 - t * t * t)), (real)1e-9);
+            real shrink = below_floor ? (real)(1.0 / 3.0) : fmax((real)(1.0 / 3.0), (real)1 - t * t * t);
+            if (kp.lam_fastdec > 0 && rho > (real)0.9) shrink = (real)kp.lam_fastdec;
+            lam = fmax(lam * shrink, (real)1e-9);
             nu = 2;
             F = Ft;
-            const bool stalled = below_floor && blind >= 2 && smax > (real)0.9 * sprev && smax < (real)20 * (real)kp.tol;
+            const bool stalled = below_floor && blind >= kp.stall_from && smax > (real)kp.stall_ratio * sprev && smax < (real)kp.stall_cap * (real)kp.tol;
             blind = below_floor ? blind + 1 : 0;
             sprev = smax;
             if (smax < (real)kp.tol || stalled || blind >= kp.max_blind) {
@@ -865,6 +880,17 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
             }
           } else {
             lam = fmax(lam, (real)1e-6) * nu;
+            if (kp.lam_jump > 0) {  // go straight to a damping that matters next to the curvature
+              real ds = 0;
+              int dn = 0;
+#pragma unroll
+              for (int k = 0; k < NMAX; ++k)
+                if ((optmask >> k) & 1u) {
+                  ds += Hs[LS::hidx(k, k)];
+                  ++dn;
+                }
+              lam = fmax(lam, (real)kp.lam_jump * ds / (real)(dn > 0 ? dn : 1));
+            }
             nu *= 2;
             if (lam > (real)1e10) {  // no descent direction resolvable any more
               finished = true;
@@ -951,6 +977,8 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
       }
     }
     // reduced, damped system: rows/cols of held or non-variable joints become identity
+    real hds = 0;
+    int hdn = 0;
 #pragma unroll
     for (int rr = 0; rr < NMAX; ++rr) {
       const bool fr = (freemask >> rr) & 1u;
@@ -959,8 +987,11 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
         const bool fc = (freemask >> cc) & 1u;
         if (!(fr && fc)) S.H[LS::hidx(rr, cc)] = 0;
       }
+      hds += fr ? S.H[LS::hidx(rr, rr)] : (real)0;
+      hdn += fr ? 1 : 0;
       S.H[LS::hidx(rr, rr)] = fr ? S.H[LS::hidx(rr, rr)] + (real)2 * delta + lam : (real)1;
     }
+    const real hdmean = hds / (real)(hdn > 0 ? hdn : 1);
     real d[NMAX];
     const bool ok = S.chol_solve(d);
     // trial point (projected onto the box)
@@ -992,12 +1023,14 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
       if (accept) {
         const real rho = (F - Ft) / fmax(pred, (real)1e-30);
         const real t = (real)2 * rho - (real)1;
-        lam = fmax(lam * (below_floor ? (real)(1.0 / 3.0) : fmax((real)(1.0 / 3.0), (real)1 - t * t * t)), (real)1e-9);
+        real shrink = below_floor ? (real)(1.0 / 3.0) : fmax((real)(1.0 / 3.0), (real)1 - t * t * t);
+        if (kp.lam_fastdec > 0 && rho > (real)0.9) shrink = (real)kp.lam_fastdec;
+        lam = fmax(lam * shrink, (real)1e-9);
         nu = 2;
         F = Ft;
         // below the floor, progress is judged by the step length alone: stop when it is under tol, when it no
         // longer contracts (rounding noise of the gradient reached), or after max_blind such steps.
-        const bool stalled = below_floor && blind >= 2 && smax > (real)0.9 * sprev && smax < (real)20 * (real)kp.tol;
+        const bool stalled = below_floor && blind >= kp.stall_from && smax > (real)kp.stall_ratio * sprev && smax < (real)kp.stall_cap * (real)kp.tol;
         blind = below_floor ? blind + 1 : 0;
         sprev = smax;
         if (smax < (real)kp.tol || stalled || blind >= kp.max_blind) {
@@ -1006,6 +1039,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
         }
       } else {
         lam = fmax(lam, (real)1e-6) * nu;
+        if (kp.lam_jump > 0) lam = fmax(lam, (real)kp.lam_jump * hdmean);
         nu *= 2;
         if (lam > (real)1e10) {  // no descent direction resolvable any more
           done = true;

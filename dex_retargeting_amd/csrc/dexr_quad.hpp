@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(256) dexr_quad_kernel(const KernelParams kp, c
           const bool quad = ae < beta;
           Fv += w * (quad ? 0.5 * ee * ee * ibeta : ae - 0.5 * beta);
           fvec[i] = (float)(w * (quad ? ee * ibeta : (ee > 0 ? 1.0 : -1.0)));
-          hw[i] = (float)(w * (quad ? ibeta : 1.0 / ae));
+          hw[i] = (float)(w * (quad ? ibeta : (kp.newton != 0 ? 0.0 : 1.0 / ae)));  // exact curvature in Newton mode
         }
       } else {
         const double d2 = rd[0] * rd[0] + rd[1] * rd[1] + rd[2] * rd[2];
@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(256) dexr_quad_kernel(const KernelParams kp, c
   };
 
   // ---- projected Levenberg-Marquardt / Newton (single call site per stage, like dexr_big.hpp) ---------------------
-  float lam = kp.lam0, nu = 2.f, sprev = 1e30f;
+  float lam = kp.lam0, nu = 2.f, sprev = 1e30f, keff = 0.f;
   bool done = false, pending = false;
   int status = ST_MAXITER, my_iters = 0, blind = 0;
   double F = 0;
@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(256) dexr_quad_kernel(const KernelParams kp, c
       if (!pending) {
         F = Fe;
       } else {
-        const double noise = 64.0 * 1.1102230246251565e-16 * fabs(F);
+        const double noise = (double)kp.floor_scale * fabs(F);
         const bool finite = (Fe == Fe) && (smax == smax) && (fabs(Fe) < 1e30);
         const bool below_floor = ok && finite && ((double)pred <= noise) && (smax < 1e-2f);
         const bool accept = ok && finite && ((Fe <= F) || below_floor);
@@ -456,10 +456,12 @@ __global__ void __launch_bounds__(256) dexr_quad_kernel(const KernelParams kp, c
         if (accept) {
           const float rho = (float)((F - Fe) / fmax((double)pred, 1e-30));
           const float tt = 2.f * rho - 1.f;
-          lam = fmaxf(lam * (below_floor ? (1.f / 3.f) : fmaxf(1.f / 3.f, 1.f - tt * tt * tt)), 1e-9f);
+          float shrink = below_floor ? (1.f / 3.f) : fmaxf(1.f / 3.f, 1.f - tt * tt * tt);
+          if (kp.lam_fastdec > 0 && rho > 0.9f) shrink = kp.lam_fastdec;
+          lam = fmaxf(lam * shrink, 1e-9f);
           nu = 2.f;
           F = Fe;
-          const bool stalled = below_floor && blind >= 2 && smax > 0.9f * sprev && smax < 20.f * kp.tol;
+          const bool stalled = below_floor && blind >= kp.stall_from && smax > kp.stall_ratio * sprev && smax < kp.stall_cap * kp.tol;
           blind = below_floor ? blind + 1 : 0;
           sprev = smax;
           if (smax < kp.tol || stalled || blind >= kp.max_blind) {
@@ -468,6 +470,9 @@ __global__ void __launch_bounds__(256) dexr_quad_kernel(const KernelParams kp, c
           }
         } else {
           lam = fmaxf(lam, 1e-6f) * nu;
+          // damping jump: at least lam_jump x the curvature of the damped model along the step that just failed
+          // (Rayleigh quotient -g.d / d.d; g and d are replicated in the quad, so the four lanes agree bit for bit)
+          if (kp.lam_jump > 0) lam = fmaxf(lam, kp.lam_jump * keff);
           nu *= 2.f;
 #pragma unroll
           for (int k = 0; k < NMAX; ++k) x[k] = xo[k];
@@ -499,6 +504,7 @@ __global__ void __launch_bounds__(256) dexr_quad_kernel(const KernelParams kp, c
       smax = 0;
       pred = 0;
     }
+    float gd = 0.f, dd = 0.f;
 #pragma unroll
     for (int k = 0; k < NMAX; ++k) {
       if (stepping) {
@@ -506,11 +512,14 @@ __global__ void __launch_bounds__(256) dexr_quad_kernel(const KernelParams kp, c
         if ((freemask >> k) & 1u) {
           const float xt = fminf(fmaxf(x[k] + d[k], tb.lo[k]), tb.hi[k]);
           pred += 0.5f * d[k] * (lam * d[k] - g[k]);
+          gd -= g[k] * d[k];
+          dd += d[k] * d[k];
           smax = fmaxf(smax, fabsf(xt - x[k]));
           x[k] = xt;
         }
       }
     }
+    if (stepping) keff = gd / fmaxf(dd, 1e-30f);
     pending = stepping;
   }
   if (pending) {

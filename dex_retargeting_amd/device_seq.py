@@ -68,6 +68,7 @@ class DeviceSeqRetargeting:
         self.state = torch.zeros(B, dtype=torch.int32, device=dev)
         self.robot_qpos = torch.zeros((B, robot.dof), dtype=torch.float64, device=dev)
         self.filtered = torch.zeros_like(self.robot_qpos)
+        self._kp_mano = None
         self._no_fixed = torch.zeros((B, max(self.n_fixed, 1)), dtype=torch.float32, device=dev)
         self.reset()
 
@@ -100,6 +101,23 @@ class DeviceSeqRetargeting:
     def retarget_keypoints(self, keypoints, fixed_qpos=None):
         """Same as retarget() but fed with raw (B, 21, 3) hand keypoints; ref_value is formed inside the kernel."""
         return self.retarget(keypoints, fixed_qpos, _keypoints=True)
+
+    def retarget_raw_keypoints(self, keypoints, hand_type="Right", fixed_qpos=None):
+        """Raw detector output -> robot qpos without leaving the device: (B, 21, 3) keypoints in the detector's own
+        frame are centred on the wrist and rotated into the MANO frame (``dexr_mano_keypoints_dev`` ==
+        single_hand_detector.py:102-104,129-158), then retargeted as :meth:`retarget_keypoints` does."""
+        from . import keypoints as kpmod
+
+        torch = self.torch
+        if keypoints.dtype != torch.float32 or not keypoints.is_contiguous() or keypoints.device != self.device:
+            keypoints = keypoints.to(device=self.device, dtype=torch.float32).contiguous()
+        if tuple(keypoints.shape) != (self.batch, kpmod.N_KEYPOINTS, 3):
+            raise ValueError(f"keypoints must have shape ({self.batch}, {kpmod.N_KEYPOINTS}, 3), got {tuple(keypoints.shape)}")
+        if self._kp_mano is None:
+            self._kp_mano = torch.empty_like(keypoints)
+        kpmod.mano_keypoints_dev(self.batch, keypoints.data_ptr(), self._kp_mano.data_ptr(), 0, hand_type,
+                                 torch.cuda.current_stream(self.device).cuda_stream)
+        return self.retarget(self._kp_mano, fixed_qpos, _keypoints=True)
 
     def retarget(self, ref_value, fixed_qpos=None, _keypoints=False):
         """ref_value: (B, n_ref, 3) float32 CUDA tensor (contiguous).  Returns the (B, dof) float64 CUDA tensor of

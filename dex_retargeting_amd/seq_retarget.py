@@ -181,13 +181,26 @@ class BatchedSeqRetargeting:
             if joint_name in _DUMMY_NAMES:
                 self.last_qpos[:, num] = pose[:, _DUMMY_NAMES.index(joint_name)]
 
-    def retarget(self, ref_value: np.ndarray, fixed_qpos: Optional[np.ndarray] = None) -> np.ndarray:
+    def retarget_keypoints(self, keypoints: np.ndarray, fixed_qpos: Optional[np.ndarray] = None) -> np.ndarray:
+        """Same as retarget() but fed with (B, 21, 3) MANO-frame hand keypoints; ref_value is formed in the kernel."""
+        return self.retarget(keypoints, fixed_qpos, _keypoints=True)
+
+    def retarget_raw_keypoints(self, keypoints: np.ndarray, hand_type="Right",
+                               fixed_qpos: Optional[np.ndarray] = None) -> np.ndarray:
+        """(B, 21, 3) keypoints in the detector's frame: wrist-frame estimate + MANO re-expression
+        (single_hand_detector.py:102-104,129-158) on the GPU, then retarget_keypoints()."""
+        from .keypoints import mano_keypoints
+
+        return self.retarget(mano_keypoints(keypoints, hand_type)[0], fixed_qpos, _keypoints=True)
+
+    def retarget(self, ref_value: np.ndarray, fixed_qpos: Optional[np.ndarray] = None, _keypoints=False) -> np.ndarray:
         """ref_value (B,n_ref,3); returns float64 (B, robot.dof) in pinocchio dof order."""
         opt = self.optimizer
         B = self.batch
         last = np.clip(self.last_qpos, self.joint_limits[:, 0], self.joint_limits[:, 1]).astype(np.float32)
         fixed = np.zeros((B, len(opt.idx_pin2fixed)), dtype=np.float32) if fixed_qpos is None else fixed_qpos
-        q = opt.retarget_batch(ref_value.astype(np.float32), fixed, last, state=self.state)
+        solve = opt.retarget_keypoints_batch if _keypoints else opt.retarget_batch
+        q = solve(ref_value.astype(np.float32), fixed, last, state=self.state)
         bad = opt.last_info["status"] == 2
         if bad.any():
             q[bad] = last[bad]

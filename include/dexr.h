@@ -101,6 +101,18 @@ int dexr_eval(const dexr_model* m, int64_t B, const float* ref, const float* fix
  * pos_out: B x n_ref x 3 float64.  Host pointers. */
 int dexr_fk(const dexr_model* m, int64_t B, const double* q, double* pos_out);
 
+/* The step right before the path: raw detector keypoints -> wrist-centred keypoints in the MANO frame, x B.
+ *   kp_c = kp - kp[0];  R = estimate_frame_from_hand_points(kp_c);  joint_pos = kp_c @ R @ operator2mano
+ * (example/vector_retargeting/single_hand_detector.py:102-104,129-158; OPERATOR2MANO_RIGHT/LEFT constants.py:7-21).
+ * keypoints, joint_pos_out: B x 21 x 3 float32 (joint_pos_out may alias nothing else); operator2mano: 9 floats,
+ * row major, HOST pointer in both variants; wrist_rot_out: B x 3 x 3 float32 (the reference's
+ * `mediapipe_wrist_rot`) or NULL.  Frames whose keypoints 0, 5, 9 are collinear have no palm plane: their rows
+ * come back non-finite (the solver then reports status 2 for them and keeps last_qpos). */
+int dexr_mano_keypoints_dev(int64_t B, const float* keypoints, const float* operator2mano, float* joint_pos_out,
+                            float* wrist_rot_out, void* stream);
+int dexr_mano_keypoints(int64_t B, const float* keypoints, const float* operator2mano, float* joint_pos_out,
+                        float* wrist_rot_out);
+
 #ifdef __cplusplus
 }
 #endif

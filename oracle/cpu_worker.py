@@ -1,0 +1,87 @@
+"""ORACLE (test infrastructure only -- never imported by the product path).
+
+One host process of bench.py's ``cpu_baseline_all_cores`` leg: solves a slice of the bench workload with the
+reference-as-configured CPU solve (oracle.solvers.solve_ref_as_configured == the reference's per-frame
+``Optimizer.retarget``, optimizer.py:77-102, scipy SLSQP standing in for nlopt).
+
+    python -m oracle.cpu_worker <config.yml (relative)> <inputs.npz> <start> <count> <sync dir>
+
+Protocol: import, solve one untimed frame, touch ``<sync dir>/ready.<start>``, wait for ``<sync dir>/go`` (at most
+60 s), solve ``count`` frames, print ``<count> <seconds>``.  :func:`run_all_cores` is the parent side; every wait
+in it has a deadline, and any failure makes it return None (the bench then simply omits the leg).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+
+def _solve(prob, ref, last):
+    from . import solvers
+
+    kw = {}
+    if prob.kind == "dexpilot":
+        w, rv, _ = prob.dexpilot_preamble(ref, np.zeros((ref.shape[0], prob.n_pair), bool))
+        kw = dict(weights=w, dexpilot_ref=rv)
+    solvers.solve_ref_as_configured(prob, ref, None, last, **kw)
+
+
+def main(argv):
+    from . import cases
+
+    rel, npz, start, count, sync = argv[0], argv[1], int(argv[2]), int(argv[3]), argv[4]
+    prob = cases.problem_from_config(rel)
+    d = np.load(npz)
+    ref, last = d["ref"][start:start + count], d["last"][start:start + count]
+    _solve(prob, ref[:1], last[:1])
+    open(os.path.join(sync, f"ready.{start}"), "w").close()
+    deadline = time.time() + 60
+    while not os.path.exists(os.path.join(sync, "go")) and time.time() < deadline:
+        time.sleep(0.005)
+    t0 = time.perf_counter()
+    _solve(prob, ref, last)
+    print(ref.shape[0], time.perf_counter() - t0, flush=True)
+
+
+def run_all_cores(rel: str, ref: np.ndarray, last: np.ndarray, procs: int, frames_per_proc: int, deadline_s: float = 120.0):
+    """Returns (frames, wall seconds between 'go' and the last worker finishing) or None on any failure/timeout."""
+    n = min(procs * frames_per_proc, ref.shape[0])
+    starts = list(range(0, n, frames_per_proc))
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t_end = time.time() + deadline_s
+    workers = []
+    with tempfile.TemporaryDirectory() as sync:
+        npz = os.path.join(sync, "inputs.npz")
+        np.savez(npz, ref=ref[:n], last=last[:n])
+        try:
+            for s in starts:
+                workers.append(subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", rel, npz, str(s),
+                                                 str(min(frames_per_proc, n - s)), sync], cwd=repo, env=env,
+                                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+            while sum(os.path.exists(os.path.join(sync, f"ready.{s}")) for s in starts) < len(starts):
+                if time.time() > t_end or any(w.poll() not in (None, 0) for w in workers):
+                    raise TimeoutError("workers did not come up")
+                time.sleep(0.01)
+            t0 = time.perf_counter()
+            open(os.path.join(sync, "go"), "w").close()
+            frames = 0
+            for w in workers:
+                out, _ = w.communicate(timeout=max(1.0, t_end - time.time()))
+                frames += int(out.split()[0])
+            return frames, time.perf_counter() - t0
+        except Exception:
+            return None
+        finally:
+            for w in workers:
+                if w.poll() is None:
+                    w.kill()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

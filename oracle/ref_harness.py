@@ -121,6 +121,35 @@ def import_reference():
     return opt, ka, sr, ou
 
 
+def import_reference_detector():
+    """The reference's MediaPipe wrapper module (example/vector_retargeting/single_hand_detector.py), imported
+    from where it lies with empty stand-ins for the ``mediapipe`` package (not installed here); only its static
+    ``SingleHandDetector.estimate_frame_from_hand_points`` and the OPERATOR2MANO constants are usable."""
+    import importlib.util
+
+    path = "/root/reference/example/vector_retargeting/single_hand_detector.py"
+    if not os.path.isfile(path):
+        raise RuntimeError("/root/reference is not present on this machine")
+    names = ["mediapipe", "mediapipe.framework", "mediapipe.framework.formats",
+             "mediapipe.framework.formats.landmark_pb2", "mediapipe.python", "mediapipe.python.solutions",
+             "mediapipe.python.solutions.hands_connections", "mediapipe.python.solutions.drawing_utils",
+             "mediapipe.python.solutions.hands"]
+    for n in names:
+        if n not in sys.modules:
+            sys.modules[n] = types.ModuleType(n)
+    for n in names[1:]:
+        parent, _, leaf = n.rpartition(".")
+        setattr(sys.modules[parent], leaf, sys.modules[n])
+    pb = sys.modules["mediapipe.framework.formats.landmark_pb2"]
+    pb.LandmarkList = pb.NormalizedLandmarkList = object
+    sys.modules["mediapipe.python.solutions.drawing_utils"].DrawingSpec = object
+    sys.modules["mediapipe.python.solutions.hands"].HandLandmark = object
+    spec = importlib.util.spec_from_file_location("_ref_single_hand_detector", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 class _FakeModel:
     def __init__(self, nq):
         self.nq = nq

@@ -11,7 +11,13 @@
   (optimizer.py:77-102, seq_retarget.py:112-134) with the scipy-SLSQP stand-in for nlopt: "reference as
   configured" answers for a short human-keypoint sequence (information + regression of oracle.solvers).
 
-Usage: python tests/golden/gen_golden.py
+* mano_frame_golden.npz -- raw detector-style keypoints (the human fixture under random rigid motions + noise)
+  -> ``mediapipe_wrist_rot`` / ``joint_pos`` computed by the REFERENCE'S OWN
+  ``SingleHandDetector.estimate_frame_from_hand_points`` and the three lines around its call
+  (example/vector_retargeting/single_hand_detector.py:102-104,129-158), right and left hand.  Pins
+  oracle/preprocess.py and the GPU ``dexr_mano_keypoints`` kernel.
+
+Usage: python tests/golden/gen_golden.py [--only-mano]
 """
 import os
 import sys
@@ -68,7 +74,46 @@ def build_reference_optimizer(rel):
     return o, seq
 
 
+def random_rotations(n, rng):
+    q = rng.standard_normal((n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q.T
+    return np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], -1),
+                     np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
+                     np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], 1)
+
+
+def gen_mano_frame():
+    det = ref_harness.import_reference_detector()
+    rng = np.random.default_rng(31)
+    fixture = np.load(os.path.join(HERE, "human_joint_right_f32.npy")).astype(np.float64)
+    n = 96
+    idx = rng.integers(0, fixture.shape[0], n)
+    R = random_rotations(n, rng)
+    t = rng.uniform(-0.5, 0.5, (n, 1, 3))
+    raw = (np.einsum("bij,bkj->bki", R, fixture[idx]) + t + 1e-3 * rng.standard_normal((n, 21, 3))).astype(np.float32)
+    out = {"raw": raw}
+    for hand, op in (("right", det.OPERATOR2MANO_RIGHT), ("left", det.OPERATOR2MANO_LEFT)):
+        kp_in = raw.astype(np.float64)
+        if hand == "left":
+            kp_in = kp_in * np.array([1.0, -1.0, 1.0])  # mirrored hand
+            out["raw_left"] = kp_in.astype(np.float32)
+            kp_in = out["raw_left"].astype(np.float64)
+        jp, rot = [], []
+        for b in range(n):
+            c = kp_in[b] - kp_in[b][0:1, :]
+            r = det.SingleHandDetector.estimate_frame_from_hand_points(c)
+            jp.append(c @ r @ op)
+            rot.append(r)
+        out[f"joint_pos_{hand}"], out[f"wrist_rot_{hand}"] = np.array(jp), np.array(rot)
+    np.savez_compressed(os.path.join(HERE, "mano_frame_golden.npz"), **out)
+    print("mano_frame_golden.npz:", {k: v.shape for k, v in out.items()})
+
+
 def main():
+    if "--only-mano" in sys.argv:
+        gen_mano_frame()
+        return
     kp = np.load("/root/reference/example/profiling/human_joint_right.pkl", allow_pickle=True)
     np.save(os.path.join(HERE, "human_joint_right_f32.npy"), np.stack(kp).astype(np.float32))
 
@@ -127,6 +172,7 @@ def main():
         sol[key + "__last_qpos"] = np.array(raw)
         print(f"{rel:45s} seq done, evals={o.opt.n_evals}")
     np.savez_compressed(os.path.join(HERE, "refsolve_golden.npz"), **sol)
+    gen_mano_frame()
 
 
 if __name__ == "__main__":

@@ -359,6 +359,80 @@ def test_keypoint_entry_point_equals_ref_value_path(rel):
         assert np.array_equal(s1, s2)
 
 
+# ---- keypoint pre-processing (section 8 row f2) ------------------------------------------------------------------------
+@pytest.mark.parametrize("hand", ["right", "left"])
+def test_mano_keypoints_match_reference_golden(hand):
+    """dexr_mano_keypoints == the reference's own estimate_frame_from_hand_points + MANO re-expression
+    (single_hand_detector.py:102-104,129-158) on the committed golden vectors.  float32 in/out, float64 frame
+    arithmetic: tolerance 1e-6 m on positions (hand scale 0.2 m), 1e-6 on the rotation entries."""
+    from dex_retargeting_amd import keypoints as kpmod
+
+    g = np.load(os.path.join(GOLD, "mano_frame_golden.npz"))
+    raw = g["raw"] if hand == "right" else g["raw_left"]
+    jp, rot = kpmod.mano_keypoints(raw, hand_type=hand.capitalize())
+    assert jp.dtype == np.float32 and rot.dtype == np.float32
+    assert np.abs(jp - g[f"joint_pos_{hand}"]).max() < 1e-6
+    assert np.abs(rot - g[f"wrist_rot_{hand}"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("B", [1, 63, 64, 65, 1000, 65536])
+def test_mano_keypoints_ragged_and_full_size(B):
+    """Tile edges (64 frames per workgroup) and the full bench size against the oracle; at the full size also the
+    size-independent properties: wrist at the origin, all inter-keypoint distances preserved (rigid motion)."""
+    from dex_retargeting_amd import keypoints as kpmod
+    from oracle import preprocess
+
+    rng = np.random.default_rng(B)
+    kp = cases.human_keypoints(B, seed=B).astype(np.float64)
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    raw = (kp @ q.T + rng.uniform(-0.3, 0.3, (B, 1, 3))).astype(np.float32)
+    jp, rot = kpmod.mano_keypoints(raw)
+    n = min(B, 2000)
+    want, want_rot = preprocess.mano_joint_pos(raw[:n])
+    assert np.abs(jp[:n] - want).max() < 1e-6
+    assert np.abs(rot[:n] - want_rot).max() < 1e-6
+    assert np.all(jp[:, 0] == 0)
+    d_in = np.linalg.norm(raw[:, 1:].astype(np.float64) - raw[:, :1], axis=2)
+    assert np.abs(np.linalg.norm(jp[:, 1:].astype(np.float64), axis=2) - d_in).max() < 1e-6
+
+
+def test_mano_keypoints_degenerate_and_bad_arguments():
+    from dex_retargeting_amd import keypoints as kpmod
+
+    raw = cases.human_keypoints(3, seed=1)
+    raw[1, 9] = raw[1, 0] + 2 * (raw[1, 5] - raw[1, 0])  # keypoints 0, 5, 9 collinear: no palm plane
+    jp, _ = kpmod.mano_keypoints(raw)
+    assert np.isfinite(jp[0]).all() and np.isfinite(jp[2]).all() and not np.isfinite(jp[1]).all()
+    with pytest.raises(ValueError):
+        kpmod.mano_keypoints(np.zeros((4, 20, 3), np.float32))
+    with pytest.raises(ValueError):
+        kpmod.mano_keypoints(raw, hand_type="both")
+    assert kpmod.mano_keypoints(np.zeros((0, 21, 3), np.float32))[0].shape == (0, 21, 3)
+
+
+def test_raw_keypoints_to_qpos_on_device_equals_host_pipeline():
+    """DeviceSeqRetargeting.retarget_raw_keypoints (frame estimate -> MANO -> gather -> solve, all enqueued on one
+    stream) == the same steps through the host entry points; unaligned device pointer for the raw keypoints."""
+    torch = pytest.importorskip("torch")
+    from dex_retargeting_amd import keypoints as kpmod
+
+    rel = "teleop/allegro_hand_right.yml"
+    B = 777
+    rng = np.random.default_rng(2)
+    kp = cases.human_keypoints(B, seed=9).astype(np.float64)
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    raw = (kp @ q.T + 0.1).astype(np.float32)
+    dev = RetargetingConfig.load_from_file(os.path.join(cases.CONFIG_DIR, rel)).build_device(B)
+    host = RetargetingConfig.load_from_file(os.path.join(cases.CONFIG_DIR, rel)).build_batched(B)
+    buf = torch.empty(B * 63 + 1, dtype=torch.float32, device="cuda:0")
+    t_raw = buf[1:].view(B, 21, 3)  # 4-byte aligned only
+    t_raw.copy_(torch.from_numpy(raw))
+    got = dev.retarget_raw_keypoints(t_raw, "Right").cpu().numpy()
+    jp, _ = kpmod.mano_keypoints(raw)
+    want = host.retarget_keypoints(jp)
+    assert np.array_equal(got, want)
+
+
 # ---- less common configuration paths ---------------------------------------------------------------------------------
 def _custom(cfg_dict):
     seq = RetargetingConfig.from_dict(dict(cfg_dict)).build()

@@ -155,3 +155,32 @@ def test_refsolve_golden_regression():
         x, _ = solvers.solve_ref_as_configured(prob, refs[t:t + 1], None, last[None])
         assert np.abs(x[0] - g[_key(rel) + "__last_qpos"][t]).max() < 1e-5
         last = x[0]
+
+
+def test_keypoint_preprocessing_oracle_matches_reference_golden():
+    """oracle/preprocess.py == the reference's own SingleHandDetector.estimate_frame_from_hand_points and the lines
+    around its call (single_hand_detector.py:102-104,129-158), as captured by tests/golden/gen_golden.py."""
+    from oracle import preprocess
+
+    g = np.load(os.path.join(GOLD, "mano_frame_golden.npz"))
+    for hand, raw in (("right", g["raw"]), ("left", g["raw_left"])):
+        jp, rot = preprocess.mano_joint_pos(raw, right=(hand == "right"))
+        assert np.abs(jp - g[f"joint_pos_{hand}"]).max() < 1e-12
+        assert np.abs(rot - g[f"wrist_rot_{hand}"]).max() < 1e-12
+        # a rotation (det +1), and the wrist ends up at the origin
+        assert np.allclose(np.einsum("bij,bkj->bik", rot, rot), np.eye(3), atol=1e-12)
+        assert np.allclose(np.linalg.det(rot), 1.0, atol=1e-12)
+        assert np.abs(jp[:, 0]).max() == 0.0
+
+
+def test_keypoint_preprocessing_undoes_a_rigid_motion():
+    """Property: the MANO-frame joint positions do not depend on where the detector's camera frame was."""
+    from oracle import preprocess
+
+    kp = cases.human_keypoints(40, seed=3).astype(np.float64)
+    rng = np.random.default_rng(5)
+    a, _ = preprocess.mano_joint_pos(kp)
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    q *= np.sign(np.linalg.det(q))
+    b, _ = preprocess.mano_joint_pos(kp @ q.T + rng.uniform(-1, 1, 3))
+    assert np.abs(a - b).max() < 1e-9
