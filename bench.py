@@ -154,6 +154,16 @@ def main():
     value = frames / elapsed
     bpf = algorithmic_bytes_per_frame(n_opt, dexpilot)
     achieved = B * bpf / (kernel_ms * 1e-3) / 1e9
+    # HBM bytes per launch as counted by rocprofv3 PMC passes of this same command (tools/profile_round.sh writes the
+    # summary, committed under profiles/): 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction per MI355X_MICROARCH.md
+    traffic, valu_frac = None, None
+    pmc_path = os.path.join(REPO, "profiles", f"pmc_{args.workload}.json")
+    if os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))
+        if pmc.get("batch") == B and world == 1:
+            traffic = pmc.get("hbm_bytes_per_launch")
+            if "SQ_INSTS_VALU" in pmc:  # wave64 VALU instruction = 4 issue cycles on a 16-lane SIMD; 1024 SIMDs, 2.4 GHz
+                valu_frac = pmc["SQ_INSTS_VALU"] * 4.0 / (1024 * kernel_ms * 1e-3 * 2.4e9)
     out = {
         "metric": json.load(open(os.path.join(REPO, "BASELINE.json")))["metric"],
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -165,7 +175,10 @@ def main():
         "solver": {"iters_mean": iters_mean, "iters_max": iters_max, "converged_frac": n_conv / B,
                    "tol_rad": 2e-6, "newton": 1},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "traffic_note": "bytes per launch from the rocprofv3 --pmc passes in profiles/ (same command, "
+                                     "same batch); null when no matching profile is committed",
+                     "valu_issue_frac": valu_frac,
                      "kernel": "dexr_kernel<NMAX,float,SOLVE[,CHAIN]> (+ float64 polish launch for position/dexpilot)",
                      "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_frame": bpf,

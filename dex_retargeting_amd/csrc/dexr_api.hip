@@ -85,6 +85,7 @@ void fill_params(const dexr_model* m, dexr::KernelParams& kp, int64_t B) {
   kp.lam_jump = m->bucket <= 8 ? 1.0f : 0.3f;
   kp.lam_fastdec = m->bucket <= 8 ? 0.1f : 0.f;
   kp.floor_scale = 1e-12f;
+  kp.step_cap = 0.3f;
   kp.n_opt = h.n_opt;
   kp.n_fixed = h.n_fixed;
   kp.n_ref = h.n_ref;
@@ -200,6 +201,7 @@ void apply_options(dexr::KernelParams& kp, const dexr_solve_options* opt) {
   if (const char* e = std::getenv("DEXR_LAM_JUMP")) kp.lam_jump = (float)std::atof(e);
   if (const char* e = std::getenv("DEXR_LAM_FASTDEC")) kp.lam_fastdec = (float)std::atof(e);
   if (const char* e = std::getenv("DEXR_FLOOR")) kp.floor_scale = (float)std::atof(e);
+  if (const char* e = std::getenv("DEXR_STEP_CAP")) kp.step_cap = (float)std::atof(e);
   kp.stall_from = 2;
   kp.stall_ratio = 0.9f;
   kp.stall_cap = 20.f;

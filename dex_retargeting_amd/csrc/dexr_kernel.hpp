@@ -52,6 +52,7 @@ struct KernelParams {
   int32_t max_blind;  // accepted steps below the rounding floor of F before giving up on further progress
   int32_t lds_frames, lds_terms;  // per-wave LDS rows: max frames / max terms over the model's components
   int32_t big_nh_rows;            // dexr_big_kernel: LDS rows reserved for the Hessian (n_max (n_max + 1) / 2)
+  float step_cap;                 // trust radius: a step whose largest component exceeds it is scaled down to it (0: off)
   float lam_jump;                 // on a rejected step lambda becomes at least lam_jump x mean diag(H) (0: plain x nu)
   float lam_fastdec;              // on an accepted step with rho > 0.9 lambda shrinks by this factor (0: Nielsen's 1/3)
   float floor_scale;              // mixed-precision kernels: value differences below floor_scale x |F| are unverifiable
@@ -817,12 +818,23 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
         real d[NMAX];
         ok = S.chol_solve(d);
         const bool stepping = has && !fresh;
+        // trust radius: scale the step so that no joint moves more than step_cap (alpha in (0, 1])
+        real dmax = 0, gd = 0, dd = 0;
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k)
+          if ((optmask >> k) & 1u) {
+            dmax = fmax(dmax, fabs(d[k]));
+            gd -= gm[k] * d[k];
+            dd += d[k] * d[k];
+          }
+        const real alpha = (kp.step_cap > 0 && dmax > (real)kp.step_cap) ? (real)kp.step_cap / dmax : (real)1;
+        // predicted decrease of the damped model along alpha*d:  alpha (1 - alpha/2) (-g.d) + alpha^2/2 lam d.d
+        pred = alpha * ((real)1 - (real)0.5 * alpha) * gd + (real)0.5 * alpha * alpha * lam * dd;
 #pragma unroll
         for (int k = 0; k < NMAX; ++k) {
           xo[k] = S.x[k];
           if ((optmask >> k) & 1u) {
-            const real xt = fmin(fmax(S.x[k] + d[k], (real)tbl.lo[k]), (real)tbl.hi[k]);
-            pred += (real)0.5 * d[k] * (lam * d[k] - gm[k]);
+            const real xt = fmin(fmax(S.x[k] + alpha * d[k], (real)tbl.lo[k]), (real)tbl.hi[k]);
             smax = fmax(smax, fabs(xt - S.x[k]));
             if (stepping) S.x[k] = xt;
           }
@@ -996,12 +1008,22 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
     const bool ok = S.chol_solve(d);
     // trial point (projected onto the box)
     real smax = 0, pred = 0;
+    real dmax = 0, gd = 0, dd = 0;
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k)
+      if ((optmask >> k) & 1u) {
+        dmax = fmax(dmax, fabs(d[k]));
+        gd -= S.g[k] * d[k];
+        dd += d[k] * d[k];
+      }
+    // trust radius (see the small-component path): step scaled to at most step_cap per joint
+    const real alpha = (kp.step_cap > 0 && dmax > (real)kp.step_cap) ? (real)kp.step_cap / dmax : (real)1;
+    pred = alpha * ((real)1 - (real)0.5 * alpha) * gd + (real)0.5 * alpha * alpha * lam * dd;
 #pragma unroll
     for (int k = 0; k < NMAX; ++k) {
       xo[k] = S.x[k];
       if ((optmask >> k) & 1u) {
-        const real xt = fmin(fmax(S.x[k] + d[k], (real)tb.lo[k]), (real)tb.hi[k]);
-        pred += (real)0.5 * d[k] * (lam * d[k] - S.g[k]);
+        const real xt = fmin(fmax(S.x[k] + alpha * d[k], (real)tb.lo[k]), (real)tb.hi[k]);
         smax = fmax(smax, fabs(xt - S.x[k]));
         if (!done) S.x[k] = xt;
       }

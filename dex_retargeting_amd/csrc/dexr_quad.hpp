@@ -504,22 +504,31 @@ __global__ void __launch_bounds__(256) dexr_quad_kernel(const KernelParams kp, c
       smax = 0;
       pred = 0;
     }
-    float gd = 0.f, dd = 0.f;
+    float dmax = 0.f, gd = 0.f, dd = 0.f;
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k)
+      if ((freemask >> k) & 1u) {
+        dmax = fmaxf(dmax, fabsf(d[k]));
+        gd -= g[k] * d[k];
+        dd += d[k] * d[k];
+      }
+    // trust radius: step scaled to at most step_cap per joint; predicted decrease of the damped model along alpha*d
+    const float alpha = (kp.step_cap > 0 && dmax > kp.step_cap) ? kp.step_cap / dmax : 1.f;
+    if (stepping) {
+      pred = alpha * (1.f - 0.5f * alpha) * gd + 0.5f * alpha * alpha * lam * dd;
+      keff = gd / fmaxf(dd, 1e-30f);
+    }
 #pragma unroll
     for (int k = 0; k < NMAX; ++k) {
       if (stepping) {
         xo[k] = x[k];
         if ((freemask >> k) & 1u) {
-          const float xt = fminf(fmaxf(x[k] + d[k], tb.lo[k]), tb.hi[k]);
-          pred += 0.5f * d[k] * (lam * d[k] - g[k]);
-          gd -= g[k] * d[k];
-          dd += d[k] * d[k];
+          const float xt = fminf(fmaxf(x[k] + alpha * d[k], tb.lo[k]), tb.hi[k]);
           smax = fmaxf(smax, fabsf(xt - x[k]));
           x[k] = xt;
         }
       }
     }
-    if (stepping) keff = gd / fmaxf(dd, 1e-30f);
     pending = stepping;
   }
   if (pending) {

@@ -26,7 +26,7 @@ Fo = prob.total(want, d["ref"], d["fixed"], last64, **kw)
 
 
 def model_for(env):
-    for k in ("DEXR_NO_QUAD", "DEXR_FORCE_BIG", "DEXR_LAM_JUMP", "DEXR_LAM_FASTDEC", "DEXR_FLOOR", "DEXR_MAX_ITER"):
+    for k in ("DEXR_NO_QUAD", "DEXR_FORCE_BIG", "DEXR_LAM_JUMP", "DEXR_LAM_FASTDEC", "DEXR_FLOOR", "DEXR_MAX_ITER", "DEXR_STEP_CAP"):
         os.environ.pop(k, None)
     os.environ.update(env)
     return RetargetingConfig.load_from_file(os.path.join(cases.CONFIG_DIR, rel)).build().optimizer.device_model()
