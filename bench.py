@@ -65,10 +65,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # launched by torch.distributed.run (RANK set): take the N > 1 path even with one rank, so that the RCCL side of
+    # this script can be exercised on a 1-GPU box too
+    if world > 1 or (os.environ.get("RANK") is not None and os.environ.get("DEXR_BENCH_DIST", "1") != "0"):
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from dex_retargeting_amd import _lib
@@ -103,51 +106,64 @@ def main():
     t_q = torch.empty((B, n_opt), dtype=torch.float32, device=dev)
     t_iters = torch.zeros(B, dtype=torch.int32, device=dev)
     t_status = torch.zeros(B, dtype=torch.int32, device=dev)
-    t_all = torch.empty((world * B, n_opt), dtype=torch.float32, device=dev) if world > 1 else None
     stream = torch.cuda.current_stream()
+    # N > 1: one RCCL all-gather of this rank's (B, n_opt) result per step, overlapped with the NEXT step's solve
+    # (two rotating buffer pairs; every gather has completed when the timed region ends)
+    pipe = None
+    if dist is not None:
+        from dex_retargeting_amd.distributed import PipelinedAllGather
+
+        pipe = PipelinedAllGather(B, n_opt, torch.float32, dev, depth=2)
+    n_step = [0]
 
     def step(record=None, diagnostics=False):
         if dexpilot:
             t_state.copy_(t_state0)
+        out = t_q if pipe is None else pipe.shard(n_step[0])
         if record is not None:
             record[0].record(stream)
         model.retarget_dev(B, t_ref.data_ptr(), 0, t_last.data_ptr(), t_state.data_ptr() if dexpilot else 0,
-                           t_q.data_ptr(), status_ptr=t_status.data_ptr() if diagnostics else 0,
+                           out.data_ptr(), status_ptr=t_status.data_ptr() if diagnostics else 0,
                            iters_ptr=t_iters.data_ptr() if diagnostics else 0, stream=stream.cuda_stream,
                            keypoints=True)
         if record is not None:
             record[1].record(stream)
-        if world > 1:
-            dist.all_gather_into_tensor(t_all, t_q)
+        if pipe is not None:
+            pipe.gather(n_step[0])
+        n_step[0] += 1
 
     for _ in range(args.warmup):
         step()
     step(diagnostics=True)  # untimed: iteration counts / status of this workload
+    if pipe is not None:
+        t_q.copy_(pipe.shard(n_step[0] - 1))
+        pipe.finish()
     torch.cuda.synchronize()
     iters_mean = float(t_iters.float().mean())
     iters_max = int(t_iters.max())
     n_conv = int((t_status == 0).sum())
 
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(record=events[k])
+    if pipe is not None:
+        pipe.finish()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
-    if world > 1:
+    if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     frames = world * B * args.steps
@@ -171,7 +187,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{wl_name}, {B} frames/GPU, human-keypoint refs (fixture frame b mod 621 + 2 mm noise), "
                                f"warm start = previous frame's solution", "config_file": rel, "batch_per_gpu": B,
-                   "n_opt": n_opt, "n_ref": n_ref, "collective": "rccl all_gather of qpos" if world > 1 else "none"},
+                   "n_opt": n_opt, "n_ref": n_ref, "collective": "rccl all_gather of qpos, overlapped with the next step's solve" if dist is not None else "none"},
         "solver": {"iters_mean": iters_mean, "iters_max": iters_max, "converged_frac": n_conv / B,
                    "tol_rad": 2e-6, "newton": 1},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -231,7 +247,7 @@ def main():
                     "sample": f"first {res[0]} frames, {procs} processes x {per_proc} frames started together, same "
                               f"solver as cpu_baseline; {avail} CPUs available to the process"}
     print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -68,3 +68,63 @@ class ShardedRetargeter:
                 a, b = shard_bounds(B, r, self.world)
                 state[a:b] = sfull[r, : b - a].astype(np.uint32)
         return out
+
+
+class PipelinedAllGather:
+    """All-gather of step k overlapped with the solve of step k+1 (RCCL runs on its own stream; xGMI is
+    point-to-point, so at 8 GPUs the gather of a 4 MB shard costs about as much as the solve it follows).
+
+    ``depth`` shard / full buffer pairs rotate.  Per step::
+
+        out = pg.shard(k)      # (per, n) tensor for this rank's result of step k; first waits until the gather that
+                               # last read this buffer (step k - depth) is complete
+        ... enqueue the solve that writes `out` on the current stream ...
+        pg.gather(k)           # enqueue all_gather(full[k % depth], out), asynchronously
+
+    and ``pg.finish()`` at the end waits for every outstanding gather and returns the last full tensor.  With
+    "nccl" (= RCCL) ``wait()`` only orders the current stream after the collective; with "gloo" it blocks the host.
+    ``on_full(k, tensor)`` -- optional -- is called as soon as step k's gather is known complete.
+    """
+
+    def __init__(self, per: int, n: int, dtype=None, device="cpu", depth: int = 2, group=None, on_full=None):
+        import torch
+        import torch.distributed as dist
+
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self.dist, self.group, self.depth, self.on_full = dist, group, depth, on_full
+        self.world = dist.get_world_size(group)
+        dtype = dtype or torch.float32
+        self._shard = [torch.zeros((per, n), dtype=dtype, device=device) for _ in range(depth)]
+        self._full = [torch.empty((self.world * per, n), dtype=dtype, device=device) for _ in range(depth)]
+        self._work = [None] * depth  # (step, Work) of the gather in flight on each buffer pair
+        self._last = None
+
+    def _retire(self, slot: int):
+        if self._work[slot] is not None:
+            k, w = self._work[slot]
+            w.wait()
+            self._work[slot] = None
+            if self.on_full is not None:
+                self.on_full(k, self._full[slot])
+
+    def shard(self, k: int):
+        slot = k % self.depth
+        self._retire(slot)
+        return self._shard[slot]
+
+    def gather(self, k: int):
+        slot = k % self.depth
+        if self._work[slot] is not None:
+            raise RuntimeError(f"step {k}: buffer {slot} still has a gather in flight (call shard(k) first)")
+        w = self.dist.all_gather_into_tensor(self._full[slot], self._shard[slot], group=self.group, async_op=True)
+        self._work[slot] = (k, w)
+        self._last = slot
+
+    def finish(self):
+        order = sorted((kw[0], s) for s, kw in enumerate(self._work) if kw is not None)
+        for _, slot in order:
+            self._retire(slot)
+        return None if self._last is None else self._full[self._last]

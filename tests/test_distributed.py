@@ -64,3 +64,45 @@ def test_two_rank_gloo_allgather_equals_single_process(tmp_path, B):
         got = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
         assert np.array_equal(got["q"], want)
         assert np.array_equal(got["state"], st)
+
+
+def _pipe_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    from dex_retargeting_amd.distributed import PipelinedAllGather
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per, n, steps = 5, 3, 7
+    seen = {}
+    pg = PipelinedAllGather(per, n, torch.float32, "cpu", depth=2, on_full=lambda k, t: seen.__setitem__(k, t.clone()))
+    for k in range(steps):
+        out = pg.shard(k)
+        out.copy_(torch.full((per, n), float(100 * k + rank)))  # the "solve" of step k on this rank
+        pg.gather(k)
+        with pytest.raises(RuntimeError):
+            pg.gather(k)  # same buffer, gather still in flight
+    last = pg.finish()
+    assert sorted(seen) == list(range(steps))
+    torch.save({"seen": seen, "last": last.clone()}, os.path.join(out_dir, f"p{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_pipelined_all_gather_two_ranks_gloo(tmp_path):
+    """Every step's gathered tensor holds rank r's shard in slot r, in step order, although buffers rotate."""
+    import torch
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_pipe_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        d = torch.load(os.path.join(str(tmp_path), f"p{rank}.pt"))
+        for k, t in d["seen"].items():
+            want = torch.cat([torch.full((5, 3), float(100 * k + r)) for r in range(2)])
+            assert torch.equal(t, want), (rank, k)
+        assert torch.equal(d["last"], d["seen"][6])
