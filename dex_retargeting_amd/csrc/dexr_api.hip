@@ -319,20 +319,22 @@ int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out) {
     // its float64 polish launch on a large component (position models: LEAP 9.9 vs 22 ms, Inspire 8.7 vs 27 ms,
     // Shadow+free 57 vs 170 ms) and loses where it does not (Shadow vector 20 vs 3.8 ms) or where the component is
     // dense and 24 wide (Shadow DexPilot 51 vs 36 ms: 1 wave/CU and a code footprint beyond the instruction cache).
-    const bool wanted = (h.kind == DEXR_KIND_POSITION || m->bucket == 32) ? !std::getenv("DEXR_NO_BIG")
-                                                                          : std::getenv("DEXR_FORCE_BIG") != nullptr;
-    m->big = wanted && m->bucket >= 16 && h.kind != DEXR_KIND_FKONLY && max_slot < 2 && lds <= 160 * 1024;
-    // four lanes per frame: dense vector / DexPilot components of 9..24 joints without mimic joints, one fork level
+    // four lanes per frame: dense components of 9..24 joints without mimic joints, one fork level
     bool has_mimic = false;
     for (const dexr_comp_table& c : m->comps)
       for (int k = 0; k < c.n_joint; ++k) has_mimic = has_mimic || c.src_kind[k] == DEXR_SRC_MIMIC;
-    // Measured (65 536 frames, tools/cmp_big.py): Shadow DexPilot (24 joints, dense) 19.6 ms vs 35.8 ms for the register
-    // kernel + float64 polish; but slower for 16-joint DexPilot hands (8.9 vs 6.8 ms) and for Shadow vector (6.9 vs
-    // 3.8 ms, which needs no polish): used where it wins, DEXR_FORCE_QUAD=1 selects it for every eligible model.
-    const bool quad_ok = !m->big && (m->bucket == 16 || m->bucket == 24) && !has_mimic && max_slot < 1 &&
-                         (h.kind == DEXR_KIND_VECTOR || h.kind == DEXR_KIND_DEXPILOT);
-    m->quad = quad_ok && !std::getenv("DEXR_NO_QUAD") &&
-              ((m->bucket == 24 && h.kind == DEXR_KIND_DEXPILOT) || std::getenv("DEXR_FORCE_QUAD"));
+    // Measured (65 536 frames, tools/cmp_big.py / tools/term_sweep.py): the quad kernel wins for Shadow DexPilot (24
+    // joints, dense: 14.6 ms vs 35.8 ms register + float64 polish) and for position models with free joints (LEAP
+    // 6.7 vs 9.5 ms LDS kernel, Allegro 4.7 vs 6.1 ms); it loses for 16-joint DexPilot hands (8.9 vs 3.1 ms) and
+    // Shadow vector (6.9 vs 3.8 ms, no polish needed): used where it wins, DEXR_FORCE_QUAD=1 selects it for every
+    // eligible model.
+    const bool quad_ok = (m->bucket == 16 || m->bucket == 24) && !has_mimic && max_slot < 1 && h.kind != DEXR_KIND_FKONLY;
+    const bool quad_wins = (m->bucket == 24 && h.kind == DEXR_KIND_DEXPILOT) || h.kind == DEXR_KIND_POSITION;
+    m->quad = quad_ok && !std::getenv("DEXR_NO_QUAD") && !std::getenv("DEXR_FORCE_BIG") &&
+              (quad_wins || std::getenv("DEXR_FORCE_QUAD"));
+    const bool wanted = (h.kind == DEXR_KIND_POSITION || m->bucket == 32) ? !std::getenv("DEXR_NO_BIG")
+                                                                          : std::getenv("DEXR_FORCE_BIG") != nullptr;
+    m->big = !m->quad && wanted && m->bucket >= 16 && h.kind != DEXR_KIND_FKONLY && max_slot < 2 && lds <= 160 * 1024;
   }
   m->chain = (h.kind == DEXR_KIND_VECTOR || h.kind == DEXR_KIND_POSITION) && !std::getenv("DEXR_NO_CHAIN");
   for (const dexr_comp_table& c : m->comps) {
