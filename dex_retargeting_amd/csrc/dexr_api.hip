@@ -157,14 +157,15 @@ int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStr
   int64_t waves = tiles * kp.n_comp;
   if (mode == dexr::MODE_SOLVE && m->bucket <= 8) {
     // persistent lanes (small components): a resident set of waves pulls frames from per-component queues
-    int occ = m->chain ? 3 : 2;  // waves per SIMD the kernels' register budgets allow
+    int occ = m->chain ? 4 : (m->bucket <= 4 ? 3 : 2);  // waves per SIMD the kernels' register budgets allow
     if (const char* e = std::getenv("DEXR_PERSIST_OCC")) occ = std::atoi(e) > 0 ? std::atoi(e) : occ;
     const int64_t resident = (int64_t)m->n_cu * 4 * occ;
     const int64_t per_comp = (resident + kp.n_comp - 1) / kp.n_comp;
-    // Few frames per lane: one 64-frame tile per wave (the queue then just numbers the tiles).  Many frames per
-    // lane: a resident set of waves drains the queue in larger chunks, which evens out the very different iteration
-    // counts of individual frames (measured: 1.0x at 65 536 Allegro frames, 2.4x at 1 M).
-    int64_t persist_from = 3;
+    // Few frames per lane: one 64-frame tile per wave (no queue).  Many frames per lane: a resident set of waves
+    // drains the queue in chunks, which evens out the different iteration counts of individual frames.  Measured
+    // (profiles/r01_term_sweep.txt, Allegro vector): tile mode is faster up to 262 144 frames (0.20 vs 0.25 ms), the
+    // queue wins at 1 M (0.61 vs 0.67 ms).
+    int64_t persist_from = 8;
     if (const char* e = std::getenv("DEXR_PERSIST_FROM")) persist_from = std::atoi(e);
     kp.qchunk = 0;  // tile mode: no queue traffic at all
     if (tiles >= persist_from * per_comp) {

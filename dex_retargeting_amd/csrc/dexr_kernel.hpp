@@ -21,7 +21,7 @@
 #include "dexr_tables.h"
 
 #ifndef DEXR_CHAIN_MINW
-#define DEXR_CHAIN_MINW 3  // minimum waves per SIMD requested for the serial-chain kernel (caps its VGPR budget)
+#define DEXR_CHAIN_MINW 4  // minimum waves per SIMD requested for the serial-chain kernel (caps its VGPR budget at 128)
 #endif
 
 namespace dexr {

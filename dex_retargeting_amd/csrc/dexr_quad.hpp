@@ -35,8 +35,11 @@ static __device__ __forceinline__ float sel4(int p, float a0, float a1, float a2
 // blockDim.x = 256 (4 waves x 16 frames); dynamic LDS per wave = 64 * (8 * 3 * lds_frames + 4 * 3 * NMAX) bytes:
 // float64 frame positions + float32 joint origins, [row][lane] (the 4 lanes of a quad hold copies).  Per-term targets
 // and DexPilot weights are recomputed from ref_value on demand (L1/L2 hits) to keep 4 waves per CU within 160 KB.
+#ifndef DEXR_QUAD_MINW
+#define DEXR_QUAD_MINW 1  // waves per SIMD the register allocation must leave room for
+#endif
 template <int NMAX>
-__global__ void __launch_bounds__(256) dexr_quad_kernel(const KernelParams kp, const dexr_comp_table* __restrict__ comps) {
+__global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const KernelParams kp, const dexr_comp_table* __restrict__ comps) {
   static_assert(NMAX % 4 == 0, "bucket must be a multiple of the quad width");
   constexpr int NR = NMAX / 4;             // Hessian rows per lane
   constexpr int NHQ = 2 * NR * (NR + 1);   // local row i keeps columns 0..4i+3
