@@ -28,7 +28,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", 
 # same kernel has 9 % fewer VALU instructions, 126 instead of 156 VGPRs (4 waves per SIMD, no scratch) and runs
 # 25 % faster (Allegro vector 0.108 -> 0.081 ms per 65 536 frames; Shadow vector 9.4 -> 4.3 ms).  The LDS kernel
 # (dexr_big) measured no gain and keeps the default.
-NO_SLP = ["-fno-slp-vectorize"]
+# float32 divisions / square roots of the solver (step scaling, Huber weights, Cholesky pivots) do not need IEEE
+# rounding or denormal support -- parity is measured against the float64 oracle: 2.5-ulp v_rcp/v_rsq sequences and
+# flushed denormals save another 8 % of the chain kernel's VALU instructions.
+NO_SLP = ["-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals-to-zero"]
 
 
 def _hipcc() -> str:

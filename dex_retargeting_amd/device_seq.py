@@ -119,6 +119,30 @@ class DeviceSeqRetargeting:
                                  torch.cuda.current_stream(self.device).cuda_stream)
         return self.retarget(self._kp_mano, fixed_qpos, _keypoints=True)
 
+    def capture(self, keypoints_seq, out=None):
+        """Capture T lock-step frames into ONE HIP graph (``torch.cuda.CUDAGraph``): ``keypoints_seq`` is a persistent
+        (T, B, 21, 3) float32 CUDA tensor the caller refills before every ``graph.replay()``; ``out`` (T, B, dof)
+        float64 receives the filtered robot qpos of every frame.  The carried state (last_qpos, filter, DexPilot bits)
+        lives in HBM, so consecutive replays continue the sequences: T kernel launches + ~10 T element-wise ops cost
+        one graph launch.  At least one eager frame must have run before (the low-pass filter's first frame is a
+        host-side branch).  Returns (graph, out)."""
+        torch = self.torch
+        if self.alpha is not None and not self._filter_init:
+            raise RuntimeError("run one eager frame first: the first frame initialises the low-pass filter")
+        if self.n_fixed:
+            raise NotImplementedError("capture() serves models without caller-supplied fixed joints")
+        T = int(keypoints_seq.shape[0])
+        if keypoints_seq.dtype != torch.float32 or not keypoints_seq.is_contiguous() or keypoints_seq.device != self.device:
+            raise ValueError("keypoints_seq must be a contiguous float32 tensor on this device")
+        if out is None:
+            out = torch.empty((T, self.batch, self.robot_qpos.shape[1]), dtype=torch.float64, device=self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for t in range(T):
+                out[t].copy_(self.retarget(keypoints_seq[t], None, _keypoints=True))
+        self.num_retargeting -= T  # capture itself solves nothing
+        return graph, out
+
     def retarget(self, ref_value, fixed_qpos=None, _keypoints=False):
         """ref_value: (B, n_ref, 3) float32 CUDA tensor (contiguous).  Returns the (B, dof) float64 CUDA tensor of
         filtered robot qpos in pinocchio dof order (a view of an internal buffer, overwritten by the next call)."""

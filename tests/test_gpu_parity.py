@@ -345,6 +345,32 @@ def test_device_resident_sequences_equal_host_batched(rel):
         assert np.array_equal(host.last_qpos, dev.last_qpos.cpu().numpy()), t
 
 
+@pytest.mark.parametrize("rel", ["teleop/allegro_hand_right.yml", "teleop/inspire_hand_right_dexpilot.yml"])
+def test_hip_graph_of_a_frame_sequence_equals_eager(rel):
+    """DeviceSeqRetargeting.capture: T frames (solve kernels + state updates) recorded once into a HIP graph and
+    replayed twice == the same 2 T frames issued eagerly, bit for bit, including the carried state."""
+    torch = pytest.importorskip("torch")
+    cfg_path = os.path.join(cases.CONFIG_DIR, rel)
+    B, T = 200, 3
+    kp = torch.from_numpy(cases.human_keypoints(B * (2 * T + 1), seed=4).reshape(2 * T + 1, B, 21, 3)).cuda()
+    eager = RetargetingConfig.load_from_file(cfg_path).build_device(B)
+    graphed = RetargetingConfig.load_from_file(cfg_path).build_device(B)
+    eager.retarget_keypoints(kp[0])
+    graphed.retarget_keypoints(kp[0])
+    buf = torch.empty((T, B, 21, 3), dtype=torch.float32, device="cuda:0")
+    graph, out = graphed.capture(buf)
+    for rep in range(2):
+        frames = kp[1 + rep * T: 1 + (rep + 1) * T]
+        buf.copy_(frames)
+        graph.replay()
+        torch.cuda.synchronize()
+        for t in range(T):
+            want = eager.retarget_keypoints(frames[t])
+            assert torch.equal(out[t], want), (rep, t)
+        assert torch.equal(graphed.last_qpos, eager.last_qpos)
+        assert torch.equal(graphed.state, eager.state)
+
+
 @pytest.mark.parametrize("rel", ["teleop/allegro_hand_right.yml", "teleop/shadow_hand_right_dexpilot.yml",
                                  "offline/leap_hand_right.yml", "teleop/panda_gripper.yml"])
 def test_keypoint_entry_point_equals_ref_value_path(rel):
