@@ -86,6 +86,7 @@ void fill_params(const dexr_model* m, dexr::KernelParams& kp, int64_t B) {
   kp.lam_fastdec = m->bucket <= 8 ? 0.1f : 0.f;
   kp.floor_scale = 1e-12f;
   kp.step_cap = 0.3f;
+  kp.blind_tol = 0.f;  // set from the tolerance in apply_options
   kp.n_opt = h.n_opt;
   kp.n_fixed = h.n_fixed;
   kp.n_ref = h.n_ref;
@@ -203,6 +204,8 @@ void apply_options(dexr::KernelParams& kp, const dexr_solve_options* opt) {
   if (const char* e = std::getenv("DEXR_LAM_FASTDEC")) kp.lam_fastdec = (float)std::atof(e);
   if (const char* e = std::getenv("DEXR_FLOOR")) kp.floor_scale = (float)std::atof(e);
   if (const char* e = std::getenv("DEXR_STEP_CAP")) kp.step_cap = (float)std::atof(e);
+  kp.blind_tol = 10.f * kp.tol;
+  if (const char* e = std::getenv("DEXR_BLIND_TOL")) kp.blind_tol = (float)std::atof(e);
   kp.stall_from = 2;
   kp.stall_ratio = 0.9f;
   kp.stall_cap = 20.f;
@@ -470,6 +473,7 @@ static int retarget_host(const dexr_model* m, int64_t B, const float* ref, const
   kp.status = d_status.as<int32_t>();
   kp.iters = d_iters.as<int32_t>();
   kp.fval = d_fval.as<float>();
+  if (f64) kp.blind_tol = 0.f;  // dexr_retarget_f64 is the validation path: every step it reports has been verified
   int rc = launch(m, dexr::MODE_SOLVE, f64, kp, nullptr);
   if (rc != DEXR_OK) return rc;
   if (!f64) {

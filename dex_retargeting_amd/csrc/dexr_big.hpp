@@ -597,6 +597,14 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
       }
     }
     pending = stepping;
+    // verified, undamped model and a Newton step below blind_tol: the step is the converged answer to well below the
+    // tolerance -- take it and stop instead of spending one more pass on confirming it
+    if (stepping && okf && smax < kp.blind_tol && lam <= kp.lam0) {
+      ++my_iters;
+      pending = false;
+      done = true;
+      status = ST_CONVERGED;
+    }
   }
   if (pending) {  // pass budget exhausted with an untested trial: hand back the accepted point
 #pragma unroll

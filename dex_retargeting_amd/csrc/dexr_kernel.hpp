@@ -52,6 +52,8 @@ struct KernelParams {
   int32_t max_blind;  // accepted steps below the rounding floor of F before giving up on further progress
   int32_t lds_frames, lds_terms;  // per-wave LDS rows: max frames / max terms over the model's components
   int32_t big_nh_rows;            // dexr_big_kernel: LDS rows reserved for the Hessian (n_max (n_max + 1) / 2)
+  float blind_tol;                // a Newton step of a verified, undamped model shorter than this is taken without a
+                                  // further evaluation of the objective and ends the solve (0: off)
   float step_cap;                 // trust radius: a step whose largest component exceeds it is scaled down to it (0: off)
   float lam_jump;                 // on a rejected step lambda becomes at least lam_jump x mean diag(H) (0: plain x nu)
   float lam_fastdec;              // on an accepted step with rho > 0.9 lambda shrinks by this factor (0: Nielsen's 1/3)
@@ -792,7 +794,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
 
       // (2) step from the accepted model (lanes holding a fresh frame evaluate their start point instead)
       real smax = 0, pred = 0;
-      bool ok = true;
+      bool ok = true, last_step = false;
       if (__any(has && !fresh)) {
         uint32_t freemask = 0;
 #pragma unroll
@@ -839,6 +841,10 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
             if (stepping) S.x[k] = xt;
           }
         }
+        // The model at the accepted point is verified and (lambda back at its floor) undamped: a Newton step this short
+        // is the converged answer to well below the tolerance, evaluating the objective there once more could only
+        // confirm it.  Take it and retire the frame one pass earlier.
+        last_step = stepping && ok && smax < (real)kp.blind_tol && lam <= (real)kp.lam0;
       }
 
       // (3) forward kinematics + fused value / gradient / Hessian at S.x
@@ -869,6 +875,12 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
             finished = true;
             status = ST_FALLBACK;
           }
+        } else if (last_step && finite) {
+          accept = true;
+          finished = true;
+          status = ST_CONVERGED;
+          ++my_iters;
+          F = Ft;
         } else {
           const real noise = (real)16 * RT::eps() * fabs(F);
           // below the rounding floor of F the decrease test is meaningless: trust the (small) Newton step
@@ -1028,6 +1040,8 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
         if (!done) S.x[k] = xt;
       }
     }
+    // verified, undamped model and a Newton step below blind_tol: take it and stop (see the small-component path)
+    const bool last_step = !done && ok && smax < (real)kp.blind_tol && lam <= (real)kp.lam0;
     S.fk(tb, nj, P, lane);
     real Ft = S.template residuals<0>(tb, kp, nt, vmask, P, T, W, lane);
 #pragma unroll
@@ -1038,9 +1052,14 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
     const bool finite = (Ft == Ft) && (smax == smax) && (fabs(Ft) < (real)1e30);
     // below the rounding floor of F the decrease test is meaningless: trust the (small) Newton step
     const bool below_floor = ok && finite && (pred <= noise) && (smax < (real)1e-2);
-    const bool accept = !done && ok && finite && ((Ft <= F) || below_floor);
+    const bool accept = !done && ok && finite && ((Ft <= F) || below_floor || last_step);
     bool redo = false;
-    if (!done) {
+    if (!done && last_step && finite) {
+      ++my_iters;
+      F = Ft;
+      done = true;
+      status = ST_CONVERGED;
+    } else if (!done) {
       ++my_iters;
       if (accept) {
         const real rho = (F - Ft) / fmax(pred, (real)1e-30);
