@@ -170,7 +170,13 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
   }
 
   // ---- float64 forward kinematics ------------------------------------------------------------------------------
+  // Lever arms (frame position - joint origin) enter the float32 Jacobian.  With free joints the whole hand sits up to
+  // ~0.5 m from the world origin, where float32 resolves 3e-8 m -- 1e-6 of a 3 cm lever arm, which biases the gradient
+  // enough to move the fixed point by 1e-5..1e-4 rad on weakly determined joints.  Both operands are therefore taken
+  // relative to c0, the float64 origin of the first revolute joint (the hand's base), before the cast.
+  double c0[3] = {0, 0, 0};
   auto fk = [&]() {
+    bool c0_set = false;
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
     double sR[BIG_NSLOT][9], sp[BIG_NSLOT][3];
 #pragma unroll
@@ -232,10 +238,15 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
 #pragma unroll
           for (int i = 0; i < 3; ++i) p[i] += q * Rn[3 * i + 2];
         }
+        if (!c0_set && tb.jtype[k] == DEXR_JOINT_REVOLUTE) {
+          c0_set = true;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) c0[i] = p[i];
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           ax[k][i] = (float)R[3 * i + 2];
-          og[k][i] = (float)p[i];
+          og[k][i] = (float)(p[i] - c0[i]);
         }
         const int sv = tb.save[k];
         if (sv >= 0) {
@@ -279,8 +290,8 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
     for (int i = 0; i < 3; ++i) {
       r[i] = pt[i] - po[i] - (double)tv[i];
       e.r[i] = (float)r[i];
-      e.pt[i] = (float)pt[i];
-      e.po[i] = (float)po[i];
+      e.pt[i] = (float)(pt[i] - c0[i]);
+      e.po[i] = (float)(po[i] - c0[i]);
     }
     const double w = (double)kp.inv_norm * (double)wt;
     e.kap = 0;

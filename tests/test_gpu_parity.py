@@ -289,6 +289,33 @@ def test_full_size_batch_properties():
     assert np.percentile(err, 99) < 2e-3  # regulariser keeps a small bias; targets are reproduced to mm
 
 
+@pytest.mark.parametrize("rel", ["teleop/allegro_hand_right.yml", "teleop/ability_hand_right.yml",
+                                 "teleop/panda_gripper_dexpilot.yml"])
+def test_queue_mode_equals_tile_mode(rel, monkeypatch):
+    """Small components are launched either as one 64-frame tile per wave or, for batches of many tiles per resident
+    wave (> 500 000 Allegro frames), as persistent lanes that pull frames from a work queue.  Every frame is solved by
+    the same per-lane arithmetic in both, so the answers must agree bit for bit: force the queue mode (several chunk
+    sizes and resident-set sizes) at a test-sized batch, ragged on purpose."""
+    seq, prob = build(rel)
+    model = seq.optimizer.device_model()
+    B = 20000 + 37
+    d = cases.human_set(prob, B, seed=3)
+    st = (lambda: np.zeros(B, np.uint32)) if prob.kind == "dexpilot" else (lambda: None)
+    monkeypatch.setenv("DEXR_PERSIST_FROM", "1000000000")
+    s_tile = st()
+    want, wi = model.retarget(d["ref"], d["fixed"], d["last"], state=s_tile, want_info=True)
+    for occ, chunk in ((1, 64), (4, 256), (2, 16)):
+        monkeypatch.setenv("DEXR_PERSIST_FROM", "0")
+        monkeypatch.setenv("DEXR_PERSIST_OCC", str(occ))
+        monkeypatch.setenv("DEXR_QCHUNK", str(chunk))
+        s_q = st()
+        got, gi = model.retarget(d["ref"], d["fixed"], d["last"], state=s_q, want_info=True)
+        assert np.array_equal(got, want), (occ, chunk)
+        assert np.array_equal(gi["iters"], wi["iters"]) and np.array_equal(gi["status"], wi["status"])
+        if s_tile is not None:
+            assert np.array_equal(s_q, s_tile)
+
+
 def test_non_finite_input_falls_back_to_last_qpos():
     seq, prob = build("teleop/allegro_hand_right.yml")
     d = cases.reachable_set(prob, 8, 0.05)

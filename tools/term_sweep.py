@@ -84,6 +84,10 @@ for cap in (0, 0.2, 0.5):
     SETTINGS.append((f"step_cap={cap}", {"DEXR_STEP_CAP": str(cap)}, None))
 for jump, dec in ((0.3, 0), (1.0, 0), (1.0, 0.1)):
     SETTINGS.append((f"jump={jump} fastdec={dec}", {"DEXR_LAM_JUMP": str(jump), "DEXR_LAM_FASTDEC": str(dec)}, None))
+if "--precision" in sys.argv:  # which knob limits the float32 answer's distance from the float64 one?
+    SETTINGS = [("default", {}, None), ("floor=7e-15", {"DEXR_FLOOR": "7.1e-15"}, None), ("tol=5e-7", {}, 5e-7),
+                ("tol=5e-7 floor=7e-15", {"DEXR_FLOOR": "7.1e-15"}, 5e-7), ("max_blind=0 blind_tol=0", {"DEXR_MAX_BLIND": "1000", "DEXR_BLIND_TOL": "0", "DEXR_STALL_FROM": "1000"}, None),
+                ("tol=5e-7 no blind exits", {"DEXR_MAX_BLIND": "1000", "DEXR_BLIND_TOL": "0", "DEXR_STALL_FROM": "1000", "DEXR_FLOOR": "7.1e-15"}, 5e-7)]
 for name, env, tol in SETTINGS:
     ms, it, dq = measure(env, tol)
     wm = it[: B // 64 * 64].reshape(-1, 64).max(1)
