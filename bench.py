@@ -44,6 +44,17 @@ def algorithmic_bytes_per_frame(n_opt: int, dexpilot: bool, n_kp: int = 21) -> i
     return n_kp * 12 + n_opt * 4 + n_opt * 4 + (8 if dexpilot else 0)
 
 
+def algorithmic_flops_per_pass(compiled) -> float:
+    """FP operations of ONE solver pass (FK + value/gradient/Hessian + factorisation + step) over all components of a
+    frame, counted from the compiled tables: per component with n joints and T terms
+    FK 100 n  +  T (20 + 18 n + 18 n(n+1)/2)  +  n^3/3 + 2 n^2  +  10 n."""
+    total = 0.0
+    for c in compiled.comps:
+        n, t = int(c["n_joint"]), int(c["n_term"])
+        total += 100 * n + t * (20 + 18 * n + 18 * n * (n + 1) / 2) + n ** 3 / 3 + 2 * n * n + 10 * n
+    return total
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,6 +191,8 @@ def main():
             traffic = pmc.get("hbm_bytes_per_launch")
             if "SQ_INSTS_VALU" in pmc:  # wave64 VALU instruction = 4 issue cycles on a 16-lane SIMD; 1024 SIMDs, 2.4 GHz
                 valu_frac = pmc["SQ_INSTS_VALU"] * 4.0 / (1024 * kernel_ms * 1e-3 * 2.4e9)
+    flops_frame = algorithmic_flops_per_pass(opt.compiled_model()) * (iters_mean + 1.0)  # +1: the start point's model
+    valu_tflops = B * flops_frame / (kernel_ms * 1e-3) / 1e12
     out = {
         "metric": json.load(open(os.path.join(REPO, "BASELINE.json")))["metric"],
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -195,6 +208,10 @@ def main():
                      "traffic_note": "bytes per launch from the rocprofv3 --pmc passes in profiles/ (same command, "
                                      "same batch); null when no matching profile is committed",
                      "valu_issue_frac": valu_frac,
+                     "valu": {"achieved": valu_tflops, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": valu_tflops / FP32_VALU_PEAK_TFLOPS, "algorithmic_flops_per_frame": flops_frame,
+                              "note": "algorithmic flops per solver pass (bench.py:algorithmic_flops_per_pass) x mean "
+                                      "passes per frame of this run"},
                      "kernel": "dexr_kernel<NMAX,float,SOLVE[,CHAIN]> (+ float64 polish launch for position/dexpilot)",
                      "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_frame": bpf,

@@ -129,10 +129,21 @@ int launch_quad(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
   const size_t per_wave = (size_t)64 * (8 * 3 * (size_t)m->lds_frames + 4 * 3 * (size_t)m->bucket);
   int wpb = 4;
   while (wpb > 1 && per_wave * wpb > 150 * 1024) wpb >>= 1;
-  const int64_t tiles = (kp.B + 15) / 16;  // 16 frames per wave
-  const int64_t waves = tiles * kp.n_comp;
+  // persistent quads: at most one wave per SIMD is resident (the kernel needs the whole register file); each starts with
+  // a static tile of 16 frames, the rest of the batch is handed out through the per-component queue counter
+  const int64_t tiles = (kp.B + 15) / 16;  // 16 frames per wave at a time
+  int64_t resident = (int64_t)m->n_cu * 4;
+  if (const char* e = std::getenv("DEXR_QUAD_WAVES")) resident = std::atoll(e) > 0 ? std::atoll(e) : resident;
+  int64_t per_comp = (resident + kp.n_comp - 1) / kp.n_comp;
+  if (per_comp > tiles) per_comp = tiles;
+  const int64_t waves = per_comp * kp.n_comp;
   const int64_t blocks = (waves + wpb - 1) / wpb;
   if (blocks > 0x7fffffffLL) return fail(DEXR_ERR_INVALID, "batch too large for one launch");
+  kp.q0 = (uint32_t)(per_comp * 16);
+  const unsigned slot = m->qnext.fetch_add(1u) % dexr_model::QSLOTS;
+  kp.queue = m->d_queue + (size_t)slot * kp.n_comp;
+  hipError_t qe = hipMemsetAsync(kp.queue, 0, (size_t)kp.n_comp * sizeof(unsigned), st);
+  if (qe != hipSuccess) return fail(DEXR_ERR_HIP, "queue reset failed: %s", hipGetErrorString(qe));
   dexr::launch_fn fn = dexr::find_quad_launcher(m->bucket);
   if (!fn) return fail(DEXR_ERR_UNSUPPORTED, "no quad kernel for bucket %d", m->bucket);
   hipError_t e = fn(kp, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, st);

@@ -52,11 +52,13 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
   const int waves_per_block = blockDim.x >> 6;
   const int64_t wave_global = (int64_t)blockIdx.x * waves_per_block + wave_in_block;
   const int comp = (int)(wave_global % kp.n_comp);
-  const int64_t tile = wave_global / kp.n_comp;  // 16 frames per tile
-  if (tile * 16 >= kp.B) return;
-  const int64_t item_raw = tile * 16 + (lane >> 2);
-  const bool valid = item_raw < kp.B;
-  const int64_t item = valid ? item_raw : kp.B - 1;
+  const int64_t tile = wave_global / kp.n_comp;  // this wave's index among the waves of its component
+  // PERSISTENT QUADS: frames need very different iteration counts (DexPilot: mean 5, maximum 40+), so a quad that
+  // finishes its frame pulls the next one instead of idling until the slowest of the wave's 16 frames is done.  Wave w
+  // starts with the static tile [16 w, 16 w + 16); frames from kp.q0 on are numbered by a per-component queue counter
+  // that a wave advances by 16 whenever its local pool is empty.
+  int64_t item = 0;     // frame this quad is working on
+  bool active = false;  // the quad holds a frame (idle quads still execute the passes, on stale data, and store nothing)
 
   const size_t per_wave = (size_t)64 * (8 * 3 * kp.lds_frames + 4 * 3 * NMAX);
   double* Pl = reinterpret_cast<double*>(lds_raw + (size_t)wave_in_block * per_wave) + lane;
@@ -96,7 +98,13 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
   };
   auto xl = [&](int k) -> float { return kp.last[item * kp.n_opt + tb.api[k]]; };
 
-  // ---- load the frame (all four lanes of the quad load the same values) ------------------------------------------
+  // DexPilot projection bits (optimizer.py:466-476) of the current frame
+  uint32_t nst = 0;
+  const bool dexpilot = kp.kind == DEXR_KIND_DEXPILOT;
+  const int F_ = kp.num_fingers, n_pair = F_ * (F_ - 1) / 2, len_s1 = F_ - 1;
+  // ---- load a frame (all four lanes of the quad load the same values) --------------------------------------------
+  auto load_frame = [&](int64_t it) {
+  item = it;
 #pragma unroll
   for (int k = 0; k < NMAX; ++k) {
     x[k] = 0;
@@ -110,10 +118,7 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
       }
     }
   }
-  // DexPilot projection bits (optimizer.py:466-476)
-  uint32_t nst = 0;
-  const bool dexpilot = kp.kind == DEXR_KIND_DEXPILOT;
-  const int F_ = kp.num_fingers, n_pair = F_ * (F_ - 1) / 2, len_s1 = F_ - 1;
+  nst = 0;
   if (dexpilot) {
     const uint32_t st = kp.state ? kp.state[item] : 0u;
     for (int i = 0; i < len_s1; ++i) {
@@ -136,6 +141,7 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
         ++idx;
       }
   }
+  };
   // target vector and weight of one term (optimizer.py:246, 479-507), recomputed on demand
   auto term_target = [&](int row, float (&tv)[3], float& wt) {
     float rv[3];
@@ -435,14 +441,63 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
 
   // ---- projected Levenberg-Marquardt / Newton (single call site per stage, like dexr_big.hpp) ---------------------
   float lam = kp.lam0, nu = 2.f, sprev = 1e30f, keff = 0.f;
-  bool done = false, pending = false;
-  int status = ST_MAXITER, my_iters = 0, blind = 0;
+  bool done = true, pending = false;  // done: no solve in progress in this quad (idle, or finished and about to retire)
+  int status = ST_MAXITER, my_iters = 0, blind = 0, my_pass = 0;
   double F = 0;
   float smax = 0, pred = 0;
   bool ok = true;
   const int max_pass = 2 * kp.max_iter + 2;
-  for (int pass = 0; pass < max_pass; ++pass) {
-    if (__all(done)) break;
+  // wave-uniform pool of unassigned frames
+  unsigned pool_next = (unsigned)((tile * 16 < (int64_t)kp.q0 && tile * 16 < kp.B) ? tile * 16 : 0);
+  unsigned pool_end = (unsigned)((tile * 16 < (int64_t)kp.q0 && tile * 16 < kp.B)
+                                     ? ((tile * 16 + 16 < kp.B) ? tile * 16 + 16 : kp.B) : 0);
+  bool dry = false;  // the queue is exhausted
+  unsigned* queue = kp.queue + comp;
+  for (;;) {
+    // (0) hand frames to idle quads
+    const unsigned long long want = __ballot(!active);
+    if (want != 0ull) {
+      if (pool_next >= pool_end && !dry) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(queue, 16u);
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + kp.q0;
+        if ((int64_t)base >= kp.B) {
+          dry = true;
+        } else {
+          pool_next = base;
+          pool_end = (unsigned)(((int64_t)base + 16 < kp.B) ? base + 16 : kp.B);
+        }
+      }
+      if (pool_next < pool_end) {
+        // rank of this quad among the wanting quads = wanting lanes below it / 4 (the four lanes of a quad agree)
+        const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
+        const unsigned cand = pool_next + ((below - (unsigned)p) >> 2);
+        const bool got = !active && cand < pool_end;
+        pool_next += (unsigned)__popcll(__ballot(got)) >> 2;
+        if (got) {
+          load_frame((int64_t)cand);
+          active = true;
+          done = false;
+          pending = false;
+          lam = kp.lam0;
+          nu = 2.f;
+          sprev = 1e30f;
+          keff = 0.f;
+          status = ST_MAXITER;
+          my_iters = 0;
+          blind = 0;
+          my_pass = 0;
+          F = 0;
+          smax = 0;
+          pred = 0;
+          ok = true;
+        }
+      }
+    }
+    if (!__any(active)) {
+      if (dry && pool_next >= pool_end) break;
+      continue;
+    }
     fk();
     const double Fe = assemble();
     bool rebuild = false;
@@ -488,7 +543,6 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
         if (!done && my_iters >= kp.max_iter) done = true;
       }
     }
-    if (__all(done)) break;
     uint32_t freemask = 0;
 #pragma unroll
     for (int k = 0; k < NMAX; ++k) {
@@ -541,30 +595,37 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
       done = true;
       status = ST_CONVERGED;
     }
-  }
-  if (pending) {
-#pragma unroll
-    for (int k = 0; k < NMAX; ++k) x[k] = xo[k];
-  }
+    // pass budget of this frame exhausted: hand back the accepted point
+    if (active && !done && ++my_pass >= max_pass) done = true;
 
-  bool bad = false;
+    // (last) retire finished frames
+    if (active && done) {
+      if (pending) {  // untested trial point
 #pragma unroll
-  for (int k = 0; k < NMAX; ++k)
-    if ((optmask >> k) & 1u) bad = bad || !(x[k] == x[k]);
-  if (bad) status = ST_FALLBACK;
-  if (valid && p == 0) {
-#pragma unroll
-    for (int k = 0; k < NMAX; ++k) {
-      if ((optmask >> k) & 1u) {
-        const float v = bad ? xl(k) : x[k];
-        kp.qout[item * kp.n_opt + tb.api[k]] = v;
-        if (kp.qout64) kp.qout64[item * kp.n_opt + tb.api[k]] = (double)v;
+        for (int k = 0; k < NMAX; ++k) x[k] = xo[k];
+        pending = false;
       }
+      bool bad = false;
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k)
+        if ((optmask >> k) & 1u) bad = bad || !(x[k] == x[k]);
+      if (bad) status = ST_FALLBACK;
+      if (p == 0) {
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k) {
+          if ((optmask >> k) & 1u) {
+            const float v = bad ? xl(k) : x[k];
+            kp.qout[item * kp.n_opt + tb.api[k]] = v;
+            if (kp.qout64) kp.qout64[item * kp.n_opt + tb.api[k]] = (double)v;
+          }
+        }
+        if (dexpilot && kp.state && comp == 0) kp.state[item] = nst;
+        if (kp.status) atomicMax(&kp.status[item], status);
+        if (kp.iters) atomicMax(&kp.iters[item], my_iters);
+        if (kp.fval) atomicAdd(&kp.fval[item], (float)F);
+      }
+      active = false;
     }
-    if (dexpilot && kp.state && comp == 0) kp.state[item] = nst;
-    if (kp.status) atomicMax(&kp.status[item], status);
-    if (kp.iters) atomicMax(&kp.iters[item], my_iters);
-    if (kp.fval) atomicAdd(&kp.fval[item], (float)F);
   }
 }
 
