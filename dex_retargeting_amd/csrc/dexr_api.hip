@@ -115,9 +115,22 @@ void fill_params(const dexr_model* m, dexr::KernelParams& kp, int64_t B) {
 int launch_big(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
   const size_t lds = (size_t)64 * (4 * (size_t)m->big_nh_rows + 8 * 3 * (size_t)m->lds_frames);
   kp.big_nh_rows = m->big_nh_rows;
+  // persistent lanes: as many waves as fit a CU's 160 KB of LDS (and one per SIMD) are resident, each starts with a
+  // static 64-frame tile, the per-component queue hands out the rest
   const int64_t tiles = (kp.B + 63) / 64;
-  const int64_t blocks = tiles * kp.n_comp;
+  int64_t per_cu = (int64_t)((160 * 1024) / (lds > 0 ? lds : 1));
+  per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+  int64_t resident = (int64_t)m->n_cu * per_cu;
+  if (const char* e = std::getenv("DEXR_BIG_WAVES")) resident = std::atoll(e) > 0 ? std::atoll(e) : resident;
+  int64_t per_comp = (resident + kp.n_comp - 1) / kp.n_comp;
+  if (per_comp > tiles) per_comp = tiles;
+  const int64_t blocks = per_comp * kp.n_comp;
   if (blocks > 0x7fffffffLL) return fail(DEXR_ERR_INVALID, "batch too large for one launch");
+  kp.q0 = (uint32_t)(per_comp * 64);
+  const unsigned slot = m->qnext.fetch_add(1u) % dexr_model::QSLOTS;
+  kp.queue = m->d_queue + (size_t)slot * kp.n_comp;
+  hipError_t qe = hipMemsetAsync(kp.queue, 0, (size_t)kp.n_comp * sizeof(unsigned), st);
+  if (qe != hipSuccess) return fail(DEXR_ERR_HIP, "queue reset failed: %s", hipGetErrorString(qe));
   dexr::launch_fn fn = dexr::find_big_launcher(m->bucket);
   if (!fn) return fail(DEXR_ERR_UNSUPPORTED, "no large-component kernel for bucket %d", m->bucket);
   hipError_t e = fn(kp, dim3((unsigned)blocks), dim3(64), lds, st);

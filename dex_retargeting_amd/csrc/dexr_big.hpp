@@ -47,11 +47,11 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
   const int lane = threadIdx.x & 63;
   const int64_t wave_global = blockIdx.x;
   const int comp = (int)(wave_global % kp.n_comp);
-  const int64_t tile = wave_global / kp.n_comp;
-  if (tile * 64 >= kp.B) return;
-  const int64_t item_raw = tile * 64 + lane;
-  const bool valid = item_raw < kp.B;
-  const int64_t item = valid ? item_raw : kp.B - 1;
+  const int64_t tile = wave_global / kp.n_comp;  // this wave's index among the waves of its component
+  // PERSISTENT LANES (as in dexr_quad.hpp): a lane that finishes its frame stores it and takes the next one -- wave w
+  // starts with the static tile [64 w, 64 w + 64), frames from kp.q0 on are handed out by the per-component queue.
+  int64_t item = 0;     // frame this lane is working on
+  bool active = false;  // the lane holds a frame
 
   float* Hl = reinterpret_cast<float*>(lds_raw) + lane;                                 // H(r,c) at Hl[hidx(r,c)*64]
   double* Pl = reinterpret_cast<double*>(lds_raw + (size_t)kp.big_nh_rows * 64 * 4) + lane;  // frame f at Pl[(3f+i)*64]
@@ -95,7 +95,13 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
   };
   auto xl = [&](int k) -> float { return kp.last[item * kp.n_opt + tb.api[k]]; };  // regularisation target (L1/L2 hit)
 
-  // ---- load the frame ----------------------------------------------------------------------------------------
+  // DexPilot projection bits (optimizer.py:466-476) of the current frame
+  uint32_t nst = 0;
+  const bool dexpilot = kp.kind == DEXR_KIND_DEXPILOT;
+  const int F_ = kp.num_fingers, n_pair = F_ * (F_ - 1) / 2, len_s1 = F_ - 1;
+  // ---- load a frame -------------------------------------------------------------------------------------------
+  auto load_frame = [&](int64_t it) {
+  item = it;
 #pragma unroll
   for (int k = 0; k < NMAX; ++k) {
     x[k] = 0;
@@ -109,10 +115,7 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
       }
     }
   }
-  // DexPilot projection bits (optimizer.py:466-476)
-  uint32_t nst = 0;
-  const bool dexpilot = kp.kind == DEXR_KIND_DEXPILOT;
-  const int F_ = kp.num_fingers, n_pair = F_ * (F_ - 1) / 2, len_s1 = F_ - 1;
+  nst = 0;
   if (dexpilot) {
     const uint32_t st = kp.state ? kp.state[item] : 0u;
     for (int i = 0; i < len_s1; ++i) {
@@ -135,6 +138,7 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
         ++idx;
       }
   }
+  };
   // target vector and weight of one term (optimizer.py:246, 479-507), recomputed on demand
   auto term_target = [&](int row, float (&tv)[3], float& wt) {
     float rv[3];
@@ -514,14 +518,61 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
   // the instruction stream (the unrolled bodies are tens of KB; the 64 KB instruction cache is the scarce resource).
   // A rejected trial costs one extra pass (the model at the old x is rebuilt), like the register kernel's re-run.
   float lam = kp.lam0, nu = 2.f, sprev = 1e30f;
-  bool done = false, pending = false;  // pending: x holds an untested trial point, xo the accepted point
-  int status = ST_MAXITER, my_iters = 0, blind = 0;
+  bool done = true, pending = false;  // done: no solve in progress; pending: x holds an untested trial, xo the accepted point
+  int status = ST_MAXITER, my_iters = 0, blind = 0, my_pass = 0;
   double F = 0;
   float smax = 0, pred = 0;
   bool ok = true;
   const int max_pass = 2 * kp.max_iter + 2;
-  for (int pass = 0; pass < max_pass; ++pass) {
-    if (__all(done)) break;
+  // wave-uniform pool of unassigned frames
+  const bool in_static = tile * 64 < (int64_t)kp.q0 && tile * 64 < kp.B;
+  unsigned pool_next = in_static ? (unsigned)(tile * 64) : 0u;
+  unsigned pool_end = in_static ? (unsigned)((tile * 64 + 64 < kp.B) ? tile * 64 + 64 : kp.B) : 0u;
+  bool dry = false;  // the queue is exhausted
+  unsigned* queue = kp.queue + comp;
+  for (;;) {
+    // (0) hand frames to idle lanes
+    const unsigned long long want = __ballot(!active);
+    if (want != 0ull) {
+      if (pool_next >= pool_end && !dry) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(queue, 64u);
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + kp.q0;
+        if ((int64_t)base >= kp.B) {
+          dry = true;
+        } else {
+          pool_next = base;
+          pool_end = (unsigned)(((int64_t)base + 64 < kp.B) ? base + 64 : kp.B);
+        }
+      }
+      if (pool_next < pool_end) {
+        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
+        const unsigned cand = pool_next + rank;
+        const bool got = !active && cand < pool_end;
+        pool_next += (unsigned)__popcll(__ballot(got));
+        if (got) {
+          load_frame((int64_t)cand);
+          active = true;
+          done = false;
+          pending = false;
+          lam = kp.lam0;
+          nu = 2.f;
+          sprev = 1e30f;
+          status = ST_MAXITER;
+          my_iters = 0;
+          blind = 0;
+          my_pass = 0;
+          F = 0;
+          smax = 0;
+          pred = 0;
+          ok = true;
+        }
+      }
+    }
+    if (!__any(active)) {
+      if (dry && pool_next >= pool_end) break;
+      continue;
+    }
     fk();
     const double Fe = assemble();
     bool rebuild = false;  // this lane rejected its trial: its model must be rebuilt at xo before it can step again
@@ -565,7 +616,6 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
         if (!done && my_iters >= kp.max_iter) done = true;
       }
     }
-    if (__all(done)) break;
     // step from the model at x
     uint32_t freemask = 0;
 #pragma unroll
@@ -616,30 +666,35 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
       done = true;
       status = ST_CONVERGED;
     }
-  }
-  if (pending) {  // pass budget exhausted with an untested trial: hand back the accepted point
-#pragma unroll
-    for (int k = 0; k < NMAX; ++k) x[k] = xo[k];
-  }
+    // pass budget of this frame exhausted: hand back the accepted point
+    if (active && !done && ++my_pass >= max_pass) done = true;
 
-  bool bad = false;
+    // (last) retire finished frames
+    if (active && done) {
+      if (pending) {  // untested trial point
 #pragma unroll
-  for (int k = 0; k < NMAX; ++k)
-    if ((optmask >> k) & 1u) bad = bad || !(x[k] == x[k]);
-  if (bad) status = ST_FALLBACK;
-  if (valid) {
-#pragma unroll
-    for (int k = 0; k < NMAX; ++k) {
-      if ((optmask >> k) & 1u) {
-        const float v = bad ? xl(k) : x[k];
-        kp.qout[item * kp.n_opt + tb.api[k]] = v;
-        if (kp.qout64) kp.qout64[item * kp.n_opt + tb.api[k]] = (double)v;
+        for (int k = 0; k < NMAX; ++k) x[k] = xo[k];
+        pending = false;
       }
+      bool bad = false;
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k)
+        if ((optmask >> k) & 1u) bad = bad || !(x[k] == x[k]);
+      if (bad) status = ST_FALLBACK;
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k) {
+        if ((optmask >> k) & 1u) {
+          const float v = bad ? xl(k) : x[k];
+          kp.qout[item * kp.n_opt + tb.api[k]] = v;
+          if (kp.qout64) kp.qout64[item * kp.n_opt + tb.api[k]] = (double)v;
+        }
+      }
+      if (dexpilot && kp.state && comp == 0) kp.state[item] = nst;
+      if (kp.status) atomicMax(&kp.status[item], status);
+      if (kp.iters) atomicMax(&kp.iters[item], my_iters);
+      if (kp.fval) atomicAdd(&kp.fval[item], (float)F);
+      active = false;
     }
-    if (dexpilot && kp.state && comp == 0) kp.state[item] = nst;
-    if (kp.status) atomicMax(&kp.status[item], status);
-    if (kp.iters) atomicMax(&kp.iters[item], my_iters);
-    if (kp.fval) atomicAdd(&kp.fval[item], (float)F);
   }
 }
 
