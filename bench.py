@@ -212,7 +212,7 @@ def main():
                               "frac": valu_tflops / FP32_VALU_PEAK_TFLOPS, "algorithmic_flops_per_frame": flops_frame,
                               "note": "algorithmic flops per solver pass (bench.py:algorithmic_flops_per_pass) x mean "
                                       "passes per frame of this run"},
-                     "kernel": "dexr_kernel<NMAX,float,SOLVE[,CHAIN]> (+ float64 polish launch for position/dexpilot)",
+                     "kernel": "dexr_kernel<4,float,SOLVE,CHAIN> (Allegro vector) / dexr_quad_kernel<24> (Shadow DexPilot, LEAP position)",
                      "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_frame": bpf,
                      "note": "path is FP32 VALU/latency bound (n_dof <= 24 per lane, no dense contraction); the HBM "
