@@ -224,14 +224,26 @@ def main():
 
     n_par = 512
     kw = {}
-    if dexpilot:
-        w, rv, _ = prob.dexpilot_preamble(ref_now[:n_par], np.zeros((n_par, prob.n_pair), bool))
+    if dexpilot:  # same incoming projection state as the timed launches: the bits the previous frame left behind
+        proj0 = ((st0[:n_par, None] >> np.arange(prob.n_pair, dtype=np.uint32)) & 1).astype(bool)
+        w, rv, _ = prob.dexpilot_preamble(ref_now[:n_par], proj0)
         kw = dict(weights=w, dexpilot_ref=rv)
     want = solvers.solve_lm_batched(prob, ref_now[:n_par], None, last[:n_par], newton=True, max_iter=100, **kw)
     got = t_q[:n_par].cpu().numpy().astype(np.float64)
     dq = np.abs(got - want).max(1)
+    # several minima exist on human targets (DexPilot especially): where the two answers are different minima, compare
+    # the objective they reach
+    last64 = last[:n_par].astype(np.float64)
+    F_got = prob.total(got, ref_now[:n_par], None, last64, **kw)
+    F_want = prob.total(want, ref_now[:n_par], None, last64, **kw)
+    other = dq >= 1e-4
     out["parity"] = {"subset": n_par, "max_abs_dq_rad": float(dq.max()), "p99_abs_dq_rad": float(np.percentile(dq, 99)),
-                     "frac_within_1e-4": float((dq < 1e-4).mean()), "oracle": "float64 projected LM/Newton on F (oracle/solvers.py)"}
+                     "frac_within_1e-4": float((dq < 1e-4).mean()),
+                     "other_minimum": {"frames": int(other.sum()),
+                                       "gpu_objective_lower_or_equal": int((F_got[other] <= F_want[other] + 1e-9).sum()),
+                                       "median_F_gpu_minus_F_oracle": float(np.median(F_got[other] - F_want[other])) if other.any() else 0.0},
+                     "max_abs_dq_rad_same_minimum": float(dq[~other].max()) if (~other).any() else None,
+                     "oracle": "float64 projected LM/Newton on F (oracle/solvers.py)"}
 
     # ---- CPU baseline: the reference path as configured (scipy SLSQP stand-in for nlopt), host cores ----------
     if world == 1 and not args.no_cpu_baseline:
@@ -240,7 +252,8 @@ def main():
             lo, hi = done, min(done + 50, B)
             kw_c = {}
             if dexpilot:
-                w, rv, _ = prob.dexpilot_preamble(ref_now[lo:hi], np.zeros((hi - lo, prob.n_pair), bool))
+                proj_c = ((st0[lo:hi, None] >> np.arange(prob.n_pair, dtype=np.uint32)) & 1).astype(bool)
+                w, rv, _ = prob.dexpilot_preamble(ref_now[lo:hi], proj_c)
                 kw_c = dict(weights=w, dexpilot_ref=rv)
             t1 = time.perf_counter()
             solvers.solve_ref_as_configured(prob, ref_now[lo:hi], None, last[lo:hi], **kw_c)
