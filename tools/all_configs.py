@@ -20,6 +20,7 @@ from oracle import cases  # noqa: E402  (input recipes only)
 
 RetargetingConfig.set_default_urdf_dir(str(DEFAULT_URDF_DIR))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 else None  # substrings of config paths to run
 dev = torch.device("cuda:0")
 kp = cases.human_keypoints(B + 1, seed=cases.SEED)
 t_kp = torch.from_numpy(np.ascontiguousarray(kp[1:])).to(dev)
@@ -28,6 +29,8 @@ print(f"# {B} frames per launch, one MI355X; dq = max_j |q_f32 - q_f64| per fram
 print(f"{'config':44s} {'n_opt':>5s} {'comps':>5s} {'ms':>8s} {'Mframes/s':>9s} {'it mean':>7s} {'it max':>6s} {'conv':>6s} {'p99.9 dq':>9s} {'>1e-4':>6s}")
 for path in sorted(glob.glob(os.path.join(cases.CONFIG_DIR, "*", "*.yml"))):
     rel = os.path.relpath(path, cases.CONFIG_DIR)
+    if ONLY is not None and not any(o in rel for o in ONLY):
+        continue
     prob = cases.problem_from_config(rel)
     seq = RetargetingConfig.load_from_file(path).build()
     model = seq.optimizer.device_model()
