@@ -77,17 +77,14 @@ template <typename real> struct RealTraits;
 template <> struct RealTraits<float> {
   static __device__ __forceinline__ float rsqrt(float v) { return __frsqrt_rn(v); }
   static __device__ __forceinline__ float sqrt(float v) { return __fsqrt_rn(v); }
-  // sin/cos for joint angles (|a| <~ 1e3 rad): 3-term Cody-Waite reduction by pi/2 + degree-7/8 minimax
-  // polynomials on [-pi/4, pi/4]; ~1 ulp, no scratch, no slow path (ocml's sincosf carries a Payne-Hanek
-  // fallback that costs ~100 VGPRs and private memory inside this kernel).
+  // sin/cos for joint angles (|a| <~ 1e3 rad): 2-term Cody-Waite reduction by pi/2 (the third term, 5.4e-15 k, is
+  // below float32 resolution of the reduced argument here) + degree-7/8 minimax polynomials on [-pi/4, pi/4]; ~1 ulp,
+  // no scratch, no slow path (ocml's sincosf carries a Payne-Hanek fallback that costs ~100 VGPRs and private memory
+  // inside this kernel).
   static __device__ __forceinline__ void sincos(float a, float* s, float* c) {
-#ifdef DEXR_EXP_FASTSINCOS
-    *s = __sinf(a); *c = __cosf(a); return;
-#endif
     const float kf = rintf(a * 0.63661977236758134f);
     float r = fmaf(-kf, 1.5707962513e+00f, a);
     r = fmaf(-kf, 7.5497894159e-08f, r);
-    r = fmaf(-kf, 5.3903029534e-15f, r);
     const float z = r * r;
     const float sp = r + r * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
     const float cp = 1.0f - 0.5f * z + z * z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
