@@ -267,6 +267,27 @@ def test_ragged_batches(B):
     assert np.array_equal(q, full[:B])  # an item's answer does not depend on its neighbours
 
 
+@pytest.mark.parametrize("rel", ["teleop/shadow_hand_right_dexpilot.yml", "offline/leap_hand_right.yml",
+                                 "offline/ability_hand_right.yml", "teleop/allegro_hand_right_dexpilot.yml"])
+def test_ragged_batches_large_component_kernels(rel):
+    """Tile edges of the quad kernel (16 frames per wave), the LDS kernel and the register kernel (64): any prefix of
+    a batch gives the same answers as the whole batch, down to single frames and the empty batch."""
+    seq, prob = build(rel)
+    model = seq.optimizer.device_model()
+    n = 200
+    d = cases.human_set(prob, n, seed=21, sigma=0.05)
+    dex = prob.kind == "dexpilot"
+    s_full = np.zeros(n, np.uint32) if dex else None
+    full = model.retarget(d["ref"], d["fixed"], d["last"], state=s_full)
+    for B in (0, 1, 3, 15, 16, 17, 63, 64, 65, 129):
+        st = np.zeros(B, np.uint32) if dex else None
+        q = model.retarget(d["ref"][:B], d["fixed"][:B], d["last"][:B], state=st)
+        assert q.shape == (B, prob.n_opt)
+        assert np.array_equal(q, full[:B]), B
+        if dex:
+            assert np.array_equal(st, s_full[:B]), B
+
+
 def test_full_size_batch_properties():
     """BASELINE.json config[1] size (65 536): bitwise determinism, permutation equivariance, sub-batch
     consistency, bounds, and the round-trip property on reachable targets."""
