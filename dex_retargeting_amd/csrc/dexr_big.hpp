@@ -62,9 +62,11 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
   const float delta = kp.norm_delta;
 
   uint32_t vmask = 0, optmask = 0;
+  uint32_t revmask = 0;  // revolute joints: a wave-uniform bit mask, so the loops below test a bit instead of loading jtype
 #pragma unroll
   for (int k = 0; k < NMAX; ++k) {
     if (k < nj) {
+      if (tb.jtype[k] == DEXR_JOINT_REVOLUTE) revmask |= 1u << k;
       const int sk = tb.src_kind[k];
       if (sk == DEXR_SRC_OPT) { vmask |= 1u << k; optmask |= 1u << k; }
       else if (sk == DEXR_SRC_MIMIC) vmask |= 1u << k;
@@ -226,7 +228,7 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
           x[k] = qf;
         }
         const double q = (double)qf;
-        if (tb.jtype[k] == DEXR_JOINT_REVOLUTE) {
+        if ((revmask >> k) & 1u) {
           double s, c;
           sincos_f64(q, &s, &c);
 #pragma unroll
@@ -242,7 +244,7 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
 #pragma unroll
           for (int i = 0; i < 3; ++i) p[i] += q * Rn[3 * i + 2];
         }
-        if (!c0_set && tb.jtype[k] == DEXR_JOINT_REVOLUTE) {
+        if (!c0_set && ((revmask >> k) & 1u)) {
           c0_set = true;
 #pragma unroll
           for (int i = 0; i < 3; ++i) c0[i] = p[i];
@@ -350,7 +352,7 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
       for (int k = 0; k < NMAX; ++k) {
         if ((mu >> k) & 1u) {
           const bool in_t = (mt >> k) & 1u, in_o = (mo >> k) & 1u;
-          if (tb.jtype[k] == DEXR_JOINT_REVOLUTE) {
+          if ((revmask >> k) & 1u) {
             float v[3] = {0, 0, 0};
             if (in_t) {
 #pragma unroll
@@ -391,7 +393,7 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
           for (int cc = 0; cc <= rr; ++cc) {
             float h = cw0 * col[cc][0] + cw1 * col[cc][1] + cw2 * col[cc][2];
             const bool same = (((mt >> cc) & (mt >> rr)) | ((mo >> cc) & (mo >> rr))) & 1u;
-            if (newton && same && ((mu >> cc) & 1u) && tb.jtype[cc] == DEXR_JOINT_REVOLUTE)
+            if (newton && same && ((mu >> cc) & 1u) && ((revmask >> cc) & 1u))
               h += ax[cc][0] * cf0 + ax[cc][1] * cf1 + ax[cc][2] * cf2;
             hrow[cc] += h;
           }

@@ -152,6 +152,7 @@ struct LaneSolver {
   static constexpr int NH = NMAX * (NMAX + 1) / 2;
   using RT = RealTraits<real>;
 
+  uint32_t revmask = ~0u;  // wave-uniform: bit k set = joint k is revolute (set by the kernel; saves the jtype loads)
   // ---- per-lane register state ---------------------------------------------------------------------------
   real x[NMAX];      // joint values of every local joint (optimised, fixed-valued and mimic alike)
   real xl[NMAX];     // regularisation target (last_qpos) for optimised joints
@@ -224,7 +225,7 @@ struct LaneSolver {
             q = (real)tb.mult[k] * pick(x, tb.src_idx[k]) + (real)tb.off[k];
             x[k] = q;
           }
-          revolute = tb.jtype[k] == DEXR_JOINT_REVOLUTE;
+          revolute = (revmask >> k) & 1u;
         }
         if (revolute) {
           real s, c;
@@ -355,7 +356,7 @@ struct LaneSolver {
           if ((mu >> k) & 1u) {
             const bool in_t = (mt >> k) & 1u, in_o = (mo >> k) & 1u;
             bool revolute = true;
-            if constexpr (!CHAIN) revolute = tb.jtype[k] == DEXR_JOINT_REVOLUTE;
+            if constexpr (!CHAIN) revolute = (revmask >> k) & 1u;
             if (revolute) {
               real v[3] = {0, 0, 0};
               if (in_t) {
@@ -397,7 +398,7 @@ struct LaneSolver {
                   real h = cw0 * col[cc][0] + cw1 * col[cc][1] + cw2 * col[cc][2] - ku * u[cc];
                   const bool same = (((mt >> cc) & (mt >> rr)) | ((mo >> cc) & (mo >> rr))) & 1u;
                   bool rev_c = true;
-                  if constexpr (!CHAIN) rev_c = tb.jtype[cc] == DEXR_JOINT_REVOLUTE;
+                  if constexpr (!CHAIN) rev_c = (revmask >> cc) & 1u;
                   if (newton && same && rev_c)
                     h += ax[cc][0] * cf0 + ax[cc][1] * cf1 + ax[cc][2] * cf2;
                   H[hidx(rr, cc)] += h;
@@ -552,6 +553,13 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
 
   LS S;
   uint32_t vmask = 0;   // joints that carry an optimisation variable (directly or as a mimic)
+  if constexpr (!CHAIN) {
+    uint32_t rm = 0;
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k)
+      if (k < nj && tb.jtype[k] == DEXR_JOINT_REVOLUTE) rm |= 1u << k;
+    S.revmask = rm;
+  }
   uint32_t optmask = 0; // joints that ARE an optimisation variable
 #pragma unroll
   for (int k = 0; k < NMAX; ++k) {

@@ -69,9 +69,12 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
   const float delta = kp.norm_delta;
 
   uint32_t optmask = 0;
+  uint32_t revmask = 0;  // revolute joints: a wave-uniform bit mask, so the loops below test a bit instead of loading jtype
 #pragma unroll
-  for (int k = 0; k < NMAX; ++k)
+  for (int k = 0; k < NMAX; ++k) {
     if (k < nj && tb.src_kind[k] == DEXR_SRC_OPT) optmask |= 1u << k;
+    if (k < nj && tb.jtype[k] == DEXR_JOINT_REVOLUTE) revmask |= 1u << k;
+  }
 
   // ---- per-lane state: replicated vectors + this lane's Hessian rows ------------------------------------------
   float x[NMAX], xo[NMAX], g[NMAX], d[NMAX];
@@ -201,7 +204,7 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
           for (int j = 0; j < 3; ++j)
             Rn[3 * i + j] = R[3 * i] * (double)Xk[j] + R[3 * i + 1] * (double)Xk[3 + j] + R[3 * i + 2] * (double)Xk[6 + j];
         const double q = (double)x[k];
-        if (tb.jtype[k] == DEXR_JOINT_REVOLUTE) {
+        if ((revmask >> k) & 1u) {
           double s, c;
           sincos_f64(q, &s, &c);
 #pragma unroll
@@ -302,7 +305,7 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
       for (int k = 0; k < NMAX; ++k) {
         if ((mu >> k) & 1u) {
           const bool in_t = (mt >> k) & 1u, in_o = (mo >> k) & 1u;
-          if (tb.jtype[k] == DEXR_JOINT_REVOLUTE) {
+          if ((revmask >> k) & 1u) {
             float v[3] = {0, 0, 0};
             const float o0 = OGl[(k * 3 + 0) * 64], o1 = OGl[(k * 3 + 1) * 64], o2 = OGl[(k * 3 + 2) * 64];
             if (in_t) { v[0] += pt[0] - o0; v[1] += pt[1] - o1; v[2] += pt[2] - o2; }
@@ -337,7 +340,7 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
           for (int c = 0; c < 4 * i + 4; ++c) {
             if ((mu >> c) & 1u) {
               float h = cw0 * col[c][0] + cw1 * col[c][1] + cw2 * col[c][2];
-              if (newton && tb.jtype[c] == DEXR_JOINT_REVOLUTE) {
+              if (newton && ((revmask >> c) & 1u)) {
                 const uint32_t same = (rt & ((mt >> c) & 1u)) | (ro & ((mo >> c) & 1u));
                 const float nt2 = ax[c][0] * cf0 + ax[c][1] * cf1 + ax[c][2] * cf2;
                 h += same ? nt2 : 0.f;
