@@ -323,7 +323,7 @@ def main():
     # ---- parity on a subset (oracle = checker only) ------------------------------------------------------------
     from oracle import solvers
 
-    n_par = 512
+    n_par = 4096 if args.workload == "allegro_vector" else 512  # 4 096-item subset on the headline
     kw = {}
     if dexpilot:  # same incoming projection state as the timed launches: the bits the previous frame left behind
         proj0 = ((st0[:n_par, None] >> np.arange(prob.n_pair, dtype=np.uint32)) & 1).astype(bool)
