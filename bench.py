@@ -219,19 +219,27 @@ def main():
     t_iters = torch.zeros(B, dtype=torch.int32, device=dev)
     t_status = torch.zeros(B, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream()
-    # N > 1: one RCCL all-gather of this rank's (B, n_opt) result per step, overlapped with the NEXT step's solve
-    # (two rotating buffer pairs; every gather has completed when the timed region ends)
+    # N > 1: one RCCL all-gather of this rank's (B, n_opt) result per step, overlapped with the following steps' solves
+    # (rotating buffer pairs; every gather has completed when the timed region ends)
     pipe = None
     if dist is not None:
         from dex_retargeting_amd.distributed import PipelinedAllGather
 
-        pipe = PipelinedAllGather(B, n_opt, torch.float32, dev, depth=2)
-    n_step = [0]
+        # one buffer pair per step (4 MB shard + world x 4 MB gathered; HBM is 288 GB): the compute stream then never
+        # has to wait for an earlier gather before reusing a buffer -- cross-stream event waits cost ~15 us each on the
+        # command processor -- and the gathers simply trail the solves on RCCL's stream
+        # ... and four steps share one collective: issuing an async collective costs the host ~100 us in
+        # torch.distributed, more than a solve takes; 4 x 4 MB per rank is still a small message for xGMI
+        G = int(os.environ.get("DEXR_BENCH_GATHER_EVERY", "4"))
+        pipe = PipelinedAllGather(B, n_opt, torch.float32, dev, depth=min(16, (args.steps + args.warmup) // G + 3),
+                                  steps_per_gather=G)
+    n_step, out_last = [0], [None]
 
     def step(record=None, diagnostics=False):
         if dexpilot:
             t_state.copy_(t_state0)
         out = t_q if pipe is None else pipe.shard(n_step[0])
+        out_last[0] = out
         if record is not None:
             record[0].record(stream)
         model.retarget_dev(B, t_ref.data_ptr(), 0, t_last.data_ptr(), t_state.data_ptr() if dexpilot else 0,
@@ -248,8 +256,9 @@ def main():
         step()
     step(diagnostics=True)  # untimed: iteration counts / status of this workload
     if pipe is not None:
-        t_q.copy_(pipe.shard(n_step[0] - 1))
+        t_q.copy_(out_last[0])
         pipe.finish()
+        n_step[0] = 0  # the timed steps start a fresh group
     torch.cuda.synchronize()
     iters_mean = float(t_iters.float().mean())
     iters_max = int(t_iters.max())
@@ -301,7 +310,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{wl_name}, {B} frames/GPU, human-keypoint refs (fixture frame b mod 621 + 2 mm noise), "
                                f"warm start = previous frame's solution", "config_file": rel, "batch_per_gpu": B,
-                   "n_opt": n_opt, "n_ref": n_ref, "collective": "rccl all_gather of qpos, overlapped with the next step's solve" if dist is not None else "none"},
+                   "n_opt": n_opt, "n_ref": n_ref, "collective": "rccl all_gather of qpos (one per 4 steps, 4 x B rows per rank), overlapped with the following solves" if dist is not None else "none"},
         "solver": {"iters_mean": iters_mean, "iters_max": iters_max, "converged_frac": n_conv / B,
                    "tol_rad": 2e-6, "newton": 1},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -71,59 +71,82 @@ class ShardedRetargeter:
 
 
 class PipelinedAllGather:
-    """All-gather of step k overlapped with the solve of step k+1 (RCCL runs on its own stream; xGMI is
-    point-to-point, so at 8 GPUs the gather of a 4 MB shard costs about as much as the solve it follows).
+    """All-gathers of per-step results overlapped with the following solves (RCCL runs on its own stream; xGMI is
+    point-to-point, so at 8 GPUs the gather of a 4 MB shard costs about as much as the solve it follows), and
+    batched: ``group`` consecutive steps share ONE collective (fewer, larger collectives -- issuing an async
+    collective costs the host ~100 us in torch.distributed, more than one solve takes).
 
-    ``depth`` shard / full buffer pairs rotate.  Per step::
+    ``depth`` buffer pairs rotate; a pair holds ``group`` steps.  Per step::
 
-        out = pg.shard(k)      # (per, n) tensor for this rank's result of step k; first waits until the gather that
-                               # last read this buffer (step k - depth) is complete
+        out = pg.shard(k)      # (per, n) tensor for this rank's result of step k; when step k opens a buffer pair it
+                               # first waits until the gather that last read that pair is complete
         ... enqueue the solve that writes `out` on the current stream ...
-        pg.gather(k)           # enqueue all_gather(full[k % depth], out), asynchronously
+        pg.gather(k)           # after the last step of a group: enqueue all_gather(full, shards), asynchronously
 
-    and ``pg.finish()`` at the end waits for every outstanding gather and returns the last full tensor.  With
-    "nccl" (= RCCL) ``wait()`` only orders the current stream after the collective; with "gloo" it blocks the host.
-    ``on_full(k, tensor)`` -- optional -- is called as soon as step k's gather is known complete.
+    and ``pg.finish()`` gathers a partly filled last group, waits for every outstanding gather and returns the last
+    full tensor, shaped (world, group, per, n).  With "nccl" (= RCCL) ``wait()`` only orders the current stream after
+    the collective; with "gloo" it blocks the host.  ``on_full(first_step, tensor, n_steps)`` -- optional -- is called
+    as soon as a group's gather is known complete.
     """
 
-    def __init__(self, per: int, n: int, dtype=None, device="cpu", depth: int = 2, group=None, on_full=None):
+    def __init__(self, per: int, n: int, dtype=None, device="cpu", depth: int = 2, group=None, on_full=None,
+                 steps_per_gather: int = 1):
         import torch
         import torch.distributed as dist
 
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
-        if depth < 1:
-            raise ValueError("depth must be >= 1")
-        self.dist, self.group, self.depth, self.on_full = dist, group, depth, on_full
+        if depth < 1 or steps_per_gather < 1:
+            raise ValueError("depth and steps_per_gather must be >= 1")
+        self.dist, self.group, self.depth, self.on_full, self.G = dist, group, depth, on_full, steps_per_gather
         self.world = dist.get_world_size(group)
         dtype = dtype or torch.float32
-        self._shard = [torch.zeros((per, n), dtype=dtype, device=device) for _ in range(depth)]
-        self._full = [torch.empty((self.world * per, n), dtype=dtype, device=device) for _ in range(depth)]
-        self._work = [None] * depth  # (step, Work) of the gather in flight on each buffer pair
+        self._shard = [torch.zeros((self.G, per, n), dtype=dtype, device=device) for _ in range(depth)]
+        self._full = [torch.empty((self.world, self.G, per, n), dtype=dtype, device=device) for _ in range(depth)]
+        self._work = [None] * depth  # (first step, Work, steps) of the gather in flight on each buffer pair
+        self._open = None            # (slot, first step, steps written) of the group being filled
         self._last = None
 
     def _retire(self, slot: int):
         if self._work[slot] is not None:
-            k, w = self._work[slot]
+            k0, w, cnt = self._work[slot]
             w.wait()
             self._work[slot] = None
             if self.on_full is not None:
-                self.on_full(k, self._full[slot])
+                self.on_full(k0, self._full[slot], cnt)
+
+    def _issue(self):
+        slot, k0, cnt = self._open
+        per, n = self._shard[slot].shape[1:]
+        w = self.dist.all_gather_into_tensor(self._full[slot].view(self.world * self.G * per, n),
+                                             self._shard[slot].view(self.G * per, n), group=self.group, async_op=True)
+        self._work[slot] = (k0, w, cnt)
+        self._last = slot
+        self._open = None
 
     def shard(self, k: int):
-        slot = k % self.depth
-        self._retire(slot)
-        return self._shard[slot]
+        slot, g = (k // self.G) % self.depth, k % self.G
+        if self._open is None:
+            if g != 0:
+                raise RuntimeError(f"step {k} does not start a group of {self.G}")
+            self._retire(slot)
+            self._open = (slot, k, 0)
+        elif self._open[0] != slot or self._open[1] + self._open[2] != k:
+            raise RuntimeError(f"step {k} out of order")
+        return self._shard[slot][g]
 
     def gather(self, k: int):
-        slot = k % self.depth
-        if self._work[slot] is not None:
-            raise RuntimeError(f"step {k}: buffer {slot} still has a gather in flight (call shard(k) first)")
-        w = self.dist.all_gather_into_tensor(self._full[slot], self._shard[slot], group=self.group, async_op=True)
-        self._work[slot] = (k, w)
-        self._last = slot
+        if self._open is None or self._open[1] + self._open[2] != k:
+            raise RuntimeError(f"step {k}: call shard(k) first (each step once, in order)")
+        slot, k0, cnt = self._open
+        self._open = (slot, k0, cnt + 1)
+        if cnt + 1 == self.G:
+            self._issue()
 
     def finish(self):
+        if self._open is not None and self._open[2] > 0:
+            self._issue()  # partly filled last group: the unused rows travel too
+        self._open = None
         order = sorted((kw[0], s) for s, kw in enumerate(self._work) if kw is not None)
         for _, slot in order:
             self._retire(slot)

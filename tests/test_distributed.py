@@ -66,7 +66,7 @@ def test_two_rank_gloo_allgather_equals_single_process(tmp_path, B):
         assert np.array_equal(got["state"], st)
 
 
-def _pipe_worker(rank, world, port, out_dir):
+def _pipe_worker(rank, world, port, out_dir, G):
     import torch
     import torch.distributed as dist
 
@@ -77,21 +77,29 @@ def _pipe_worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     per, n, steps = 5, 3, 7
     seen = {}
-    pg = PipelinedAllGather(per, n, torch.float32, "cpu", depth=2, on_full=lambda k, t: seen.__setitem__(k, t.clone()))
+
+    def on_full(k0, t, cnt):
+        for g in range(cnt):
+            seen[k0 + g] = t[:, g].clone()  # (world, per, n) of step k0 + g
+
+    pg = PipelinedAllGather(per, n, torch.float32, "cpu", depth=2, on_full=on_full, steps_per_gather=G)
     for k in range(steps):
         out = pg.shard(k)
         out.copy_(torch.full((per, n), float(100 * k + rank)))  # the "solve" of step k on this rank
         pg.gather(k)
         with pytest.raises(RuntimeError):
-            pg.gather(k)  # same buffer, gather still in flight
+            pg.gather(k)  # each step once
     last = pg.finish()
     assert sorted(seen) == list(range(steps))
-    torch.save({"seen": seen, "last": last.clone()}, os.path.join(out_dir, f"p{rank}.pt"))
+    assert tuple(last.shape) == (world, G, per, n)
+    torch.save({"seen": seen}, os.path.join(out_dir, f"p{rank}.pt"))
     dist.destroy_process_group()
 
 
-def test_pipelined_all_gather_two_ranks_gloo(tmp_path):
-    """Every step's gathered tensor holds rank r's shard in slot r, in step order, although buffers rotate."""
+@pytest.mark.parametrize("G", [1, 3])
+def test_pipelined_all_gather_two_ranks_gloo(tmp_path, G):
+    """Every step's gathered tensor holds rank r's shard in slot r, in step order, although buffers rotate and (G = 3)
+    three steps share one collective, the last group being only partly filled."""
     import torch
     import torch.multiprocessing as mp
 
@@ -99,10 +107,9 @@ def test_pipelined_all_gather_two_ranks_gloo(tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_pipe_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_pipe_worker, args=(2, port, str(tmp_path), G), nprocs=2, join=True)
     for rank in range(2):
         d = torch.load(os.path.join(str(tmp_path), f"p{rank}.pt"))
         for k, t in d["seen"].items():
-            want = torch.cat([torch.full((5, 3), float(100 * k + r)) for r in range(2)])
+            want = torch.stack([torch.full((5, 3), float(100 * k + r)) for r in range(2)])
             assert torch.equal(t, want), (rank, k)
-        assert torch.equal(d["last"], d["seen"][6])
