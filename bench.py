@@ -49,26 +49,25 @@ def run_mixed_fleet(args):
     (dex_retargeting_amd/fleet.py).  Single-rank only; the 8-GPU run of this config shards the batch like the others."""
     import torch
 
+    import bench_data
     from dex_retargeting_amd.constants import DEFAULT_URDF_DIR
     from dex_retargeting_amd.fleet import MixedFleet
     from dex_retargeting_amd.retargeting_config import RetargetingConfig
-    from oracle import cases, solvers
 
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     RetargetingConfig.set_default_urdf_dir(str(DEFAULT_URDF_DIR))
-    seqs = [RetargetingConfig.load_from_file(os.path.join(cases.CONFIG_DIR, r)).build() for r in FLEET]
-    probs = [cases.problem_from_config(r) for r in FLEET]
+    seqs = [RetargetingConfig.load_from_file(os.path.join(bench_data.CONFIG_DIR, r)).build() for r in FLEET]
     fleet = MixedFleet([q.optimizer for q in seqs])
     B = args.batch
-    rng = np.random.default_rng(cases.SEED)
+    rng = np.random.default_rng(bench_data.SEED)
     mid = rng.integers(0, len(FLEET), B)
-    kp = cases.human_keypoints(B + 1, seed=cases.SEED)
+    kp = bench_data.human_keypoints(B + 1, seed=bench_data.SEED)
     t_mid = torch.from_numpy(mid).to(dev)
     t_prev, t_now = torch.from_numpy(np.ascontiguousarray(kp[:-1])).to(dev), torch.from_numpy(np.ascontiguousarray(kp[1:])).to(dev)
     start = np.zeros((B, fleet.n_max), np.float32)
-    for m, pr in enumerate(probs):
-        start[mid == m, : pr.n_opt] = pr.joint_limits.mean(1).astype(np.float32)
+    for m, sq in enumerate(seqs):
+        start[mid == m, : sq.optimizer.opt_dof] = sq.joint_limits.mean(1).astype(np.float32)
     t_state = torch.zeros(B, dtype=torch.int32, device=dev)
     t_last = fleet.retarget(t_mid, t_prev, torch.from_numpy(start).to(dev), t_state)  # untimed warm start
     t_state0 = t_state.clone()
@@ -95,6 +94,10 @@ def run_mixed_fleet(args):
     st_in = t_state0.cpu().numpy().astype(np.uint32)
     bpf = 21 * 12 + 2 * 4 * fleet.n_max + 4 + 8  # keypoints + padded last/qpos rows + model id + DexPilot state in/out
     achieved = B * bpf / (step_ms * 1e-3) / 1e9
+    # ---- checker (oracle) and CPU baseline: only from here on ----------------------------------------------------
+    from oracle import cases, solvers
+
+    probs = [cases.problem_from_config(r) for r in FLEET]
     parity, cpu_t, cpu_n = {}, 0.0, 0
     for m, (rel, pr) in enumerate(zip(FLEET, probs)):
         idx = np.nonzero(mid == m)[0][:128]
@@ -186,28 +189,24 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from dex_retargeting_amd import _lib
+    import bench_data  # seeded synthetic inputs (no oracle code before the checker sections at the end)
     from dex_retargeting_amd.constants import DEFAULT_URDF_DIR
     from dex_retargeting_amd.retargeting_config import RetargetingConfig
-    from oracle import cases  # input recipes only (seeded synthetic data); the solve below is the HIP path
 
     RetargetingConfig.set_default_urdf_dir(str(DEFAULT_URDF_DIR))
     rel, wl_name = WORKLOADS[args.workload]
-    seq = RetargetingConfig.load_from_file(os.path.join(cases.CONFIG_DIR, rel)).build()
+    seq = RetargetingConfig.load_from_file(os.path.join(bench_data.CONFIG_DIR, rel)).build()
     opt = seq.optimizer
     model = opt.device_model()
-    prob = cases.problem_from_config(rel)
     B = args.batch
-    n_opt, n_ref = prob.n_opt, prob.n_ref
-    dexpilot = prob.kind == "dexpilot"
+    n_opt, n_ref = opt.opt_dof, int(opt.compiled_model().header["n_ref"])
+    dexpilot = opt.retargeting_type == "DEXPILOT"
 
     # ---- synthetic inputs, resident in HBM ------------------------------------------------------------------
-    seed = cases.SEED + 1000 * rank
-    kp = cases.human_keypoints(B + 1, seed=seed)  # (B+1, 21, 3) float32
-    ref_all = cases.ref_from_keypoints(prob, kp).astype(np.float32)
-    ref_now = ref_all[1:]
+    seed = bench_data.SEED + 1000 * rank
+    kp = bench_data.human_keypoints(B + 1, seed=seed)  # (B+1, 21, 3) float32
     kp_prev, kp_now = np.ascontiguousarray(kp[:-1]), np.ascontiguousarray(kp[1:])
-    mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
+    mid = np.repeat(seq.joint_limits.mean(1)[None], B, 0).astype(np.float32)
     st0 = np.zeros(B, np.uint32) if dexpilot else None
     # untimed: the previous frame's solution = the warm start a running sequence would carry
     last = model.retarget(kp_prev, None, mid, state=st0, keypoints=True)
@@ -329,8 +328,12 @@ def main():
                              "fraction is reported as north_star asks, see DESIGN.md section 4"},
     }
 
-    # ---- parity on a subset (oracle = checker only) ------------------------------------------------------------
-    from oracle import solvers
+    # ---- parity on a subset (oracle = checker only; nothing above this line touches oracle/) ---------------------
+    from oracle import cases, solvers
+
+    prob = cases.problem_from_config(rel)
+    assert (prob.n_opt, prob.n_ref) == (n_opt, n_ref)
+    ref_now = cases.ref_from_keypoints(prob, kp).astype(np.float32)[1:]
 
     n_par = 4096 if args.workload == "allegro_vector" else 512  # 4 096-item subset on the headline
     kw = {}

@@ -89,14 +89,15 @@ def reachable_set(prob: OracleProblem, B: int, sigma: float, seed: int = SEED, d
 
 
 def human_keypoints(B: int, seed: int = SEED, noise: float = 2e-3) -> np.ndarray:
-    """(B,21,3) f32: fixture frame b mod 621 + N(0, 2 mm)."""
-    kp = np.load(HUMAN_FIXTURE)
-    rng = np.random.default_rng(seed + 1)
-    out = kp[np.arange(B) % kp.shape[0]].astype(np.float64)
-    if noise > 0:
-        out = out + noise * rng.standard_normal(out.shape)
-        out[:, 0] = 0.0
-    return out.astype(np.float32)
+    """(B,21,3) f32: fixture frame b mod 621 + N(0, 2 mm).  One definition, shared with the
+    measurement harness (bench_data.py) so that tests and bench feed identical frames."""
+    import sys
+
+    if REPO not in sys.path:
+        sys.path.insert(0, REPO)
+    import bench_data
+
+    return bench_data.human_keypoints(B, seed, noise)
 
 
 def ref_from_keypoints(prob: OracleProblem, kp: np.ndarray) -> np.ndarray:
