@@ -224,11 +224,10 @@ def main():
     if dist is not None:
         from dex_retargeting_amd.distributed import PipelinedAllGather
 
-        # one buffer pair per step (4 MB shard + world x 4 MB gathered; HBM is 288 GB): the compute stream then never
-        # has to wait for an earlier gather before reusing a buffer -- cross-stream event waits cost ~15 us each on the
-        # command processor -- and the gathers simply trail the solves on RCCL's stream
-        # ... and four steps share one collective: issuing an async collective costs the host ~100 us in
-        # torch.distributed, more than a solve takes; 4 x 4 MB per rank is still a small message for xGMI
+        # four steps share one collective (issuing an async collective costs the host ~100 us in torch.distributed,
+        # more than a solve takes; 4 x 4 MB per rank is still a small message for xGMI), and there are enough buffer
+        # pairs (HBM is 288 GB) that the compute stream hardly ever has to wait for an earlier gather before reusing
+        # one: the gathers simply trail the solves on RCCL's stream
         G = int(os.environ.get("DEXR_BENCH_GATHER_EVERY", "4"))
         pipe = PipelinedAllGather(B, n_opt, torch.float32, dev, depth=min(16, (args.steps + args.warmup) // G + 3),
                                   steps_per_gather=G)
