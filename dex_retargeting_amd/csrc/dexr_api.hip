@@ -139,7 +139,7 @@ int launch_big(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
 }
 
 int launch_quad(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
-  const size_t per_wave = (size_t)64 * (8 * 3 * (size_t)m->lds_frames + 4 * 3 * (size_t)m->bucket);
+  const size_t per_wave = (size_t)64 * (8 * 3 * (size_t)m->lds_frames + 4 * 3 * (size_t)m->bucket + 4 * (size_t)m->bucket);
   int wpb = 4;
   while (wpb > 1 && per_wave * wpb > 150 * 1024) wpb >>= 1;
   // persistent quads: at most one wave per SIMD is resident (the kernel needs the whole register file); each starts with

@@ -32,8 +32,9 @@ static __device__ __forceinline__ float sel4(int p, float a0, float a1, float a2
   return (p & 2) ? hi : lo;
 }
 
-// blockDim.x = 256 (4 waves x 16 frames); dynamic LDS per wave = 64 * (8 * 3 * lds_frames + 4 * 3 * NMAX) bytes:
-// float64 frame positions + float32 joint origins, [row][lane] (the 4 lanes of a quad hold copies).  Per-term targets
+// blockDim.x = 256 (4 waves x 16 frames); dynamic LDS per wave = 64 * (8 * 3 * lds_frames + 4 * 3 * NMAX + 4 * NMAX)
+// bytes: float64 frame positions + float32 joint origins + the accepted point, [row][lane] (the 4 lanes of a quad
+// hold copies).  Per-term targets
 // and DexPilot weights are recomputed from ref_value on demand (L1/L2 hits) to keep 4 waves per CU within 160 KB.
 #ifndef DEXR_QUAD_MINW
 #define DEXR_QUAD_MINW 1  // waves per SIMD the register allocation must leave room for
@@ -60,9 +61,12 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
   int64_t item = 0;     // frame this quad is working on
   bool active = false;  // the quad holds a frame (idle quads still execute the passes, on stale data, and store nothing)
 
-  const size_t per_wave = (size_t)64 * (8 * 3 * kp.lds_frames + 4 * 3 * NMAX);
+  const size_t per_wave = (size_t)64 * (8 * 3 * kp.lds_frames + 4 * 3 * NMAX + 4 * NMAX);
   double* Pl = reinterpret_cast<double*>(lds_raw + (size_t)wave_in_block * per_wave) + lane;
   float* OGl = reinterpret_cast<float*>(lds_raw + (size_t)wave_in_block * per_wave + (size_t)64 * 8 * 3 * kp.lds_frames) + lane;
+  // the accepted point (read back only when a trial is rejected): in LDS, the registers it would take are the ones that
+  // otherwise spill to scratch
+  float* XOl = OGl + (size_t)64 * 3 * NMAX;
 
   const dexr_comp_table& tb = comps[comp];
   const int nj = tb.n_joint, nt = tb.n_term;
@@ -77,7 +81,7 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
   }
 
   // ---- per-lane state: replicated vectors + this lane's Hessian rows ------------------------------------------
-  float x[NMAX], xo[NMAX], g[NMAX], d[NMAX];
+  float x[NMAX], g[NMAX], d[NMAX];
   float ax[NMAX][3];  // joint origins live in LDS (OGl): only read once per term and chain joint
   float Hq[NHQ];
 
@@ -536,7 +540,7 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
           if (kp.lam_jump > 0) lam = fmaxf(lam, kp.lam_jump * keff);
           nu *= 2.f;
 #pragma unroll
-          for (int k = 0; k < NMAX; ++k) x[k] = xo[k];
+          for (int k = 0; k < NMAX; ++k) x[k] = XOl[k * 64];
           if (lam > 1e10f) {
             done = true;
             status = finite ? ST_CONVERGED : ST_FALLBACK;
@@ -581,7 +585,7 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
 #pragma unroll
     for (int k = 0; k < NMAX; ++k) {
       if (stepping) {
-        xo[k] = x[k];
+        XOl[k * 64] = x[k];
         if ((freemask >> k) & 1u) {
           const float xt = fminf(fmaxf(x[k] + alpha * d[k], tb.lo[k]), tb.hi[k]);
           smax = fmaxf(smax, fabsf(xt - x[k]));
@@ -605,7 +609,7 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
     if (active && done) {
       if (pending) {  // untested trial point
 #pragma unroll
-        for (int k = 0; k < NMAX; ++k) x[k] = xo[k];
+        for (int k = 0; k < NMAX; ++k) x[k] = XOl[k * 64];
         pending = false;
       }
       bool bad = false;
