@@ -351,13 +351,13 @@ int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out) {
     bool has_mimic = false;
     for (const dexr_comp_table& c : m->comps)
       for (int k = 0; k < c.n_joint; ++k) has_mimic = has_mimic || c.src_kind[k] == DEXR_SRC_MIMIC;
-    // Measured (65 536 frames, tools/cmp_big.py / tools/term_sweep.py): the quad kernel wins for Shadow DexPilot (24
-    // joints, dense: 14.6 ms vs 35.8 ms register + float64 polish) and for position models with free joints (LEAP
-    // 6.7 vs 9.5 ms LDS kernel, Allegro 4.7 vs 6.1 ms); it loses for 16-joint DexPilot hands (8.9 vs 3.1 ms) and
-    // Shadow vector (6.9 vs 3.8 ms, no polish needed): used where it wins, DEXR_FORCE_QUAD=1 selects it for every
-    // eligible model.
+    // Measured (65 536 frames, tools/all_configs.py): with persistent quads the quad kernel wins for every DexPilot
+    // model without mimic joints (Shadow 6.3 ms vs 35.8 ms register + float64 polish; LEAP 3.8-4.4 vs 6.5 ms; Allegro
+    // 2.0-2.3 vs 2.1-2.6 ms) and for position models with free joints (LEAP 3.3 vs 9.5 ms LDS kernel); the register
+    // kernel stays ahead for Shadow vector (1.9-3.0 vs 3.2-3.9 ms).  DEXR_FORCE_QUAD=1 selects it for every eligible
+    // model, DEXR_NO_QUAD=1 for none.
     const bool quad_ok = (m->bucket == 16 || m->bucket == 24) && !has_mimic && max_slot < 1 && h.kind != DEXR_KIND_FKONLY;
-    const bool quad_wins = (m->bucket == 24 && h.kind == DEXR_KIND_DEXPILOT) || h.kind == DEXR_KIND_POSITION;
+    const bool quad_wins = h.kind == DEXR_KIND_DEXPILOT || h.kind == DEXR_KIND_POSITION;
     m->quad = quad_ok && !std::getenv("DEXR_NO_QUAD") && !std::getenv("DEXR_FORCE_BIG") &&
               (quad_wins || std::getenv("DEXR_FORCE_QUAD"));
     const bool wanted = (h.kind == DEXR_KIND_POSITION || m->bucket == 32) ? !std::getenv("DEXR_NO_BIG")
