@@ -20,7 +20,7 @@ class DexrError(RuntimeError):
 
 class SolveOptions(C.Structure):
     _fields_ = [("max_iter", C.c_int32), ("tol", C.c_float), ("lambda0", C.c_float), ("newton", C.c_int32),
-                ("precision", C.c_int32), ("polish", C.c_int32)]
+                ("precision", C.c_int32), ("polish", C.c_int32), ("strict", C.c_int32)]
 
 
 EXPORTS = ["dexr_last_error", "dexr_version", "dexr_device_count", "dexr_default_options", "dexr_model_create",

@@ -246,7 +246,8 @@ void apply_options(dexr::KernelParams& kp, const dexr_solve_options* opt) {
 int polish_launch(const dexr_model* m, dexr::KernelParams kp, const dexr_solve_options* opt, hipStream_t st) {
   int polish = opt ? opt->polish : -1;
   if (polish < 0) polish = (m->h.kind == DEXR_KIND_POSITION || m->h.kind == DEXR_KIND_DEXPILOT) ? 12 : 0;
-  if (polish == 0 || m->bucket == 32 || m->big || m->quad) return DEXR_OK;  // those ran with float64 kinematics
+  if (polish == 0 || m->bucket == 32) return DEXR_OK;
+  if ((m->big || m->quad) && !(opt && opt->strict)) return DEXR_OK;  // those ran with float64 kinematics
   kp.x0 = kp.qout;
   kp.max_iter = polish;
   kp.tol *= 0.25f;
@@ -274,6 +275,7 @@ int dexr_device_count(void) {
 
 void dexr_default_options(dexr_solve_options* opt) {
   if (!opt) return;
+  opt->strict = 0;
   opt->max_iter = 64;
   opt->tol = 2e-6f;
   opt->lambda0 = 1e-4f;

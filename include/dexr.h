@@ -47,6 +47,10 @@ typedef struct dexr_solve_options {
   int32_t polish;     /* float64 polishing iterations run after the float32 solve, started at its answer:
                          -1 auto (default: 12 for position / DexPilot models, whose float32 rounding floor sits
                          near 1e-4 rad; 0 for vector models), 0 off, n > 0 at most n iterations           */
+  int32_t strict;     /* 1: polish also after the mixed-precision kernels (float64 kinematics, float32 gradient and
+                         Hessian) that serve large components.  Their answers sit within 1e-6 rad of the float64
+                         minimiser except in nearly flat valleys of mimic position models, where a 1e-7 gradient
+                         error moves the stationary point by up to 4e-4 rad.  Default 0.      */
 } dexr_solve_options;
 
 const char* dexr_last_error(void);

@@ -548,6 +548,26 @@ def test_raw_keypoints_to_qpos_on_device_equals_host_pipeline():
     assert np.array_equal(got, want)
 
 
+def test_strict_option_polishes_mixed_precision_answers():
+    """Mimic position models run on the LDS kernel (float64 kinematics, float32 gradient): in nearly flat valleys its
+    stationary point sits up to a few 1e-4 rad from the float64 one.  `strict=1` adds the float64 polish launch."""
+    seq, prob = build("offline/ability_hand_right.yml")
+    opt = seq.optimizer
+    B = 8192
+    kp = cases.human_keypoints(B + 1, seed=cases.SEED)
+    ref = np.ascontiguousarray(cases.ref_from_keypoints(prob, kp), dtype=np.float32)
+    mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
+    model = opt.device_model()
+    last = model.retarget(ref[:-1], None, mid)
+    q64 = model.retarget_f64(ref[1:], None, last)
+    dq = {}
+    for strict in (0, 1):
+        q = model.retarget(ref[1:], None, last, opts=_lib.default_options(strict=strict))
+        dq[strict] = np.abs(q.astype(np.float64) - q64).max(1)
+    assert (dq[1] > 1e-4).sum() <= (dq[0] > 1e-4).sum()
+    assert np.percentile(dq[1], 99.9) < 1e-5, np.percentile(dq[1], [99, 99.9, 100])
+
+
 # ---- less common configuration paths ---------------------------------------------------------------------------------
 def _custom(cfg_dict):
     seq = RetargetingConfig.from_dict(dict(cfg_dict)).build()
