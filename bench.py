@@ -233,19 +233,15 @@ def main():
                                   steps_per_gather=G)
     n_step, out_last = [0], [None]
 
-    def step(record=None, diagnostics=False):
+    def step(diagnostics=False):
         if dexpilot:
             t_state.copy_(t_state0)
         out = t_q if pipe is None else pipe.shard(n_step[0])
         out_last[0] = out
-        if record is not None:
-            record[0].record(stream)
         model.retarget_dev(B, t_ref.data_ptr(), 0, t_last.data_ptr(), t_state.data_ptr() if dexpilot else 0,
                            out.data_ptr(), status_ptr=t_status.data_ptr() if diagnostics else 0,
                            iters_ptr=t_iters.data_ptr() if diagnostics else 0, stream=stream.cuda_stream,
                            keypoints=True)
-        if record is not None:
-            record[1].record(stream)
         if pipe is not None:
             pipe.gather(n_step[0])
         n_step[0] += 1
@@ -262,20 +258,24 @@ def main():
     iters_max = int(t_iters.max())
     n_conv = int((t_status == 0).sum())
 
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events bracket the K launches on the stream they are issued on; average launch duration = span / K.  (An event
+    # pair around every single launch puts two extra packets between consecutive kernels and costs ~8 us per step.)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev0.record(stream)
     for k in range(args.steps):
-        step(record=events[k])
+        step()
+    ev1.record(stream)
     if pipe is not None:
         pipe.finish()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    kernel_ms = float(ev0.elapsed_time(ev1)) / args.steps
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
