@@ -41,6 +41,20 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert b"gfx950" in lib.dexr_version()
 
 
+def test_solve_options_struct_matches_header():
+    # the ctypes mirror of dexr_solve_options must list the header's fields in the header's order (all 4-byte)
+    h = open(os.path.join(REPO, "include", "dexr.h")).read()
+    body = re.search(r"typedef struct dexr_solve_options \{(.*?)\} dexr_solve_options;", h, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b(?:int32_t|float)\s+(\w+)\s*;", body)
+    assert fields == [f[0] for f in _lib.SolveOptions._fields_]
+    import ctypes
+
+    assert ctypes.sizeof(_lib.SolveOptions) == 4 * len(fields)
+    o = _lib.default_options()
+    assert (o.max_iter, o.newton, o.precision, o.polish, o.strict) == (64, 1, 0, -1, 0) and abs(o.tol - 2e-6) < 1e-12
+
+
 def test_table_struct_sizes_match_header():
     # numpy dtypes in model_compiler.py must be byte-identical to the C structs in include/dexr_tables.h
     h = open(os.path.join(REPO, "include", "dexr_tables.h")).read()
