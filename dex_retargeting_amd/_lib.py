@@ -23,8 +23,20 @@ class SolveOptions(C.Structure):
                 ("precision", C.c_int32), ("polish", C.c_int32), ("strict", C.c_int32)]
 
 
+class Tuning(C.Structure):
+    """Mirror of dexr_tuning (include/dexr.h): per-model launch / damping parameters."""
+    _fields_ = [("struct_size", C.c_uint32), ("kernel", C.c_int32), ("chain", C.c_int32), ("persist_occ", C.c_int32),
+                ("persist_from", C.c_int32), ("qchunk", C.c_int32), ("resident_waves", C.c_int32),
+                ("max_blind", C.c_int32), ("stall_from", C.c_int32), ("stall_ratio", C.c_float),
+                ("stall_cap", C.c_float), ("lam_jump", C.c_float), ("lam_fastdec", C.c_float),
+                ("floor_scale", C.c_float), ("step_cap", C.c_float), ("blind_tol_scale", C.c_float)]
+
+
+KERNEL_AUTO, KERNEL_REGISTER, KERNEL_QUAD, KERNEL_LDS = -1, 0, 1, 2
+
 EXPORTS = ["dexr_last_error", "dexr_version", "dexr_device_count", "dexr_default_options", "dexr_model_create",
-           "dexr_model_destroy", "dexr_model_info", "dexr_retarget_dev", "dexr_retarget", "dexr_retarget_f64",
+           "dexr_model_destroy", "dexr_model_info", "dexr_model_get_tuning", "dexr_model_set_tuning", "dexr_model_kernel",
+           "dexr_retarget_dev", "dexr_retarget", "dexr_retarget_f64",
            "dexr_retarget_kp_dev", "dexr_retarget_kp", "dexr_eval", "dexr_fk", "dexr_mano_keypoints_dev",
            "dexr_mano_keypoints"]
 
@@ -57,6 +69,9 @@ def load() -> C.CDLL:
     lib.dexr_model_destroy.argtypes = [vp]
     lib.dexr_model_destroy.restype = None
     lib.dexr_model_info.argtypes = [vp, C.c_void_p]
+    lib.dexr_model_get_tuning.argtypes = [vp, C.POINTER(Tuning)]
+    lib.dexr_model_set_tuning.argtypes = [vp, C.POINTER(Tuning)]
+    lib.dexr_model_kernel.argtypes = [vp, i32p, i32p, i32p]
     lib.dexr_retarget_dev.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, optp, vp]
     lib.dexr_retarget.argtypes = [vp, i64, f32p, f32p, f32p, u32p, f32p, i32p, i32p, f32p, optp]
     lib.dexr_retarget_kp_dev.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, optp, vp]
@@ -108,6 +123,29 @@ class Model:
     @property
     def handle(self) -> C.c_void_p:
         return self._h
+
+    # launch / damping parameters of this handle (dexr_tuning) -----------------------------------
+    def get_tuning(self) -> Tuning:
+        t = Tuning()
+        t.struct_size = C.sizeof(Tuning)
+        check(load().dexr_model_get_tuning(self._h, C.byref(t)))
+        return t
+
+    def tune(self, **kw) -> Tuning:
+        """Change fields of the handle's dexr_tuning, e.g. ``model.tune(kernel=KERNEL_REGISTER, persist_from=0)``."""
+        t = self.get_tuning()
+        for k, v in kw.items():
+            if k not in dict(Tuning._fields_):
+                raise AttributeError(f"dexr_tuning has no field {k}")
+            setattr(t, k, v)
+        check(load().dexr_model_set_tuning(self._h, C.byref(t)))
+        return t
+
+    def kernel(self):
+        """(family, bucket, chain) of the float32 solve kernel this handle launches."""
+        f, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        check(load().dexr_model_kernel(self._h, C.byref(f), C.byref(b), C.byref(c)))
+        return int(f.value), int(b.value), bool(c.value)
 
     # host-pointer entry points -------------------------------------------------------------------
     def retarget(self, ref, fixed, last, state=None, opts: Optional[SolveOptions] = None, want_info=False,

@@ -62,6 +62,9 @@ struct dexr_model {
   unsigned* d_queue = nullptr;
   mutable std::atomic<unsigned> qnext{0};
   int n_cu = 256;
+  int max_slot = -1;      // deepest saved-transform slot any component uses
+  bool has_mimic = false;
+  dexr_tuning tune;       // launch / damping parameters (dexr_model_set_tuning); never read from the environment
 };
 
 namespace {
@@ -82,10 +85,10 @@ void fill_params(const dexr_model* m, dexr::KernelParams& kp, int64_t B) {
   // damping dynamics (measured, tools/term_sweep.py): a rejected step raises lambda at least to lam_jump x the mean
   // curvature instead of creeping up by x2, x4, ...; small components also drop it by 10x (not 3x) after a step the
   // model predicted well.  Allegro vector, 65 536 frames: 0.143 -> 0.119 ms; Shadow DexPilot: 19.4 -> 15.4 ms.
-  kp.lam_jump = m->bucket <= 8 ? 1.0f : 0.3f;
-  kp.lam_fastdec = m->bucket <= 8 ? 0.1f : 0.f;
-  kp.floor_scale = 1e-12f;
-  kp.step_cap = 0.3f;
+  kp.lam_jump = m->tune.lam_jump;
+  kp.lam_fastdec = m->tune.lam_fastdec;
+  kp.floor_scale = m->tune.floor_scale;
+  kp.step_cap = m->tune.step_cap;
   kp.blind_tol = 0.f;  // set from the tolerance in apply_options
   kp.n_opt = h.n_opt;
   kp.n_fixed = h.n_fixed;
@@ -121,7 +124,7 @@ int launch_big(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
   int64_t per_cu = (int64_t)((160 * 1024) / (lds > 0 ? lds : 1));
   per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
   int64_t resident = (int64_t)m->n_cu * per_cu;
-  if (const char* e = std::getenv("DEXR_BIG_WAVES")) resident = std::atoll(e) > 0 ? std::atoll(e) : resident;
+  if (m->tune.resident_waves > 0) resident = m->tune.resident_waves;
   int64_t per_comp = (resident + kp.n_comp - 1) / kp.n_comp;
   if (per_comp > tiles) per_comp = tiles;
   const int64_t blocks = per_comp * kp.n_comp;
@@ -146,7 +149,7 @@ int launch_quad(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
   // a static tile of 16 frames, the rest of the batch is handed out through the per-component queue counter
   const int64_t tiles = (kp.B + 15) / 16;  // 16 frames per wave at a time
   int64_t resident = (int64_t)m->n_cu * 4;
-  if (const char* e = std::getenv("DEXR_QUAD_WAVES")) resident = std::atoll(e) > 0 ? std::atoll(e) : resident;
+  if (m->tune.resident_waves > 0) resident = m->tune.resident_waves;
   int64_t per_comp = (resident + kp.n_comp - 1) / kp.n_comp;
   if (per_comp > tiles) per_comp = tiles;
   const int64_t waves = per_comp * kp.n_comp;
@@ -167,8 +170,6 @@ int launch_quad(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
 int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStream_t st) {
   if (kp.B <= 0) return DEXR_OK;
   if (mode == dexr::MODE_SOLVE && !f64 && m->quad) {
-    // the quad kernel scales its damping jump by the curvature along the failed step (not by mean diag H)
-    if (!std::getenv("DEXR_LAM_JUMP")) kp.lam_jump = 1.0f;
     return launch_quad(m, kp, st);
   }
   if (mode == dexr::MODE_SOLVE && !f64 && m->big) return launch_big(m, kp, st);
@@ -183,21 +184,19 @@ int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStr
   if (mode == dexr::MODE_SOLVE && m->bucket <= 8) {
     // persistent lanes (small components): a resident set of waves pulls frames from per-component queues
     int occ = m->chain ? 4 : (m->bucket <= 4 ? 3 : 2);  // waves per SIMD the kernels' register budgets allow
-    if (const char* e = std::getenv("DEXR_PERSIST_OCC")) occ = std::atoi(e) > 0 ? std::atoi(e) : occ;
+    if (m->tune.persist_occ > 0) occ = m->tune.persist_occ;
     const int64_t resident = (int64_t)m->n_cu * 4 * occ;
     const int64_t per_comp = (resident + kp.n_comp - 1) / kp.n_comp;
     // Few frames per lane: one 64-frame tile per wave (no queue).  Many frames per lane: a resident set of waves
     // drains the queue in chunks, which evens out the different iteration counts of individual frames.  Measured
     // (profiles/r01_term_sweep.txt, Allegro vector): tile mode is faster up to 262 144 frames (0.20 vs 0.25 ms), the
     // queue wins at 1 M (0.61 vs 0.67 ms).
-    int64_t persist_from = 8;
-    if (const char* e = std::getenv("DEXR_PERSIST_FROM")) persist_from = std::atoi(e);
+    const int64_t persist_from = m->tune.persist_from;
     kp.qchunk = 0;  // tile mode: no queue traffic at all
     if (tiles >= persist_from * per_comp) {
       waves = per_comp * kp.n_comp;
       kp.q0 = (uint32_t)(per_comp * 64);
-      kp.qchunk = 256;
-      if (const char* e = std::getenv("DEXR_QCHUNK")) kp.qchunk = std::atoi(e) > 0 ? std::atoi(e) : 256;
+      kp.qchunk = m->tune.qchunk > 0 ? (uint32_t)m->tune.qchunk : 256u;
     }
     if (kp.qchunk) {
       const unsigned slot = m->qnext.fetch_add(1u) % dexr_model::QSLOTS;
@@ -215,7 +214,64 @@ int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStr
   return DEXR_OK;
 }
 
-void apply_options(dexr::KernelParams& kp, const dexr_solve_options* opt) {
+// Default launch / damping parameters of a model (measured, tools/term_sweep.py): a rejected step raises lambda at
+// least to lam_jump x the curvature scale instead of creeping up by x2, x4, ...; small components also drop it by 10x
+// (not 3x) after a step the model predicted well.  Allegro vector, 65 536 frames: 0.143 -> 0.119 ms; Shadow DexPilot:
+// 19.4 -> 15.4 ms.
+void default_tuning(dexr_model* m) {
+  dexr_tuning& t = m->tune;
+  std::memset(&t, 0, sizeof(t));
+  t.struct_size = (uint32_t)sizeof(dexr_tuning);
+  t.kernel = DEXR_KERNEL_AUTO;
+  t.chain = 1;
+  t.persist_occ = 0;
+  t.persist_from = 8;
+  t.qchunk = 256;
+  t.resident_waves = 0;
+  t.max_blind = 8;
+  t.stall_from = 2;
+  t.stall_ratio = 0.9f;
+  t.stall_cap = 20.f;
+  t.lam_jump = m->bucket <= 8 ? 1.0f : 0.3f;
+  t.lam_fastdec = m->bucket <= 8 ? 0.1f : 0.f;
+  t.floor_scale = 1e-12f;
+  t.step_cap = 0.3f;
+  t.blind_tol_scale = 10.f;
+}
+
+// Which float32 solve kernel serves the model.  Measured on MI355X (65 536 frames, tools/all_configs.py,
+// tools/cmp_big.py): the LDS kernel wins where the register kernel needs its float64 polish launch on a large
+// component (position models: Inspire 8.7 vs 27 ms, Shadow + free joints 57 vs 170 ms) and loses where it does not
+// (Shadow vector 20 vs 3.8 ms).  With persistent quads the quad kernel wins for every DexPilot model without mimic
+// joints (Shadow 6.3 ms vs 35.8 ms register + float64 polish; LEAP 3.8-4.4 vs 6.5 ms; Allegro 2.0-2.3 vs 2.1-2.6 ms) and
+// for position models with free joints (LEAP 3.3 vs 9.5 ms LDS kernel); the register kernel stays ahead for Shadow
+// vector (1.9-3.0 vs 3.2-3.9 ms).  tune.kernel overrides the policy where the chosen family supports the model.
+void select_kernels(dexr_model* m) {
+  const dexr_model_header& h = m->h;
+  const int want = m->tune.kernel;
+  const size_t lds = (size_t)64 * (4 * (size_t)m->big_nh_rows + 8 * 3 * (size_t)m->lds_frames);
+  // four lanes per frame: dense components of 9..24 joints without mimic joints, one fork level
+  const bool quad_ok = (m->bucket == 16 || m->bucket == 24) && !m->has_mimic && m->max_slot < 1 && h.kind != DEXR_KIND_FKONLY;
+  const bool big_ok = m->bucket >= 16 && h.kind != DEXR_KIND_FKONLY && m->max_slot < 2 && lds <= 160 * 1024;
+  const bool quad_wins = h.kind == DEXR_KIND_DEXPILOT || h.kind == DEXR_KIND_POSITION;
+  const bool big_wins = h.kind == DEXR_KIND_POSITION || m->bucket == 32;
+  m->quad = quad_ok && (want == DEXR_KERNEL_QUAD || (want == DEXR_KERNEL_AUTO && quad_wins));
+  m->big = !m->quad && big_ok && (want == DEXR_KERNEL_LDS || (want == DEXR_KERNEL_AUTO && big_wins));
+  // the quad kernel scales its damping jump by the curvature along the failed step (not by mean diag H)
+  // serial-chain specialisation (LocalTab keeps LF frames / LT terms in registers): every component must be an
+  // unbranched chain of exactly `bucket` revolute optimised joints with at most LF frames and LT terms
+  m->chain = m->tune.chain != 0 && (h.kind == DEXR_KIND_VECTOR || h.kind == DEXR_KIND_POSITION);
+  for (const dexr_comp_table& c : m->comps) {
+    if (c.n_joint != m->bucket || c.n_frame > dexr::LocalTab<4>::LF || c.n_term > dexr::LocalTab<4>::LT) m->chain = false;
+    for (int k = 0; k < c.n_joint && m->chain; ++k)
+      if (c.restore[k] != (k == 0 ? -2 : -1) || c.save[k] != -1 || c.src_kind[k] != DEXR_SRC_OPT ||
+          c.jtype[k] != DEXR_JOINT_REVOLUTE)
+        m->chain = false;
+  }
+  if (m->bucket != 4) m->chain = false;  // only the 4-joint bucket has a chain instantiation
+}
+
+void apply_options(const dexr_model* m, dexr::KernelParams& kp, const dexr_solve_options* opt) {
   dexr_solve_options o;
   dexr_default_options(&o);
   if (opt) o = *opt;
@@ -223,22 +279,11 @@ void apply_options(dexr::KernelParams& kp, const dexr_solve_options* opt) {
   kp.tol = o.tol > 0 ? o.tol : 2e-6f;
   kp.lam0 = o.lambda0 > 0 ? o.lambda0 : 1e-4f;
   kp.newton = o.newton;
-  kp.max_blind = 8;
-  if (const char* e = std::getenv("DEXR_LAM_JUMP")) kp.lam_jump = (float)std::atof(e);
-  if (const char* e = std::getenv("DEXR_LAM_FASTDEC")) kp.lam_fastdec = (float)std::atof(e);
-  if (const char* e = std::getenv("DEXR_FLOOR")) kp.floor_scale = (float)std::atof(e);
-  if (const char* e = std::getenv("DEXR_STEP_CAP")) kp.step_cap = (float)std::atof(e);
-  kp.blind_tol = 10.f * kp.tol;
-  if (const char* e = std::getenv("DEXR_BLIND_TOL")) kp.blind_tol = (float)std::atof(e);
-  kp.stall_from = 2;
-  kp.stall_ratio = 0.9f;
-  kp.stall_cap = 20.f;
-  if (const char* e = std::getenv("DEXR_STALL_FROM")) kp.stall_from = std::atoi(e);
-  if (const char* e = std::getenv("DEXR_STALL_RATIO")) kp.stall_ratio = (float)std::atof(e);
-  if (const char* e = std::getenv("DEXR_STALL_CAP")) kp.stall_cap = (float)std::atof(e);
-  if (const char* e = std::getenv("DEXR_MAX_BLIND")) kp.max_blind = std::atoi(e);  // developer knobs
-  if (const char* e = std::getenv("DEXR_MAX_ITER")) kp.max_iter = std::atoi(e);
-  if (const char* e = std::getenv("DEXR_NEWTON")) kp.newton = std::atoi(e);
+  kp.max_blind = m->tune.max_blind;
+  kp.blind_tol = m->tune.blind_tol_scale * kp.tol;
+  kp.stall_from = m->tune.stall_from;
+  kp.stall_ratio = m->tune.stall_ratio;
+  kp.stall_cap = m->tune.stall_cap;
 }
 
 // Optional float64 polish: same kernel in double precision, started at the float32 answer (x0 = qout, in place),
@@ -339,41 +384,15 @@ int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out) {
     if (c.n_term > m->lds_terms) m->lds_terms = c.n_term;
   }
   m->bucket = pick_bucket(maxj > 0 ? maxj : 1);
-  {
-    int max_slot = -1;
-    for (const dexr_comp_table& c : m->comps)
-      for (int k = 0; k < c.n_joint; ++k) max_slot = c.save[k] > max_slot ? c.save[k] : max_slot;
-    m->big_nh_rows = maxj * (maxj + 1) / 2;
-    const size_t lds = (size_t)64 * (4 * (size_t)m->big_nh_rows + 8 * 3 * (size_t)m->lds_frames);
-    // Measured on MI355X (65 536 frames, tools/cmp_big.py): the LDS kernel wins where the register kernel needs
-    // its float64 polish launch on a large component (position models: LEAP 9.9 vs 22 ms, Inspire 8.7 vs 27 ms,
-    // Shadow+free 57 vs 170 ms) and loses where it does not (Shadow vector 20 vs 3.8 ms) or where the component is
-    // dense and 24 wide (Shadow DexPilot 51 vs 36 ms: 1 wave/CU and a code footprint beyond the instruction cache).
-    // four lanes per frame: dense components of 9..24 joints without mimic joints, one fork level
-    bool has_mimic = false;
-    for (const dexr_comp_table& c : m->comps)
-      for (int k = 0; k < c.n_joint; ++k) has_mimic = has_mimic || c.src_kind[k] == DEXR_SRC_MIMIC;
-    // Measured (65 536 frames, tools/all_configs.py): with persistent quads the quad kernel wins for every DexPilot
-    // model without mimic joints (Shadow 6.3 ms vs 35.8 ms register + float64 polish; LEAP 3.8-4.4 vs 6.5 ms; Allegro
-    // 2.0-2.3 vs 2.1-2.6 ms) and for position models with free joints (LEAP 3.3 vs 9.5 ms LDS kernel); the register
-    // kernel stays ahead for Shadow vector (1.9-3.0 vs 3.2-3.9 ms).  DEXR_FORCE_QUAD=1 selects it for every eligible
-    // model, DEXR_NO_QUAD=1 for none.
-    const bool quad_ok = (m->bucket == 16 || m->bucket == 24) && !has_mimic && max_slot < 1 && h.kind != DEXR_KIND_FKONLY;
-    const bool quad_wins = h.kind == DEXR_KIND_DEXPILOT || h.kind == DEXR_KIND_POSITION;
-    m->quad = quad_ok && !std::getenv("DEXR_NO_QUAD") && !std::getenv("DEXR_FORCE_BIG") &&
-              (quad_wins || std::getenv("DEXR_FORCE_QUAD"));
-    const bool wanted = (h.kind == DEXR_KIND_POSITION || m->bucket == 32) ? !std::getenv("DEXR_NO_BIG")
-                                                                          : std::getenv("DEXR_FORCE_BIG") != nullptr;
-    m->big = !m->quad && wanted && m->bucket >= 16 && h.kind != DEXR_KIND_FKONLY && max_slot < 2 && lds <= 160 * 1024;
-  }
-  m->chain = (h.kind == DEXR_KIND_VECTOR || h.kind == DEXR_KIND_POSITION) && !std::getenv("DEXR_NO_CHAIN");
-  for (const dexr_comp_table& c : m->comps) {
-    if (c.n_joint != m->bucket) m->chain = false;
-    for (int k = 0; k < c.n_joint && m->chain; ++k)
-      if (c.restore[k] != (k == 0 ? -2 : -1) || c.save[k] != -1 || c.src_kind[k] != DEXR_SRC_OPT ||
-          c.jtype[k] != DEXR_JOINT_REVOLUTE)
-        m->chain = false;
-  }
+  m->big_nh_rows = maxj * (maxj + 1) / 2;
+  for (const dexr_comp_table& c : m->comps)
+    for (int k = 0; k < c.n_joint; ++k) {
+      m->max_slot = c.save[k] > m->max_slot ? c.save[k] : m->max_slot;
+      m->has_mimic = m->has_mimic || c.src_kind[k] == DEXR_SRC_MIMIC;
+    }
+  default_tuning(m);
+  select_kernels(m);
+  if (m->quad) m->tune.lam_jump = 1.0f;  // the quad kernel scales the jump by the curvature along the failed step
   if (m->bucket < 0) {
     delete m;
     return fail(DEXR_ERR_UNSUPPORTED, "component with %d joints exceeds the largest kernel bucket", maxj);
@@ -410,6 +429,41 @@ int dexr_model_info(const dexr_model* m, dexr_model_header* header_out) {
   return DEXR_OK;
 }
 
+int dexr_model_get_tuning(const dexr_model* m, dexr_tuning* out) {
+  if (!m || !out) return fail(DEXR_ERR_INVALID, "null argument");
+  if (out->struct_size < sizeof(uint32_t) || out->struct_size > sizeof(dexr_tuning))
+    return fail(DEXR_ERR_INVALID, "dexr_tuning.struct_size=%u not understood (library: %zu)", out->struct_size, sizeof(dexr_tuning));
+  const uint32_t n = out->struct_size;
+  std::memcpy(out, &m->tune, n);
+  out->struct_size = n;
+  return DEXR_OK;
+}
+
+int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning) {
+  if (!m || !tuning) return fail(DEXR_ERR_INVALID, "null argument");
+  if (tuning->struct_size < sizeof(uint32_t) || tuning->struct_size > sizeof(dexr_tuning))
+    return fail(DEXR_ERR_INVALID, "dexr_tuning.struct_size=%u not understood (library: %zu)", tuning->struct_size, sizeof(dexr_tuning));
+  dexr_tuning t = m->tune;  // fields beyond the caller's (older, shorter) struct keep their values
+  std::memcpy(&t, tuning, tuning->struct_size);
+  t.struct_size = (uint32_t)sizeof(dexr_tuning);
+  if (t.kernel < DEXR_KERNEL_AUTO || t.kernel > DEXR_KERNEL_LDS) return fail(DEXR_ERR_INVALID, "unknown kernel family %d", t.kernel);
+  if (t.persist_from < 0 || t.qchunk < 0 || t.persist_occ < 0 || t.resident_waves < 0 || t.max_blind < 0)
+    return fail(DEXR_ERR_INVALID, "negative launch parameter");
+  if (!(t.step_cap >= 0) || !(t.lam_jump >= 0) || !(t.lam_fastdec >= 0) || !(t.floor_scale >= 0) || !(t.blind_tol_scale >= 0))
+    return fail(DEXR_ERR_INVALID, "negative or non-finite damping parameter");
+  m->tune = t;
+  select_kernels(m);
+  return DEXR_OK;
+}
+
+int dexr_model_kernel(const dexr_model* m, int32_t* family, int32_t* bucket, int32_t* chain) {
+  if (!m) return fail(DEXR_ERR_INVALID, "null argument");
+  if (family) *family = m->quad ? DEXR_KERNEL_QUAD : m->big ? DEXR_KERNEL_LDS : DEXR_KERNEL_REGISTER;
+  if (bucket) *bucket = m->bucket;
+  if (chain) *chain = m->chain ? 1 : 0;
+  return DEXR_OK;
+}
+
 static int retarget_dev_impl(const dexr_model* m, int64_t B, const float* ref, bool ref_is_keypoints, const float* fixed,
                              const float* last, uint32_t* state, float* qpos_out, int32_t* status_out,
                              int32_t* iters_out, float* fval_out, const dexr_solve_options* opt, void* stream) {
@@ -424,7 +478,7 @@ static int retarget_dev_impl(const dexr_model* m, int64_t B, const float* ref, b
   hipStream_t st = static_cast<hipStream_t>(stream);
   dexr::KernelParams kp;
   fill_params(m, kp, B);
-  apply_options(kp, opt);
+  apply_options(m, kp, opt);
   if (ref_is_keypoints) kp.kpts = ref;
   else kp.ref = ref;
   kp.fixed = fixed;
@@ -488,7 +542,7 @@ static int retarget_host(const dexr_model* m, int64_t B, const float* ref, const
   HIP_TRY(hipMemset(d_fval.p, 0, nb * sizeof(float)));
   dexr::KernelParams kp;
   fill_params(m, kp, B);
-  apply_options(kp, opt);
+  apply_options(m, kp, opt);
   if (ref_is_keypoints) kp.kpts = d_ref.as<float>();
   else kp.ref = d_ref.as<float>();
   kp.fixed = d_fix.as<float>();

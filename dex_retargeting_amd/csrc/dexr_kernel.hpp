@@ -748,9 +748,11 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
       pool_next = (unsigned)(tile * 64);
       pool_end = (unsigned)((tile * 64 + 64 < kp.B) ? tile * 64 + 64 : kp.B);
       if ((int64_t)pool_next >= kp.B) return;
-    } else {  // queue mode: the first tile is static as well (no start-up stampede on the counter)
-      pool_next = (unsigned)((tile * 64 < kp.B) ? tile * 64 : kp.B);
-      pool_end = (unsigned)((tile * 64 + 64 < kp.B) ? tile * 64 + 64 : kp.B);
+    } else {  // queue mode: the first tile is static as well (no start-up stampede on the counter).  The grid is rounded
+      // up to whole blocks: a surplus wave (tile * 64 >= q0, where the queue's numbering starts) gets no static tile.
+      const bool in_static = tile * 64 < (int64_t)kp.q0 && tile * 64 < kp.B;
+      pool_next = in_static ? (unsigned)(tile * 64) : 0u;
+      pool_end = in_static ? (unsigned)((tile * 64 + 64 < kp.B) ? tile * 64 + 64 : kp.B) : 0u;
     }
     unsigned* queue = kp.queue + comp;
 

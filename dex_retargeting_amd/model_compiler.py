@@ -256,6 +256,9 @@ def compile_model(model: KinematicModel, kind: int, idx_pin2target: Sequence[int
     """mimic: (mimic pin idx, source pin idx, multiplier, offset).  lower/upper: optimiser box per target joint
     (already widened; +-inf allowed)."""
     n_opt, n_fixed = len(idx_pin2target), len(idx_pin2fixed)
+    if len(terms) > MAXT:
+        raise ValueError(f"{len(terms)} reference rows (target links / vectors) exceed the table format's {MAXT} "
+                         f"(DEXR_MAXT, include/dexr_tables.h)")
     opt_of_pin = {int(p): i for i, p in enumerate(idx_pin2target)}
     fixed_of_pin = {int(p): i for i, p in enumerate(idx_pin2fixed)}
     mimic_of_pin = {int(m): (int(s), float(a), float(b)) for (m, s, a, b) in mimic}

@@ -160,10 +160,24 @@ class Optimizer:
         if fixed.shape[1] != n_fixed:
             raise ValueError(f"Optimizer has {n_fixed} joints but non_target_qpos {fixed_qpos} is given")
         model = self.device_model()
-        ref = np.ascontiguousarray(ref_value, dtype=np.float32).reshape(B, self._compiled.n_ref, 3)
-        q, info = model.retarget(ref, fixed, last, state=state, opts=self._options(), want_info=True)
+        n_ref = self._compiled.n_ref
+        ref = np.ascontiguousarray(ref_value, dtype=np.float32)
+        if ref.size != B * n_ref * 3:
+            raise ValueError(f"ref_value must have shape ({B}, {n_ref}, 3), got {np.shape(ref_value)}")
+        ref = ref.reshape(B, n_ref, 3)
+        q, info = model.retarget(ref, fixed, last, state=self._check_state(state, B), opts=self._options(), want_info=True)
         self.last_info = info
         return q
+
+    @staticmethod
+    def _check_state(state: Optional[np.ndarray], B: int) -> Optional[np.ndarray]:
+        """The kernels read and write `state` through a raw pointer: insist on the exact layout."""
+        if state is None:
+            return None
+        if not isinstance(state, np.ndarray) or state.dtype != np.uint32 or state.shape != (B,) or \
+                not state.flags["C_CONTIGUOUS"]:
+            raise ValueError(f"state must be a C-contiguous uint32 array of shape ({B},)")
+        return state
 
     def retarget_keypoints_batch(self, keypoints: np.ndarray, fixed_qpos: Optional[np.ndarray], last_qpos: np.ndarray,
                                  state: Optional[np.ndarray] = None) -> np.ndarray:
@@ -176,8 +190,15 @@ class Optimizer:
         if (0 if fixed is None else fixed.shape[1]) != len(self.idx_pin2fixed):
             raise ValueError(f"Optimizer has {len(self.idx_pin2fixed)} joints but non_target_qpos {fixed_qpos} is given")
         model = self.device_model()
-        kp = np.ascontiguousarray(keypoints, dtype=np.float32).reshape(B, -1, 3)
-        q, info = model.retarget(kp, fixed, last, state=state, opts=self._options(), want_info=True, keypoints=True)
+        n_kp = int(self._compiled.header["n_keypoints"])
+        kp = np.ascontiguousarray(keypoints, dtype=np.float32)
+        if n_kp <= 0:
+            raise ValueError("this optimizer carries no target_link_human_indices: keypoint input is not available")
+        if kp.size != B * n_kp * 3:  # the kernel indexes n_keypoints rows per frame
+            raise ValueError(f"keypoints must have shape ({B}, {n_kp}, 3), got {np.shape(keypoints)}")
+        kp = kp.reshape(B, n_kp, 3)
+        q, info = model.retarget(kp, fixed, last, state=self._check_state(state, B), opts=self._options(),
+                                 want_info=True, keypoints=True)
         self.last_info = info
         return q
 
@@ -194,7 +215,11 @@ class Optimizer:
         if self.last_info["status"][0] == 2:  # non-finite: same fallback as the reference's RuntimeError path
             print("dexr: solver produced non-finite values, returning last_qpos")
             return np.array(last_qpos, dtype=np.float32)
-        self.opt._last = float(self.last_info["fval"][0])
+        # nlopt's last_optimum_value() is the closure's return value, i.e. the data term WITHOUT the regulariser
+        # (optimizer.py:198,304,575; printed by SeqRetargeting.verbose as "Last distance"); the kernels report
+        # F = f + norm_delta |x - last|^2
+        reg = float(self.norm_delta) * float(((q[0].astype(np.float64) - last[0].astype(np.float64)) ** 2).sum())
+        self.opt._last = float(self.last_info["fval"][0]) - reg
         return q[0]
 
     def get_objective_function(self, ref_value: np.ndarray, fixed_qpos: np.ndarray, last_qpos: np.ndarray):

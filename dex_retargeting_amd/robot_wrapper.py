@@ -62,48 +62,61 @@ class RobotWrapper:
         return self.dof_joint_names.index(name)
 
     def get_link_index(self, name: str):
+        """Frame id of a link in pinocchio's frame numbering (universe, root link, then joint frame / child link in
+        depth-first order) == ``model.getFrameId(name, pin.BODY)`` (robot_wrapper.py:61-65): it indexes
+        ``link_names``."""
         if name not in self.link_names:
             raise ValueError(f"{name} is not a link name. Valid link names: \n{self.link_names}")
-        return self.kin.body_frame_index(name)
+        return self.kin.body_frame_id(name)
 
     def get_link_name(self, index: int) -> str:
-        return self.kin.frames[index].name
+        return self.kin.frame_names[index]
 
-    # ---- kinematics (robot_wrapper.py:82-87), batched ----------------------------------------------
+    def get_joint_parent_child_frames(self, joint_name: str):
+        """robot_wrapper.py:67-77: (``frames[joint_frame].parent``, id of the frame whose previousFrame is the joint's
+        frame).  pinocchio's ``Frame.parent`` is the index of the supporting joint in ``model.joints`` (universe = 0)."""
+        kin = self.kin
+        ids = [i for i, n in enumerate(kin.frame_names) if n == joint_name and kin.frame_table[i][0] != "BODY"]
+        if not ids:
+            raise ValueError(f"{joint_name} is not a joint name")
+        joint_id = ids[0]
+        parent_id = kin.frame_table[joint_id][1] + 1
+        child_id = -1
+        for idx, (_, _, prev, _) in enumerate(kin.frame_table):
+            if prev == joint_id and idx != joint_id:
+                child_id = idx
+        if child_id == -1:
+            raise ValueError(f"Can not find child link of {joint_name}")
+        return parent_id, child_id
+
+    # ---- kinematics (robot_wrapper.py:82-95), batched ----------------------------------------------
     def compute_forward_kinematics(self, qpos: npt.NDArray):
         self._qpos = np.atleast_2d(np.asarray(qpos, dtype=np.float64))
 
     def link_positions(self, qpos: npt.NDArray, link_indices: Sequence[int]) -> np.ndarray:
-        """(B, nq) -> (B, L, 3) world positions of the given body frames, computed on the GPU."""
+        """(B, nq) -> (B, L, 3) world positions of the given links (frame ids from get_link_index), on the GPU."""
         key = tuple(int(i) for i in link_indices)
         if key not in self._fk_models:
-            names = [self.kin.frames[i].name for i in key]
+            names = [self.kin.frames[self.kin.body_of_frame_id(i)].name for i in key]
             self._fk_models[key] = _lib.Model(compile_fk(self.kin, names).to_blob())
         q = np.atleast_2d(np.asarray(qpos, dtype=np.float64))
         return self._fk_models[key].fk(q, len(key))
 
     def get_link_pose(self, link_id: int) -> npt.NDArray:
-        """4x4 pose of one link at the configuration last given to compute_forward_kinematics.  Only the
-        translation is produced by the device path (that is all the retargeting objectives read,
-        optimizer.py:157-159,260,521); the rotation block is filled on the host from the same tables."""
+        """4x4 pose of one link at the configuration last given to compute_forward_kinematics.  The translation comes
+        from the device path (that is all the retargeting objectives read, optimizer.py:157-159,260,521); the rotation
+        block is filled on the host from the same kinematic model."""
         pos = self.link_positions(self._qpos[:1], [link_id])[0, 0]
-        T = np.eye(4)
-        T[:3, :3] = self._host_rotation(self._qpos[0], link_id)
+        T, _ = self.kin.frame_pose_and_local_jacobian(self._qpos[0], self.kin.body_of_frame_id(link_id))
         T[:3, 3] = pos
         return T
 
     def get_link_pose_inv(self, link_id: int) -> npt.NDArray:
         return np.linalg.inv(self.get_link_pose(link_id))
 
-    def _host_rotation(self, q: np.ndarray, link_id: int) -> np.ndarray:
-        # cold path helper for warm_start (seq_retarget.py:84-95): orientation of one body frame
-        f = self.kin.frames[link_id]
-        R = np.eye(3)
-        for j in self.kin.ancestors(f.parent) if f.parent >= 0 else []:
-            jt = self.kin.joints[j]
-            R = R @ jt.placement[:3, :3]
-            if jt.type == "revolute":
-                a, th = jt.axis, q[j]
-                K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
-                R = R @ (np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K))
-        return R @ f.placement[:3, :3]
+    def compute_single_link_local_jacobian(self, qpos, link_id: int) -> npt.NDArray:
+        """6 x dof frame Jacobian in the LOCAL frame (robot_wrapper.py:93-95), host float64: the solver kernels never
+        build this matrix (they form the world-aligned columns a x (p - o) directly), it exists for callers of the
+        reference API."""
+        return self.kin.frame_pose_and_local_jacobian(np.asarray(qpos, dtype=np.float64),
+                                                      self.kin.body_of_frame_id(link_id))[1]

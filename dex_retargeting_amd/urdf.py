@@ -192,14 +192,21 @@ class KinematicModel:
         self.joints: List[DofJoint] = []
         self.frames: List[BodyFrame] = []
         self.frame_names: List[str] = ["universe"]  # every frame name pinocchio would expose (joints + links)
+        # pinocchio-style frame table, same order as frame_names: (kind, parent dof joint or -1, previous frame id,
+        # index into self.frames for BODY entries or -1).  Frame ids handed out by RobotWrapper index THIS list,
+        # like pin.Model.getFrameId (robot_wrapper.py:57-77).
+        self.frame_table: List[Tuple[str, int, int, int]] = [("FIXED_JOINT", -1, 0, -1)]
 
         root = robot.root_link
         self.frames.append(BodyFrame(root, -1, np.eye(4)))
         self.frame_names.append(root)
+        self.frame_table.append(("BODY", -1, 0, 0))
 
         def walk(link: str, parent_joint: int, link_in_joint: np.ndarray):
+            link_fid = max(i for i, n in enumerate(self.frame_names) if n == link and self.frame_table[i][0] == "BODY")
             for uj in children.get(link, []):
                 self.frame_names.append(uj.name)
+                joint_fid = len(self.frame_names) - 1
                 if uj.type in ("revolute", "prismatic"):
                     if uj.lower is None or uj.upper is None:
                         raise ValueError(f"joint {uj.name}: revolute/prismatic joints need lower/upper limits")
@@ -210,13 +217,17 @@ class KinematicModel:
                     idx = len(self.joints)
                     self.joints.append(DofJoint(uj.name, uj.type, parent_joint, link_in_joint @ uj.origin,
                                                 axis / nrm, float(uj.lower), float(uj.upper)))
+                    self.frame_table.append(("JOINT", idx, link_fid, -1))
                     self.frames.append(BodyFrame(uj.child, idx, np.eye(4)))
                     self.frame_names.append(uj.child)
+                    self.frame_table.append(("BODY", idx, joint_fid, len(self.frames) - 1))
                     walk(uj.child, idx, np.eye(4))
                 elif uj.type == "fixed":
                     child_in_joint = link_in_joint @ uj.origin
+                    self.frame_table.append(("FIXED_JOINT", parent_joint, link_fid, -1))
                     self.frames.append(BodyFrame(uj.child, parent_joint, child_in_joint))
                     self.frame_names.append(uj.child)
+                    self.frame_table.append(("BODY", parent_joint, joint_fid, len(self.frames) - 1))
                     walk(uj.child, parent_joint, child_in_joint)
                 else:
                     # continuous -> nq=2 != nv=1 in pinocchio, rejected by the reference (robot_wrapper.py:22-23)
@@ -224,6 +235,7 @@ class KinematicModel:
 
         walk(root, -1, np.eye(4))
         self._frame_index = {f.name: i for i, f in enumerate(self.frames)}
+        self._body_fid = {self.frame_names[i]: i for i, e in enumerate(self.frame_table) if e[0] == "BODY"}
 
     # ---- metadata mirroring RobotWrapper's properties -------------------------------------------
     @property
@@ -246,6 +258,50 @@ class KinematicModel:
         if name not in self._frame_index:
             raise ValueError(f"{name} is not a link name. Valid link names: \n{self.link_names}")
         return self._frame_index[name]
+
+    def body_frame_id(self, name: str) -> int:
+        """pinocchio-style frame id of a link (== model.getFrameId(name, pin.BODY), robot_wrapper.py:57-65)."""
+        if name not in self._body_fid:
+            raise ValueError(f"{name} is not a link name. Valid link names: \n{self.link_names}")
+        return self._body_fid[name]
+
+    def body_of_frame_id(self, fid: int) -> int:
+        """index into self.frames of the BODY frame with pinocchio-style id `fid`."""
+        if not (0 <= fid < len(self.frame_table)) or self.frame_table[fid][0] != "BODY":
+            raise ValueError(f"frame id {fid} is not a BODY frame")
+        return self.frame_table[fid][3]
+
+    def frame_pose_and_local_jacobian(self, q: np.ndarray, body: int) -> Tuple[np.ndarray, np.ndarray]:
+        """Host float64 (cold path): 4x4 world pose of body frame `body` (index into self.frames) at configuration q
+        and its 6 x dof Jacobian expressed in the frame's own (LOCAL) axes, linear rows first -- what
+        ``pin.computeFrameJacobian`` returns by default (robot_wrapper.py:93-95)."""
+        q = np.asarray(q, dtype=np.float64).reshape(-1)
+        f = self.frames[body]
+        T = np.eye(4)
+        info = []  # (dof idx, type, world axis, world origin)
+        for j in (self.ancestors(f.parent) if f.parent >= 0 else []):
+            jt = self.joints[j]
+            T = T @ jt.placement
+            a_w = T[:3, :3] @ jt.axis
+            info.append((j, jt.type, a_w, T[:3, 3].copy()))
+            M = np.eye(4)
+            if jt.type == "revolute":
+                a, th = jt.axis, q[j]
+                K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+                M[:3, :3] = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+            else:
+                M[:3, 3] = jt.axis * q[j]
+            T = T @ M
+        T = T @ f.placement
+        R, p = T[:3, :3], T[:3, 3]
+        J = np.zeros((6, self.dof))
+        for j, typ, a_w, o_w in info:
+            if typ == "revolute":
+                J[:3, j] = R.T @ np.cross(a_w, p - o_w)
+                J[3:, j] = R.T @ a_w
+            else:
+                J[:3, j] = R.T @ a_w
+        return T, J
 
     def mimic_joints(self) -> Tuple[List[str], List[str], List[float], List[float]]:
         """(source names, mimic names, multipliers, offsets) in URDF joint order

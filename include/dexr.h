@@ -53,6 +53,33 @@ typedef struct dexr_solve_options {
                          error moves the stationary point by up to 4e-4 rad.  Default 0.      */
 } dexr_solve_options;
 
+/* Per-model launch / damping parameters.  These are the values the launcher derives from the model's shape and from
+ * measurements on MI355X; they are exposed so that a deployment (or the profiling tools under
+ * tools/) can override them for ONE model handle, explicitly, instead of through process-wide environment variables.
+ * Nothing in the library reads the environment.  Obtain the current values with dexr_model_get_tuning(), change
+ * fields, hand them back with dexr_model_set_tuning() (not thread-safe against launches in flight on that handle). */
+#define DEXR_KERNEL_AUTO (-1)
+#define DEXR_KERNEL_REGISTER 0 /* one lane per (frame, component), Hessian in registers (dexr_kernel.hpp)            */
+#define DEXR_KERNEL_QUAD 1     /* four lanes per frame, distributed Hessian rows (dexr_quad.hpp)                      */
+#define DEXR_KERNEL_LDS 2      /* one lane per frame, Hessian in LDS (dexr_big.hpp)                                   */
+typedef struct dexr_tuning {
+  uint32_t struct_size; /* sizeof(dexr_tuning) of the caller's header: lets the struct grow compatibly          */
+  int32_t kernel;       /* DEXR_KERNEL_*: float32 solve kernel family (AUTO: measured policy, dexr_api.hip)      */
+  int32_t chain;        /* 1: serial-chain specialisation where the tables allow it (default), 0: never          */
+  int32_t persist_occ;  /* small components: resident waves per SIMD in queue mode (0: derived from the kernel)  */
+  int32_t persist_from; /* small components: queue mode from this many 64-frame tiles per resident wave (8)       */
+  int32_t qchunk;       /* frames a wave takes from the queue per atomic (256)                                    */
+  int32_t resident_waves; /* quad / LDS kernels: resident waves (0: one per SIMD resp. what the LDS allows)       */
+  int32_t max_blind;    /* accepted steps below the rounding floor of F before the solve stops (8)                */
+  int32_t stall_from;   /* see dexr_kernel.hpp "stalled"                                                          */
+  float stall_ratio, stall_cap;
+  float lam_jump;       /* rejected step: lambda >= lam_jump x curvature scale (0: plain Nielsen)                 */
+  float lam_fastdec;    /* accepted step with rho > 0.9: lambda *= lam_fastdec (0: Nielsen's 1/3)                 */
+  float floor_scale;    /* mixed-precision kernels: value differences below floor_scale x |F| are unverifiable    */
+  float step_cap;       /* trust radius per joint [rad|m] (0: off)                                                */
+  float blind_tol_scale; /* a verified undamped Newton step shorter than blind_tol_scale x tol ends the solve (10) */
+} dexr_tuning;
+
 const char* dexr_last_error(void);
 const char* dexr_version(void);
 int dexr_device_count(void);
@@ -64,6 +91,11 @@ void dexr_default_options(dexr_solve_options* opt);
 int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out);
 void dexr_model_destroy(dexr_model* m);
 int dexr_model_info(const dexr_model* m, dexr_model_header* header_out);
+int dexr_model_get_tuning(const dexr_model* m, dexr_tuning* out);     /* out->struct_size must be set by the caller */
+int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning);  /* re-runs the kernel selection           */
+/* Which float32 solve kernel the handle launches: DEXR_KERNEL_* in *family, joint bucket in *bucket, 1 in *chain
+ * when the serial-chain specialisation is active (diagnostics for tools/ and tests). */
+int dexr_model_kernel(const dexr_model* m, int32_t* family, int32_t* bucket, int32_t* chain);
 
 /* == Optimizer.retarget x B  (optimizer.py:77-102).
  *   ref      B x n_ref x 3 float32  (vector/dexpilot: task-origin vectors; position: target positions)

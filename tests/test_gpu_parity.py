@@ -347,7 +347,7 @@ def test_full_size_batches_of_the_persistent_kernels(rel):
 
 @pytest.mark.parametrize("rel", ["teleop/allegro_hand_right.yml", "teleop/ability_hand_right.yml",
                                  "teleop/panda_gripper_dexpilot.yml"])
-def test_queue_mode_equals_tile_mode(rel, monkeypatch):
+def test_queue_mode_equals_tile_mode(rel):
     """Small components are launched either as one 64-frame tile per wave or, for batches of many tiles per resident
     wave (> 500 000 Allegro frames), as persistent lanes that pull frames from a work queue.  Every frame is solved by
     the same per-lane arithmetic in both, so the answers must agree bit for bit: force the queue mode (several chunk
@@ -357,13 +357,11 @@ def test_queue_mode_equals_tile_mode(rel, monkeypatch):
     B = 20000 + 37
     d = cases.human_set(prob, B, seed=3)
     st = (lambda: np.zeros(B, np.uint32)) if prob.kind == "dexpilot" else (lambda: None)
-    monkeypatch.setenv("DEXR_PERSIST_FROM", "1000000000")
+    model.tune(persist_from=1000000000)
     s_tile = st()
     want, wi = model.retarget(d["ref"], d["fixed"], d["last"], state=s_tile, want_info=True)
     for occ, chunk in ((1, 64), (4, 256), (2, 16)):
-        monkeypatch.setenv("DEXR_PERSIST_FROM", "0")
-        monkeypatch.setenv("DEXR_PERSIST_OCC", str(occ))
-        monkeypatch.setenv("DEXR_QCHUNK", str(chunk))
+        model.tune(persist_from=0, persist_occ=occ, qchunk=chunk)
         s_q = st()
         got, gi = model.retarget(d["ref"], d["fixed"], d["last"], state=s_q, want_info=True)
         assert np.array_equal(got, want), (occ, chunk)

@@ -55,6 +55,24 @@ def test_solve_options_struct_matches_header():
     assert (o.max_iter, o.newton, o.precision, o.polish, o.strict) == (64, 1, 0, -1, 0) and abs(o.tol - 2e-6) < 1e-12
 
 
+def test_tuning_struct_matches_header_and_library_reads_no_environment():
+    h = open(os.path.join(REPO, "include", "dexr.h")).read()
+    body = re.search(r"typedef struct dexr_tuning \{(.*?)\} dexr_tuning;", h, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in re.findall(r"\b(?:uint32_t|int32_t|float)\s+([\w\s,]+);", body):
+        fields += [f.strip() for f in decl.split(",")]
+    assert fields == [f[0] for f in _lib.Tuning._fields_]
+    import ctypes
+
+    assert ctypes.sizeof(_lib.Tuning) == 4 * len(fields)
+    # developer knobs are fields of dexr_tuning / dexr_solve_options, not environment variables
+    for src in ("dexr_api.hip", "dexr_kernel.hpp", "dexr_quad.hpp", "dexr_big.hpp", "dexr_prep.hip"):
+        path = os.path.join(REPO, "dex_retargeting_amd", "csrc", src)
+        if os.path.exists(path):
+            assert "getenv" not in open(path).read(), src
+
+
 def test_table_struct_sizes_match_header():
     # numpy dtypes in model_compiler.py must be byte-identical to the C structs in include/dexr_tables.h
     h = open(os.path.join(REPO, "include", "dexr_tables.h")).read()

@@ -9,6 +9,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import torch  # noqa: E402,F401
 
+from dex_retargeting_amd import _lib  # noqa: E402
 from dex_retargeting_amd.constants import DEFAULT_URDF_DIR  # noqa: E402
 from dex_retargeting_amd.retargeting_config import RetargetingConfig  # noqa: E402
 from oracle import cases  # noqa: E402
@@ -22,14 +23,13 @@ ref = np.ascontiguousarray(cases.ref_from_keypoints(prob, kp), dtype=np.float32)
 mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
 
 
-def model_for(env):
-    for k in ("DEXR_FORCE_QUAD", "DEXR_NO_QUAD"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
-    return RetargetingConfig.load_from_file(os.path.join(cases.CONFIG_DIR, rel)).build().optimizer.device_model()
+def model_for(kernel):
+    m = RetargetingConfig.load_from_file(os.path.join(cases.CONFIG_DIR, rel)).build().optimizer.device_model()
+    m.tune(kernel=kernel)  # dexr_tuning.kernel: per-handle kernel family
+    return m
 
 
-m_reg, m_quad = model_for({"DEXR_NO_QUAD": "1"}), model_for({"DEXR_FORCE_QUAD": "1"})
+m_reg, m_quad = model_for(_lib.KERNEL_REGISTER), model_for(_lib.KERNEL_QUAD)
 st0 = np.zeros(B, np.uint32)
 last = m_reg.retarget(ref[:-1], None, mid, state=st0)
 s1, s2 = st0.copy(), st0.copy()

@@ -77,21 +77,18 @@ for thr in (8, 10, 12, 16):
 if NO_SWEEP:
     sys.exit(0)
 print("\n# launch-mode sweep (median ms of 20); persist = resident waves + queue, occN = waves per SIMD, cM = queue chunk")
-KEYS = ("DEXR_PERSIST_FROM", "DEXR_PERSIST_OCC", "DEXR_QCHUNK")
-MODES = [("tile", {"DEXR_PERSIST_FROM": "1000000"}), ("default", {})]
+DEFAULT = dict(persist_from=8, persist_occ=0, qchunk=256)  # dexr_tuning defaults
+MODES = [("tile", dict(persist_from=1000000)), ("default", {})]
 for occ in (2, 3, 4, 6):
     for ch in (16, 64, 256):
-        MODES.append((f"occ{occ}c{ch}", {"DEXR_PERSIST_FROM": "0", "DEXR_PERSIST_OCC": str(occ), "DEXR_QCHUNK": str(ch)}))
+        MODES.append((f"occ{occ}c{ch}", dict(persist_from=0, persist_occ=occ, qchunk=ch)))
 for Bs in (4096, 16384, 65536, 131072, 262144, 1048576):
     kpn, la = workload(Bs)
     res = []
     for name, env in MODES:
-        for k in KEYS:
-            os.environ.pop(k, None)
-        os.environ.update(env)
+        model.tune(**{**DEFAULT, **env})
         ms, _ = run(Bs, kpn, la, reps=12)
         res.append((ms, name))
     best = min(res)
     print(f"B={Bs:8d}  " + "  ".join(f"{n} {m:.4f}" for m, n in res) + f"  -> best {best[1]} {Bs / best[0] / 1e3:.0f} kframes/ms")
-for k in KEYS:
-    os.environ.pop(k, None)
+model.tune(**DEFAULT)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool (GPU): time per solver iteration of the small-component kernel at 1..4 waves per SIMD.
 
-Every frame is forced to run exactly DEXR_MAX_ITER iterations (tol = 0 is unreachable, the blind/stall exits are
+Every frame is forced to run exactly max_iter iterations (tol = 0 is unreachable, the blind/stall exits are
 disabled), so kernel time = launch overhead + iterations x per-iteration time; the slope over max_iter is the
 per-iteration latency.  B = 16384 k Allegro frames = k waves per SIMD (4 components x 256 tiles x k = 1024 k waves).
 """
@@ -25,9 +25,7 @@ seq = RetargetingConfig.load_from_file(os.path.join(cases.CONFIG_DIR, rel)).buil
 model = seq.optimizer.device_model()
 prob = cases.problem_from_config(rel)
 dev = torch.device("cuda:0")
-os.environ["DEXR_PERSIST_FROM"] = "1000000"  # tile mode
-os.environ["DEXR_MAX_BLIND"] = "1000000"
-os.environ["DEXR_STALL_FROM"] = "1000000"
+model.tune(persist_from=1000000, max_blind=1000000, stall_from=1000000, blind_tol_scale=0.0)  # tile mode, no early exits
 s = torch.cuda.current_stream()
 print(f"# {rel}: forced iteration counts, tile mode; ms (median of 15)")
 for B in (1024, 4096, 16384, 32768, 49152, 65536):
@@ -38,8 +36,7 @@ for B in (1024, 4096, 16384, 32768, 49152, 65536):
     t_q = torch.empty((B, prob.n_opt), dtype=torch.float32, device=dev)
     row = []
     for mi in (1, 2, 4, 8, 16, 32):
-        os.environ["DEXR_MAX_ITER"] = str(mi)
-        opts = _lib.default_options(tol=1e-30)
+        opts = _lib.default_options(tol=1e-30, max_iter=mi)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(15)]
         for i in range(18):
             if i >= 3:

@@ -11,6 +11,8 @@ import torch  # noqa: E402,F401
 
 from dex_retargeting_amd.constants import DEFAULT_URDF_DIR  # noqa: E402
 from dex_retargeting_amd.retargeting_config import RetargetingConfig  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _tune  # noqa: E402
 from oracle import cases  # noqa: E402  (input recipes only)
 
 rel = sys.argv[1] if len(sys.argv) > 1 else "offline/leap_hand_right.yml"
@@ -23,26 +25,25 @@ ref = np.ascontiguousarray(cases.ref_from_keypoints(prob, kp), dtype=np.float32)
 mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
 
 
-def model_for(env):
-    for k in ("DEXR_NO_BIG", "DEXR_FORCE_BIG", "DEXR_NO_QUAD", "DEXR_FORCE_QUAD", "DEXR_NEWTON"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
+def model_for(knobs):
     seq = RetargetingConfig.load_from_file(os.path.join(cases.CONFIG_DIR, rel)).build()
-    return seq.optimizer.device_model()
+    m = seq.optimizer.device_model()
+    _, opts = _tune.apply(m, knobs)
+    return m, opts
 
 
-m0 = model_for({})
+m0, _ = model_for({})
 st = (lambda: np.zeros(B, np.uint32)) if dexpilot else (lambda: None)
 last = m0.retarget(ref[:-1], None, mid, state=st())
 q64, i64 = m0.retarget_f64(ref[1:], None, last, state=st(), want_info=True)
 print(f"# {rel} B={B}")
 print("float64 register kernel: iters mean %.2f" % i64["iters"].mean(), np.bincount(i64["iters"]).tolist())
-for name, env in (("default", {}), ("register f32 + polish", {"DEXR_NO_BIG": "1", "DEXR_NO_QUAD": "1"}),
-                  ("force big", {"DEXR_FORCE_BIG": "1", "DEXR_NO_QUAD": "1"}), ("force quad", {"DEXR_FORCE_QUAD": "1"}),
-                  ("default, gauss-newton", {"DEXR_NEWTON": "0"})):
+for name, env in (("default", {}), ("register f32 + polish", {"kernel": "register"}),
+                  ("force big", {"kernel": "lds"}), ("force quad", {"kernel": "quad"}),
+                  ("default, gauss-newton", {"newton": 0})):
     try:
-        m = model_for(env)
-        q, info = m.retarget(ref[1:], None, last, state=st(), want_info=True)
+        m, opts = model_for(env)
+        q, info = m.retarget(ref[1:], None, last, state=st(), opts=opts, want_info=True)
     except Exception as e:  # variant not available for this model
         print(f"{name}: {e}")
         continue

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool (GPU): cost/accuracy of the float32 termination rules on a bench workload.
 
-For each setting of the developer knobs (DEXR_MAX_BLIND / DEXR_STALL_*) solve the full 65 536-frame workload in
+For each setting of the dexr_tuning fields (max_blind / stall_*) solve the full 65 536-frame workload in
 float32 and compare with the float64 kernel's answer (dexr_retarget_f64, tight) on every frame.
 
     python tools/term_sweep.py [config.yml] > gpurun_out/term_sweep.txt
@@ -27,7 +27,9 @@ model = seq.optimizer.device_model()
 prob = cases.problem_from_config(rel)
 dexpilot = prob.kind == "dexpilot"
 dev = torch.device("cuda:0")
-KEYS = ("DEXR_MAX_BLIND", "DEXR_STALL_FROM", "DEXR_STALL_RATIO", "DEXR_STALL_CAP", "DEXR_LAM_JUMP", "DEXR_LAM_FASTDEC", "DEXR_FLOOR", "DEXR_STEP_CAP", "DEXR_BLIND_TOL")
+T0 = model.get_tuning()
+DEFAULT = {k: getattr(T0, k) for k in ("max_blind", "stall_from", "stall_ratio", "stall_cap", "lam_jump", "lam_fastdec",
+                                       "floor_scale", "step_cap", "blind_tol_scale")}  # this model's dexr_tuning defaults
 
 kp = cases.human_keypoints(B + 1, seed=cases.SEED)
 mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
@@ -54,9 +56,7 @@ def go(diag=False, opts=None):
 def measure(env, tol=None):
     from dex_retargeting_amd import _lib
 
-    for k in KEYS:
-        os.environ.pop(k, None)
-    os.environ.update(env)
+    model.tune(**{**DEFAULT, **env})
     opts = _lib.default_options(tol=tol) if tol else None
     for _ in range(3):
         go(opts=opts)
@@ -77,17 +77,17 @@ def measure(env, tol=None):
 print(f"# {rel} B={B}: float32 kernel vs float64 kernel on all frames")
 print(f"{'setting':44s} {'ms':>8s} {'it mean':>8s} {'tile max':>8s} {'max dq':>10s} {'p99.99':>10s} {'>1e-5':>7s} {'>1e-4':>7s}")
 SETTINGS = [("default", {}, None),
-            ("round-1 first kernel: jump=0 fastdec=0 floor=7e-15 cap=0 blind=0", {"DEXR_LAM_JUMP": "0", "DEXR_LAM_FASTDEC": "0", "DEXR_FLOOR": "7.1e-15", "DEXR_STEP_CAP": "0", "DEXR_BLIND_TOL": "0"}, None)]
+            ("round-1 first kernel: jump=0 fastdec=0 floor=7e-15 cap=0 blind=0", dict(lam_jump=0.0, lam_fastdec=0.0, floor_scale=7.1e-15, step_cap=0.0, blind_tol_scale=0.0), None)]
 for bt in (0, 2e-6, 2e-5, 1e-4):
-    SETTINGS.append((f"blind_tol={bt:g}", {"DEXR_BLIND_TOL": str(bt)}, None))
+    SETTINGS.append((f"blind_tol={bt:g}", dict(blind_tol_scale=bt / 2e-6), None))
 for cap in (0, 0.2, 0.5):
-    SETTINGS.append((f"step_cap={cap}", {"DEXR_STEP_CAP": str(cap)}, None))
+    SETTINGS.append((f"step_cap={cap}", dict(step_cap=float(cap)), None))
 for jump, dec in ((0.3, 0), (1.0, 0), (1.0, 0.1)):
-    SETTINGS.append((f"jump={jump} fastdec={dec}", {"DEXR_LAM_JUMP": str(jump), "DEXR_LAM_FASTDEC": str(dec)}, None))
+    SETTINGS.append((f"jump={jump} fastdec={dec}", dict(lam_jump=float(jump), lam_fastdec=float(dec)), None))
 if "--precision" in sys.argv:  # which knob limits the float32 answer's distance from the float64 one?
-    SETTINGS = [("default", {}, None), ("floor=7e-15", {"DEXR_FLOOR": "7.1e-15"}, None), ("tol=5e-7", {}, 5e-7),
-                ("tol=5e-7 floor=7e-15", {"DEXR_FLOOR": "7.1e-15"}, 5e-7), ("max_blind=0 blind_tol=0", {"DEXR_MAX_BLIND": "1000", "DEXR_BLIND_TOL": "0", "DEXR_STALL_FROM": "1000"}, None),
-                ("tol=5e-7 no blind exits", {"DEXR_MAX_BLIND": "1000", "DEXR_BLIND_TOL": "0", "DEXR_STALL_FROM": "1000", "DEXR_FLOOR": "7.1e-15"}, 5e-7)]
+    SETTINGS = [("default", {}, None), ("floor=7e-15", dict(floor_scale=7.1e-15), None), ("tol=5e-7", {}, 5e-7),
+                ("tol=5e-7 floor=7e-15", dict(floor_scale=7.1e-15), 5e-7), ("max_blind=0 blind_tol=0", dict(max_blind=1000, blind_tol_scale=0.0, stall_from=1000), None),
+                ("tol=5e-7 no blind exits", dict(max_blind=1000, blind_tol_scale=0.0, stall_from=1000, floor_scale=7.1e-15), 5e-7)]
 for name, env, tol in SETTINGS:
     ms, it, dq = measure(env, tol)
     wm = it[: B // 64 * 64].reshape(-1, 64).max(1)
