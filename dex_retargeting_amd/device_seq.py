@@ -92,11 +92,12 @@ class DeviceSeqRetargeting:
                                    hand_type or HandType.right, is_mano_convention)
         if pose.shape[0] != self.batch:
             raise ValueError(f"expected {self.batch} wrist poses, got {pose.shape[0]}")
-        last = self.last_qpos.cpu().numpy()
-        for num, joint_name in enumerate(self.optimizer.target_joint_names):
-            if joint_name in _DUMMY_NAMES:
-                last[:, num] = pose[:, _DUMMY_NAMES.index(joint_name)]
-        self.last_qpos.copy_(self.torch.from_numpy(last))
+        # scatter the six pose columns into the dummy joints' slots of last_qpos on the device (no read-back)
+        pairs = [(num, _DUMMY_NAMES.index(n)) for num, n in enumerate(self.optimizer.target_joint_names) if n in _DUMMY_NAMES]
+        if pairs:
+            dst = self.torch.tensor([p[0] for p in pairs], dtype=self.torch.long, device=self.device)
+            src = np.ascontiguousarray(pose[:, [p[1] for p in pairs]], dtype=np.float32)
+            self.last_qpos.index_copy_(1, dst, self.torch.from_numpy(src).to(self.device))
 
     def retarget_keypoints(self, keypoints, fixed_qpos=None):
         """Same as retarget() but fed with raw (B, 21, 3) hand keypoints; ref_value is formed inside the kernel."""

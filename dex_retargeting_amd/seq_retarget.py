@@ -14,19 +14,22 @@ from .optimizer_utils import LPFilter
 
 
 def _matrix_from_quaternion(q) -> np.ndarray:
-    """(w, x, y, z) -> rotation matrix (pytransform3d.rotations.matrix_from_quaternion convention)."""
-    w, x, y, z = np.asarray(q, dtype=np.float64) / np.linalg.norm(q)
-    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
-                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
-                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    """(..., 4) quaternions (w, x, y, z) -> (..., 3, 3) rotation matrices (pytransform3d's
+    ``rotations.matrix_from_quaternion`` convention, which normalises its input)."""
+    q = np.asarray(q, dtype=np.float64)
+    q = q / np.linalg.norm(q, axis=-1, keepdims=True)
+    w, x, y, z = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    return np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], -1),
+                     np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
+                     np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], -2)
 
 
 def _intrinsic_xyz_euler(R: np.ndarray) -> np.ndarray:
-    """Angles (a, b, c) with R = Rx(a) Ry(b) Rz(c): euler_from_matrix(R, 0, 1, 2, extrinsic=False)."""
-    b = np.arcsin(np.clip(R[0, 2], -1.0, 1.0))
-    a = np.arctan2(-R[1, 2], R[2, 2])
-    c = np.arctan2(-R[0, 1], R[0, 0])
-    return np.array([a, b, c])
+    """(..., 3, 3) -> angles (a, b, c) with R = Rx(a) Ry(b) Rz(c): euler_from_matrix(R, 0, 1, 2, extrinsic=False)."""
+    b = np.arcsin(np.clip(R[..., 0, 2], -1.0, 1.0))
+    a = np.arctan2(-R[..., 1, 2], R[..., 2, 2])
+    c = np.arctan2(-R[..., 0, 1], R[..., 0, 0])
+    return np.stack([a, b, c], -1)
 
 
 _DUMMY_NAMES = ["dummy_x_translation_joint", "dummy_y_translation_joint", "dummy_z_translation_joint",
@@ -50,15 +53,11 @@ def warm_start_pose_vec(optimizer: Optimizer, wrist_pos: np.ndarray, wrist_quat:
     wrist_link_id = robot.get_link_index(urdf_joint.child)
     robot.compute_forward_kinematics(robot.q0.copy())  # dummy joints at zero (seq_retarget.py:84-93)
     root2wrist = robot.get_link_pose_inv(wrist_link_id)
-    out = np.zeros((wrist_pos.shape[0], 6))
-    for b in range(wrist_pos.shape[0]):
-        target = np.eye(4)
-        target[:3, :3] = _matrix_from_quaternion(wrist_quat[b]) @ operator2mano.T
-        target[:3, 3] = wrist_pos[b]
-        root = target @ root2wrist
-        out[b, :3] = root[:3, 3]
-        out[b, 3:] = _intrinsic_xyz_euler(root[:3, :3])
-    return out
+    # target_root = [R_q op^T | pos] @ root2wrist for all B poses at once (seq_retarget.py:73-95)
+    Rw = _matrix_from_quaternion(wrist_quat) @ operator2mano.T
+    Rroot = Rw @ root2wrist[:3, :3]
+    proot = Rw @ root2wrist[:3, 3] + wrist_pos
+    return np.concatenate([proot, _intrinsic_xyz_euler(Rroot)], axis=1)
 
 
 class SeqRetargeting:

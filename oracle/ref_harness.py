@@ -194,6 +194,12 @@ class FakeRobotWrapper:
             raise ValueError(f"{name} is not a link name. Valid link names: \n{self.link_names}")
         return self._links.index(name)
 
+    def get_joint_parent_child_frames(self, joint_name: str):
+        """robot_wrapper.py:67-77 in this stand-in's own link numbering (ids index ``self._links``); only the child id is
+        used by the reference (seq_retarget.py:83)."""
+        j = [jj for jj in self.kin.joints if jj.name == joint_name][0]
+        return self._links.index(j.parent), self._links.index(j.child)
+
     def compute_forward_kinematics(self, qpos):
         self._q = np.array(qpos, dtype=np.float64)
 

@@ -17,7 +17,21 @@
   (example/vector_retargeting/single_hand_detector.py:102-104,129-158), right and left hand.  Pins
   oracle/preprocess.py and the GPU ``dexr_mano_keypoints`` kernel.
 
-Usage: python tests/golden/gen_golden.py [--only-mano]
+* fk_golden.npz -- link global transforms of every fixture URDF (with and without dummy free joints) at seeded
+  configurations, computed by the REFERENCE'S OWN URDF reader and forward kinematics
+  (/root/reference/src/dex_retargeting/yourdfpy.py: URDF.load :896-959, _forward_kinematics_joint :1013-1050,
+  build_tree / update_kinematics / get_link_global_transform :1862-1939, _add_dummy_joints :1942-1984) through
+  oracle/ref_urdf.py, plus the URDF text the reference's ``write_xml_file`` (:1098-1105) emits -- the file pinocchio
+  actually parses in RetargetingConfig.build (retargeting_config.py:176-186).  Pins oracle/kin.py,
+  dex_retargeting_amd/urdf.py, the table compiler and the GPU ``dexr_fk`` kernel (keyed by joint / link NAME).
+* warm_start_golden.npz -- ``last_qpos`` after the REFERENCE'S OWN ``SeqRetargeting.warm_start``
+  (seq_retarget.py:45-110) for seeded wrist poses, both hand types and both conventions, on every offline config.
+* seq_wrapper_golden.npz -- the REFERENCE'S OWN ``SeqRetargeting.retarget`` (seq_retarget.py:112-134) + ``LPFilter``
+  (optimizer_utils.py:7-13) + mimic adaptor wrapped around a deterministic stub optimizer that replays recorded
+  solver outputs: pins the per-frame bookkeeping (clip of the carried qpos, unfiltered carry, robot-qpos composition,
+  mimic fill, low-pass filter) independently of any solver.
+
+Usage: python tests/golden/gen_golden.py [--only-mano | --only-fk | --only-seq]
 """
 import os
 import sys
@@ -110,9 +124,131 @@ def gen_mano_frame():
     print("mano_frame_golden.npz:", {k: v.shape for k, v in out.items()})
 
 
+def gen_fk_golden():
+    import glob
+
+    from oracle import ref_urdf
+
+    out = {}
+    n_cfg = 4
+    for path in sorted(glob.glob(os.path.join(cases.URDF_DIR, "*", "*.urdf"))):
+        rel = os.path.relpath(path, cases.URDF_DIR)
+        for dummy in (False, True):
+            key = rel.replace("/", "__").replace(".urdf", "") + ("__free" if dummy else "")
+            u = ref_urdf.load_reference_urdf(path, dummy)
+            lo = np.array([j.limit.lower for j in u.actuated_joints], dtype=np.float64)
+            hi = np.array([j.limit.upper for j in u.actuated_joints], dtype=np.float64)
+            rng = np.random.default_rng(len(key) * 1000 + len(u.robot.joints) + (7 if dummy else 0))
+            cfg = rng.uniform(lo, hi, size=(n_cfg, len(lo)))
+            cfg[0] = 0.0  # the zero configuration (may lie outside the limits: FK does not care)
+            cfg[1] = lo
+            out[key + "__links"] = np.array([l.name for l in u.robot.links])
+            out[key + "__joints"] = np.array(u.actuated_joint_names)
+            out[key + "__lower"], out[key + "__upper"] = lo, hi
+            mim = [j for j in u.robot.joints if j.mimic is not None]
+            out[key + "__mimic"] = np.array([j.name for j in mim] or [""])
+            out[key + "__mimic_src"] = np.array([j.mimic.joint for j in mim] or [""])
+            out[key + "__mimic_mult"] = np.array([j.mimic.multiplier for j in mim], dtype=np.float64)
+            out[key + "__mimic_off"] = np.array([j.mimic.offset for j in mim], dtype=np.float64)
+            out[key + "__cfg"] = cfg
+            out[key + "__T"] = np.stack([ref_urdf.reference_link_transforms(u, c) for c in cfg])
+            # what pinocchio is given: the re-written URDF (mimic tags are not written, yourdfpy.py:1787-1802)
+            tmp = os.path.join("/tmp", f"dexr_rewrite_{os.getpid()}.urdf")
+            u.write_xml_file(tmp)
+            out[key + "__rewritten"] = np.array(open(tmp).read())
+            os.remove(tmp)
+            print(f"{key:40s} links={len(u.robot.links)} actuated={len(lo)} mimic={len(mim)}")
+    np.savez_compressed(os.path.join(HERE, "fk_golden.npz"), **out)
+
+
+class _ReplayOptimizer:
+    """Deterministic stub with the attribute surface SeqRetargeting touches (seq_retarget.py:12-134): ``retarget``
+    records its arguments and replays a prepared answer."""
+
+    def __init__(self, base, answers):
+        self.__dict__["_base"] = base
+        self.__dict__["answers"] = answers
+        self.__dict__["calls"] = []
+
+    def __getattr__(self, name):
+        return getattr(self._base, name)
+
+    def retarget(self, ref_value, fixed_qpos, last_qpos):
+        self.calls.append((np.array(ref_value), np.array(fixed_qpos), np.array(last_qpos)))
+        return self.answers[len(self.calls) - 1].astype(np.float32)
+
+
+def gen_seq_and_warm_start():
+    opt_mod, ka_mod, sr_mod, ou_mod = ref_harness.import_reference()
+    import dex_retargeting.constants as rc  # noqa: E402  (pure-python constants of the reference)
+
+    ws, sq = {}, {}
+    offline = sorted(f for f in os.listdir(os.path.join(cases.CONFIG_DIR, "offline")) if f.endswith(".yml"))
+    for f in offline:
+        rel = "offline/" + f
+        key = rel.replace("/", "__").replace(".yml", "")
+        o, seq = build_reference_optimizer(rel)
+        rng = np.random.default_rng(len(key))
+        n = 6
+        pos = rng.uniform(-0.4, 0.4, (n, 3))
+        quat = rng.standard_normal((n, 4))
+        hand = [rc.HandType.right if i % 2 == 0 else rc.HandType.left for i in range(n)]
+        mano = [i % 3 == 0 for i in range(n)]
+        outs = []
+        for i in range(n):
+            seq.reset()
+            seq.warm_start(pos[i], quat[i], hand[i], mano[i])
+            outs.append(np.array(seq.last_qpos, dtype=np.float32))
+        ws[key + "__pos"], ws[key + "__quat"] = pos, quat
+        ws[key + "__hand_is_right"] = np.array([h == rc.HandType.right for h in hand])
+        ws[key + "__mano"] = np.array(mano)
+        ws[key + "__last_qpos"] = np.array(outs)
+        ws[key + "__target_joint_names"] = np.array(o.target_joint_names)
+        print(f"warm_start {rel}")
+    np.savez_compressed(os.path.join(HERE, "warm_start_golden.npz"), **ws)
+
+    # SeqRetargeting bookkeeping around a replaying stub: one config per structural case
+    for rel in ["teleop/allegro_hand_right.yml",          # no mimic, alpha 0.2
+                "teleop/ability_hand_right.yml",          # mimic joints filled after the solve
+                "offline/inspire_hand_right.yml",         # free joints + mimic, alpha 1 (filter is the identity)
+                "teleop/panda_gripper.yml"]:              # 1 target joint + mimic finger
+        key = rel.replace("/", "__").replace(".yml", "")
+        o, _ = build_reference_optimizer(rel)
+        cfg = cases.load_cfg(rel)
+        T = 12
+        rng = np.random.default_rng(5 + len(key))
+        lim = o.robot.joint_limits[o.idx_pin2target]
+        # recorded "solver outputs": inside the optimiser's widened box, some beyond the joint limits by < 1e-3 so that
+        # the clip of the carried value (seq_retarget.py:118-120) matters
+        ans = rng.uniform(lim[:, 0], lim[:, 1], (T, len(lim)))
+        ans[3] = lim[:, 0] - 9e-4
+        ans[7] = lim[:, 1] + 9e-4
+        stub = _ReplayOptimizer(o, ans)
+        alpha = cfg.get("low_pass_alpha", 0.1)
+        seq = sr_mod.SeqRetargeting(stub, has_joint_limits=True, lp_filter=ou_mod.LPFilter(alpha) if 0 <= alpha <= 1 else None)
+        n_ref = len(o.target_link_human_indices[0]) if o.retargeting_type != "POSITION" else len(o.target_link_human_indices)
+        outs = []
+        for t in range(T):
+            outs.append(seq.retarget(rng.standard_normal((n_ref, 3)), fixed_qpos=np.zeros(len(o.idx_pin2fixed))))
+        sq[key + "__answers"] = ans.astype(np.float32)
+        sq[key + "__alpha"] = np.array(alpha)
+        sq[key + "__robot_qpos"] = np.array(outs)
+        sq[key + "__last_given"] = np.array([c[2] for c in stub.calls])
+        sq[key + "__joint_names"] = np.array(seq.joint_names)
+        sq[key + "__target_joint_names"] = np.array(o.target_joint_names)
+        print(f"seq wrapper {rel}: alpha={alpha}")
+    np.savez_compressed(os.path.join(HERE, "seq_wrapper_golden.npz"), **sq)
+
+
 def main():
     if "--only-mano" in sys.argv:
         gen_mano_frame()
+        return
+    if "--only-fk" in sys.argv:
+        gen_fk_golden()
+        return
+    if "--only-seq" in sys.argv:
+        gen_seq_and_warm_start()
         return
     kp = np.load("/root/reference/example/profiling/human_joint_right.pkl", allow_pickle=True)
     np.save(os.path.join(HERE, "human_joint_right_f32.npy"), np.stack(kp).astype(np.float32))
@@ -173,6 +309,8 @@ def main():
         print(f"{rel:45s} seq done, evals={o.opt.n_evals}")
     np.savez_compressed(os.path.join(HERE, "refsolve_golden.npz"), **sol)
     gen_mano_frame()
+    gen_fk_golden()
+    gen_seq_and_warm_start()
 
 
 if __name__ == "__main__":
