@@ -7,12 +7,21 @@
 
 A "step" is one pass of the hot path over one batch: B = 65 536 independent frames per GPU (weak scaling) of the
 workload BASELINE.json quotes the metric on -- Allegro right hand, VectorOptimizer -- solved to the tight
-tolerance, inputs resident in HBM when the timed region starts, result qpos resident (and, for N > 1,
-all-gathered with one RCCL all-gather) when it ends.
+tolerance, inputs resident in HBM when the timed region starts, result qpos resident (and, for N > 1, all-gathered
+with one RCCL all-gather per step) when it ends.  Consecutive steps solve DIFFERENT batches (four pre-staged
+batches are rotated), so no step re-solves the previous step's inputs.
 
-Workload (synthetic, seeded): keypoints = frame (b mod 621) of the human fixture
-+ N(0, 2 mm); ref_value = kp[task] - kp[origin] (profile_online_retargeting.py:24-30); last_qpos = the solver's own
-answer for the neighbouring frame (b-1), i.e. the warm start a running sequence would have (seq_retarget.py:124).
+Headline workload (synthetic, seeded): keypoints = frame (b mod 621) of the human fixture
++ N(0, 2 mm); ref_value = kp[task] - kp[origin] formed inside the kernel (profile_online_retargeting.py:24-30);
+last_qpos = the solver's own answer for the neighbouring frame (b-1), i.e. the warm start a running sequence has
+(seq_retarget.py:124).  float32 arithmetic (dtype "f32"); the same line carries
+
+* "f64":        the same config timed with float64 arithmetic throughout (the reference's arithmetic type);
+* "cold_start": the reference's own test regime (tests/test_optimizer.py:27-81: reachable targets, start sigma = 0.5);
+* "also":       the other two single-GPU BASELINE configs (Shadow DexPilot, LEAP position), each with its own
+                roofline / HBM traffic / parity block;
+* "parity":     max |dq| against the float64 oracle on a subset, and the distance to the reference-as-configured
+                SLSQP answers (oracle/, checker only -- imported after every timed region).
 
 Rank 0 prints ONE JSON line with the driver's contract plus `roofline` and `cpu_baseline`.
 """
@@ -30,6 +39,8 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3
+FP64_VALU_PEAK_TFLOPS = 78.6
+N_BATCHES = 4  # pre-staged input batches rotated over the steps
 
 FLEET = ["teleop/allegro_hand_right.yml", "teleop/shadow_hand_right_dexpilot.yml", "teleop/leap_hand_right.yml",
          "teleop/ability_hand_right.yml"]  # BASELINE.json configs[4]: 4 URDFs in one batch
@@ -40,106 +51,15 @@ WORKLOADS = {
     "leap_position": ("offline/leap_hand_right.yml", "LEAP right hand + 6 free joints, PositionOptimizer"),
     "mixed_fleet": (None, "Mixed fleet: Allegro vector + Shadow DexPilot + LEAP vector + Ability vector, frames interleaved"),
 }
+KERNEL_NAMES = {0: "dexr_kernel (one lane per frame and component, Hessian in registers)",
+                1: "dexr_quad_kernel (four lanes per frame)", 2: "dexr_big_kernel (Hessian in LDS)"}
 
 
-def run_mixed_fleet(args):
-    """BASELINE.json configs[4] on ONE GPU's share: B frames whose robot changes from frame to frame.  A step buckets
-    the frames by model (wavefronts must be model-uniform: the kinematic tables are scalar operands), solves the four
-    buckets concurrently on four HIP streams and scatters the answers back into the caller's order, all on the device
-    (dex_retargeting_amd/fleet.py).  Single-rank only; the 8-GPU run of this config shards the batch like the others."""
-    import torch
-
-    import bench_data
-    from dex_retargeting_amd.constants import DEFAULT_URDF_DIR
-    from dex_retargeting_amd.fleet import MixedFleet
-    from dex_retargeting_amd.retargeting_config import RetargetingConfig
-
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
-    RetargetingConfig.set_default_urdf_dir(str(DEFAULT_URDF_DIR))
-    seqs = [RetargetingConfig.load_from_file(os.path.join(bench_data.CONFIG_DIR, r)).build() for r in FLEET]
-    fleet = MixedFleet([q.optimizer for q in seqs])
-    B = args.batch
-    rng = np.random.default_rng(bench_data.SEED)
-    mid = rng.integers(0, len(FLEET), B)
-    kp = bench_data.human_keypoints(B + 1, seed=bench_data.SEED)
-    t_mid = torch.from_numpy(mid).to(dev)
-    t_prev, t_now = torch.from_numpy(np.ascontiguousarray(kp[:-1])).to(dev), torch.from_numpy(np.ascontiguousarray(kp[1:])).to(dev)
-    start = np.zeros((B, fleet.n_max), np.float32)
-    for m, sq in enumerate(seqs):
-        start[mid == m, : sq.optimizer.opt_dof] = sq.joint_limits.mean(1).astype(np.float32)
-    t_state = torch.zeros(B, dtype=torch.int32, device=dev)
-    t_last = fleet.retarget(t_mid, t_prev, torch.from_numpy(start).to(dev), t_state)  # untimed warm start
-    t_state0 = t_state.clone()
-    stream = torch.cuda.current_stream()
-
-    def step():
-        t_state.copy_(t_state0)
-        return fleet.retarget(t_mid, t_now, t_last, t_state)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in ev:
-        a.record(stream)
-        out = step()
-        b.record(stream)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    step_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    q = out.cpu().numpy()
-    last = t_last.cpu().numpy()
-    st_in = t_state0.cpu().numpy().astype(np.uint32)
-    bpf = 21 * 12 + 2 * 4 * fleet.n_max + 4 + 8  # keypoints + padded last/qpos rows + model id + DexPilot state in/out
-    achieved = B * bpf / (step_ms * 1e-3) / 1e9
-    # ---- checker (oracle) and CPU baseline: only from here on ----------------------------------------------------
-    from oracle import cases, solvers
-
-    probs = [cases.problem_from_config(r) for r in FLEET]
-    parity, cpu_t, cpu_n = {}, 0.0, 0
-    for m, (rel, pr) in enumerate(zip(FLEET, probs)):
-        idx = np.nonzero(mid == m)[0][:128]
-        ref = cases.ref_from_keypoints(pr, kp[1:][idx]).astype(np.float32)
-        kw = {}
-        if pr.kind == "dexpilot":
-            proj = ((st_in[idx, None] >> np.arange(pr.n_pair, dtype=np.uint32)) & 1).astype(bool)
-            w, rv, _ = pr.dexpilot_preamble(ref, proj)
-            kw = dict(weights=w, dexpilot_ref=rv)
-        la = last[idx][:, : pr.n_opt]
-        want = solvers.solve_lm_batched(pr, ref, None, la, newton=True, max_iter=100, **kw)
-        dq = np.abs(q[idx][:, : pr.n_opt].astype(np.float64) - want).max(1)
-        parity[rel] = {"subset": len(idx), "max_abs_dq_rad": float(dq.max()), "frac_within_1e-4": float((dq < 1e-4).mean())}
-        if not args.no_cpu_baseline:
-            t1 = time.perf_counter()
-            solvers.solve_ref_as_configured(pr, ref[:60], None, la[:60], **{k: v[:60] for k, v in kw.items()})
-            cpu_t += time.perf_counter() - t1
-            cpu_n += 60
-    out_json = {
-        "metric": "retargeted frames/sec, mixed-fleet batch (BASELINE.json configs[4]), one MI355X",
-        "value": B * args.steps / elapsed, "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{WORKLOADS['mixed_fleet'][1]}; {B} frames/GPU, model id uniform at random per frame, "
-                               f"human-keypoint refs, warm start = previous frame's solution", "models": FLEET,
-                   "batch_per_gpu": B, "collective": "none"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": step_ms,
-                     "algorithmic_bytes_per_frame": bpf,
-                     "kernel": "bucket by model (torch index ops) + 4 solve kernels on 4 streams + scatter"},
-        "parity": parity,
-    }
-    if cpu_n:
-        out_json["cpu_baseline"] = {"value": cpu_n / cpu_t, "unit": "frames/s", "cores": 1, "kind": "port",
-                                    "sample": "60 frames of each of the four models, reference-as-configured port"}
-    print(json.dumps(out_json))
-
-
-def algorithmic_bytes_per_frame(n_opt: int, dexpilot: bool, n_kp: int = 21) -> int:
-    """Compulsory HBM traffic of one frame through dexr_retarget_kp_dev:
-    21 raw keypoints in (252 B) + last_qpos in + qpos out (+ 4 B DexPilot state in and out)."""
-    return n_kp * 12 + n_opt * 4 + n_opt * 4 + (8 if dexpilot else 0)
+def algorithmic_bytes_per_frame(n_opt: int, dexpilot: bool, n_rows: int, keypoints: bool) -> int:
+    """Compulsory HBM traffic of one frame: the input rows (21 raw keypoints =
+    252 B through dexr_retarget_kp_dev, or n_ref ready-made ref_value rows) + last_qpos in + qpos out (+ 4 B DexPilot
+    state in and out)."""
+    return (21 if keypoints else n_rows) * 12 + n_opt * 4 + n_opt * 4 + (8 if dexpilot else 0)
 
 
 def algorithmic_flops_per_pass(compiled) -> float:
@@ -153,23 +73,210 @@ def algorithmic_flops_per_pass(compiled) -> float:
     return total
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=65536, help="frames per GPU")
-    ap.add_argument("--workload", default="allegro_vector", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=1200, help="frames of the workload timed on the host CPU")
-    args = ap.parse_args()
-    if args.workload == "mixed_fleet":
-        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-            raise SystemExit("--workload mixed_fleet measures one GPU's share; run it with --gpus 1")
-        if args.batch == 65536:
-            args.batch = 131072  # 1 048 576 frames / 8 GPUs
-        return run_mixed_fleet(args)
+class Workload:
+    """One named single-model workload on one GPU: model handle + N_BATCHES staged input batches in HBM."""
 
+    def __init__(self, name, rank, B, dev, torch):
+        import bench_data
+        from dex_retargeting_amd.constants import DEFAULT_URDF_DIR
+        from dex_retargeting_amd.retargeting_config import RetargetingConfig
+
+        RetargetingConfig.set_default_urdf_dir(str(DEFAULT_URDF_DIR))
+        self.name, self.B, self.dev, self.torch = name, B, dev, torch
+        self.rel, self.title = WORKLOADS[name]
+        self.seq = RetargetingConfig.load_from_file(os.path.join(bench_data.CONFIG_DIR, self.rel)).build()
+        self.opt = self.seq.optimizer
+        self.model = self.opt.device_model()
+        self.n_opt = self.opt.opt_dof
+        self.n_ref = int(self.opt.compiled_model().header["n_ref"])
+        self.dexpilot = self.opt.retargeting_type == "DEXPILOT"
+        self.seed = bench_data.SEED + 1000 * rank
+        self.stream = torch.cuda.current_stream()
+        self.t_iters = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.t_status = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.t_state = torch.zeros(B, dtype=torch.int32, device=dev) if self.dexpilot else None
+        self.t_q = torch.empty((B, self.n_opt), dtype=torch.float32, device=dev)
+        self.tracking = self._stage_tracking(bench_data)
+        self.cold = None
+
+    def _stage_tracking(self, bench_data):
+        """N_BATCHES batches of B frames: different fixture phase and noise per batch; the warm start of frame b is
+        the solver's own (untimed) answer for frame b-1 of the same batch."""
+        torch, B = self.torch, self.B
+        mid = np.repeat(self.seq.joint_limits.mean(1)[None], B, 0).astype(np.float32)
+        out = []
+        for j in range(N_BATCHES):
+            kp = bench_data.human_keypoints(B + 1, seed=self.seed + 17 * j, offset=155 * j)
+            st = np.zeros(B, np.uint32) if self.dexpilot else None
+            last = self.model.retarget(np.ascontiguousarray(kp[:-1]), None, mid, state=st, keypoints=True)
+            out.append(dict(kind="kp", host_in=np.ascontiguousarray(kp[1:]), host_last=last, host_state=st,
+                            t_in=torch.from_numpy(np.ascontiguousarray(kp[1:])).to(self.dev),
+                            t_last=torch.from_numpy(last).to(self.dev),
+                            t_state0=None if st is None else torch.from_numpy(st.astype(np.int32)).to(self.dev)))
+        return out
+
+    def stage_cold(self):
+        """The reference's own test regime (tests/test_optimizer.py:27-81): reachable targets, start sigma = 0.5 rad."""
+        import bench_data
+
+        torch = self.torch
+        out = []
+        for j in range(N_BATCHES):
+            ref, start = bench_data.reachable_batch(self.seq, self.B, 0.5, seed=self.seed + 31 * j + 5)
+            out.append(dict(kind="ref", host_in=ref, host_last=start, host_state=None,
+                            t_in=torch.from_numpy(ref).to(self.dev), t_last=torch.from_numpy(start).to(self.dev),
+                            t_state0=torch.zeros(self.B, dtype=torch.int32, device=self.dev) if self.dexpilot else None))
+        self.cold = out
+        return out
+
+    def launch(self, batch, out, opts=None, diagnostics=False):
+        if self.dexpilot:
+            self.t_state.copy_(batch["t_state0"])
+        self.model.retarget_dev(self.B, batch["t_in"].data_ptr(), 0, batch["t_last"].data_ptr(),
+                                self.t_state.data_ptr() if self.dexpilot else 0, out.data_ptr(),
+                                status_ptr=self.t_status.data_ptr() if diagnostics else 0,
+                                iters_ptr=self.t_iters.data_ptr() if diagnostics else 0, opts=opts,
+                                stream=self.stream.cuda_stream, keypoints=batch["kind"] == "kp")
+
+    def diagnostics(self, batches, opts=None):
+        """Untimed: iteration statistics of every staged batch (frame level: the maximum over the frame's components)."""
+        torch = self.torch
+        its, conv, tilemax = [], 0, []
+        for b in batches:
+            self.launch(b, self.t_q, opts=opts, diagnostics=True)
+            torch.cuda.synchronize()
+            it = self.t_iters.cpu().numpy()
+            its.append(it)
+            conv += int((self.t_status == 0).sum())
+            tilemax.append(it[: self.B // 64 * 64].reshape(-1, 64).max(1))
+        it = np.concatenate(its)
+        tm = np.concatenate(tilemax)
+        return {"iters_mean": float(it.mean()), "iters_max": int(it.max()), "converged_frac": conv / (self.B * len(batches)),
+                # passes a 64-frame tile executes (its slowest frame) vs. passes its frames need: the share of issued
+                # lane-passes that do useful work when a wave owns a fixed tile (tile mode)
+                "tile_max_mean": float(tm.mean()),
+                "active_lane_fraction": float((it[: len(tm) * 64] + 1).sum() / (64.0 * (tm + 1).sum()))}
+
+    def timed(self, batches, steps, warmup, opts=None, pipe=None, dist=None):
+        """warmup untimed steps, then exactly `steps` steps bracketed by barrier + synchronize; returns
+        (elapsed wall seconds, mean launch ms from HIP events on the launch stream)."""
+        torch = self.torch
+        n = [0]
+
+        def step():
+            k = n[0]
+            out = self.t_q if pipe is None else pipe.shard(k)
+            self.launch(batches[k % len(batches)], out, opts=opts)
+            if pipe is not None:
+                pipe.gather(k)
+            n[0] += 1
+
+        for _ in range(warmup):
+            step()
+        if pipe is not None:
+            pipe.finish()
+            n[0] = (n[0] + pipe.G - 1) // pipe.G * pipe.G  # the timed steps start a fresh group
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record(self.stream)
+        for _ in range(steps):
+            step()
+        ev1.record(self.stream)
+        if pipe is not None:
+            pipe.finish()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = float(ev0.elapsed_time(ev1)) / steps
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, kernel_ms
+
+    def roofline(self, kernel_ms, iters_mean, batch_kind="kp", precision="f32", world=1):
+        bpf = algorithmic_bytes_per_frame(self.n_opt, self.dexpilot, self.n_ref, batch_kind == "kp")
+        achieved = self.B * bpf / (kernel_ms * 1e-3) / 1e9
+        flops_frame = algorithmic_flops_per_pass(self.opt.compiled_model()) * (iters_mean + 1.0)  # +1: start point's model
+        tf = self.B * flops_frame / (kernel_ms * 1e-3) / 1e12
+        peak_tf = FP32_VALU_PEAK_TFLOPS if precision == "f32" else FP64_VALU_PEAK_TFLOPS
+        traffic, valu_frac = None, None
+        # HBM bytes per launch as counted by rocprofv3 PMC passes of this same command (tools/profile_round.sh writes
+        # the summary, committed under profiles/): 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction per
+        # MI355X_MICROARCH.md.  Only attached to the line it was measured for (same batch, f32, keypoint input).
+        pmc_path = os.path.join(REPO, "profiles", f"pmc_{self.name}.json")
+        if os.path.exists(pmc_path) and precision == "f32" and batch_kind == "kp" and world == 1:
+            pmc = json.load(open(pmc_path))
+            if pmc.get("batch") == self.B:
+                traffic = pmc.get("hbm_bytes_per_launch")
+                if "SQ_INSTS_VALU" in pmc:  # wave64 VALU instruction = 4 issue cycles on a 16-lane SIMD; 1024 SIMDs, 2.4 GHz
+                    valu_frac = pmc["SQ_INSTS_VALU"] * 4.0 / (1024 * kernel_ms * 1e-3 * 2.4e9)
+        fam, bucket, chain = self.model.kernel()
+        kname = KERNEL_NAMES[fam] + f", bucket {bucket}" + (", serial-chain specialisation" if chain else "")
+        if precision == "f64":
+            kname = f"dexr_kernel<{bucket}, double> (register kernel, float64 arithmetic)"
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic, "valu_issue_frac": valu_frac,
+                "valu": {"achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf,
+                         "algorithmic_flops_per_frame": flops_frame},
+                "kernel": kname, "kernel_ms": kernel_ms, "algorithmic_bytes_per_frame": bpf}
+
+
+def parity_block(wl, batch, q_gpu, n_par, n_slsqp):
+    """Checker (oracle) section: max |dq| against the float64 oracle minimiser of F on the first n_par frames of
+    `batch`, and the distance to the reference-as-configured SLSQP answers on the first n_slsqp."""
+    from oracle import cases, solvers
+
+    prob = cases.problem_from_config(wl.rel)
+    assert (prob.n_opt, prob.n_ref) == (wl.n_opt, wl.n_ref)
+    ref = batch["host_in"][:n_par]
+    if batch["kind"] == "kp":
+        ref = cases.ref_from_keypoints(prob, ref).astype(np.float32)
+    last = batch["host_last"][:n_par]
+
+    def kw_for(sl):
+        if not wl.dexpilot:
+            return {}
+        st = batch["host_state"][sl] if batch["host_state"] is not None else np.zeros(len(ref[sl]), np.uint32)
+        proj = ((st[:, None] >> np.arange(prob.n_pair, dtype=np.uint32)) & 1).astype(bool)
+        w, rv, _ = prob.dexpilot_preamble(ref[sl], proj)
+        return dict(weights=w, dexpilot_ref=rv)
+
+    kw = kw_for(slice(0, n_par))
+    want = solvers.solve_lm_batched(prob, ref, None, last, newton=True, max_iter=100, **kw)
+    got = q_gpu[:n_par].astype(np.float64)
+    dq = np.abs(got - want).max(1)
+    last64 = last.astype(np.float64)
+    F_got = prob.total(got, ref, None, last64, **kw)
+    F_want = prob.total(want, ref, None, last64, **kw)
+    other = dq >= 1e-4
+    out = {"subset": n_par, "max_abs_dq_rad": float(dq.max()), "p99_abs_dq_rad": float(np.percentile(dq, 99)),
+           "frac_within_1e-4": float((dq < 1e-4).mean()),
+           "other_minimum": {"frames": int(other.sum()),
+                             "gpu_objective_lower_or_equal": int((F_got[other] <= F_want[other] + 1e-9).sum())},
+           "max_abs_dq_rad_same_minimum": float(dq[~other].max()) if (~other).any() else None,
+           "oracle": "float64 projected LM/Newton on F (oracle/solvers.py)"}
+    if n_slsqp:
+        sl = slice(0, n_slsqp)
+        q_ref, _ = solvers.solve_ref_as_configured(prob, ref[sl], None, last[sl], **kw_for(sl))
+        q_ref = q_ref.astype(np.float64)
+        kws = {k: v[sl] for k, v in kw.items()}
+        F_ref = prob.total(q_ref, ref[sl], None, last64[sl], **kws)
+        d = np.abs(got[sl] - q_ref).max(1)
+        out["vs_reference_as_configured"] = {
+            "subset": n_slsqp, "median_abs_dq_rad": float(np.median(d)), "p99_abs_dq_rad": float(np.percentile(d, 99)),
+            "max_abs_dq_rad": float(d.max()), "frac_F_gpu_le_F_ref": float((F_got[sl] <= F_ref + 1e-12).mean()),
+            "median_F_ref_minus_F_gpu": float(np.median(F_ref - F_got[sl])),
+            "reference": f"oracle restatement of the reference objective (value without, gradient with the regulariser) + "
+                         f"scipy SLSQP ftol {prob.ftol:g} standing in for nlopt LD_SLSQP ftol_abs (optimizer.py:96-99)"}
+    return out, prob, ref, last, kw_for
+
+
+def run_single(args):
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -189,188 +296,143 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    import bench_data  # seeded synthetic inputs (no oracle code before the checker sections at the end)
-    from dex_retargeting_amd.constants import DEFAULT_URDF_DIR
-    from dex_retargeting_amd.retargeting_config import RetargetingConfig
+    from dex_retargeting_amd import _lib
 
-    RetargetingConfig.set_default_urdf_dir(str(DEFAULT_URDF_DIR))
-    rel, wl_name = WORKLOADS[args.workload]
-    seq = RetargetingConfig.load_from_file(os.path.join(bench_data.CONFIG_DIR, rel)).build()
-    opt = seq.optimizer
-    model = opt.device_model()
     B = args.batch
-    n_opt, n_ref = opt.opt_dof, int(opt.compiled_model().header["n_ref"])
-    dexpilot = opt.retargeting_type == "DEXPILOT"
+    wl = Workload(args.workload, rank, B, dev, torch)
+    diag = wl.diagnostics(wl.tracking)
 
-    # ---- synthetic inputs, resident in HBM ------------------------------------------------------------------
-    seed = bench_data.SEED + 1000 * rank
-    kp = bench_data.human_keypoints(B + 1, seed=seed)  # (B+1, 21, 3) float32
-    kp_prev, kp_now = np.ascontiguousarray(kp[:-1]), np.ascontiguousarray(kp[1:])
-    mid = np.repeat(seq.joint_limits.mean(1)[None], B, 0).astype(np.float32)
-    st0 = np.zeros(B, np.uint32) if dexpilot else None
-    # untimed: the previous frame's solution = the warm start a running sequence would carry
-    last = model.retarget(kp_prev, None, mid, state=st0, keypoints=True)
-    t_ref = torch.from_numpy(kp_now).to(dev)  # raw keypoints: ref_value is formed inside the kernel
-    t_last = torch.from_numpy(last).to(dev)
-    t_state0 = torch.from_numpy(st0.astype(np.int32)).to(dev) if dexpilot else None
-    t_state = t_state0.clone() if dexpilot else None
-    t_q = torch.empty((B, n_opt), dtype=torch.float32, device=dev)
-    t_iters = torch.zeros(B, dtype=torch.int32, device=dev)
-    t_status = torch.zeros(B, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream()
-    # N > 1: one RCCL all-gather of this rank's (B, n_opt) result per step, overlapped with the following steps' solves
-    # (rotating buffer pairs; every gather has completed when the timed region ends)
-    pipe = None
+    # ---- headline: float32 tracking -----------------------------------------------------------------------------
+    pipe, pipelined = None, None
     if dist is not None:
         from dex_retargeting_amd.distributed import PipelinedAllGather
 
-        # four steps share one collective (issuing an async collective costs the host ~100 us in torch.distributed,
-        # more than a solve takes; 4 x 4 MB per rank is still a small message for xGMI), and there are enough buffer
-        # pairs (HBM is 288 GB) that the compute stream hardly ever has to wait for an earlier gather before reusing
-        # one: the gathers simply trail the solves on RCCL's stream
+        # SURVEY.md 8d definition: ONE RCCL all-gather of this rank's (B, n_opt) result per step, issued right after the
+        # solve that produced it (RCCL's stream waits for the solve; the next solve writes another buffer); every
+        # gather has completed when the timed region ends.
+        pipe = PipelinedAllGather(B, wl.n_opt, torch.float32, dev, depth=min(16, args.steps + args.warmup + 2),
+                                  steps_per_gather=1)
+    elapsed, kernel_ms = wl.timed(wl.tracking, args.steps, args.warmup, pipe=pipe, dist=dist)
+    if dist is not None:
+        # second figure: four steps share one collective (fewer, larger collectives; the host cost of issuing an async
+        # collective through torch.distributed, ~100 us, exceeds one 80 us solve)
         G = int(os.environ.get("DEXR_BENCH_GATHER_EVERY", "4"))
-        pipe = PipelinedAllGather(B, n_opt, torch.float32, dev, depth=min(16, (args.steps + args.warmup) // G + 3),
-                                  steps_per_gather=G)
-    n_step, out_last = [0], [None]
-
-    def step(diagnostics=False):
-        if dexpilot:
-            t_state.copy_(t_state0)
-        out = t_q if pipe is None else pipe.shard(n_step[0])
-        out_last[0] = out
-        model.retarget_dev(B, t_ref.data_ptr(), 0, t_last.data_ptr(), t_state.data_ptr() if dexpilot else 0,
-                           out.data_ptr(), status_ptr=t_status.data_ptr() if diagnostics else 0,
-                           iters_ptr=t_iters.data_ptr() if diagnostics else 0, stream=stream.cuda_stream,
-                           keypoints=True)
-        if pipe is not None:
-            pipe.gather(n_step[0])
-        n_step[0] += 1
-
-    for _ in range(args.warmup):
-        step()
-    step(diagnostics=True)  # untimed: iteration counts / status of this workload
-    if pipe is not None:
-        t_q.copy_(out_last[0])
-        pipe.finish()
-        n_step[0] = 0  # the timed steps start a fresh group
+        pipe4 = PipelinedAllGather(B, wl.n_opt, torch.float32, dev, depth=min(16, (args.steps + args.warmup) // G + 3),
+                                   steps_per_gather=G)
+        e4, k4 = wl.timed(wl.tracking, args.steps, args.warmup, pipe=pipe4, dist=dist)
+        pipelined = {"value": world * B * args.steps / e4, "unit": "frames/s", "ms_per_step": e4 / args.steps * 1e3,
+                     "gather_every_steps": G, "note": f"{G} steps share one all-gather of {G} x B rows per rank"}
+    # per-step answers of the last timed step's batch for the parity check
+    last_batch = wl.tracking[(args.steps + args.warmup - 1) % N_BATCHES]
+    wl.launch(last_batch, wl.t_q)
     torch.cuda.synchronize()
-    iters_mean = float(t_iters.float().mean())
-    iters_max = int(t_iters.max())
-    n_conv = int((t_status == 0).sum())
+    q_head = wl.t_q.cpu().numpy()
 
-    # HIP events bracket the K launches on the stream they are issued on; average launch duration = span / K.  (An event
-    # pair around every single launch puts two extra packets between consecutive kernels and costs ~8 us per step.)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for k in range(args.steps):
-        step()
-    ev1.record(stream)
-    if pipe is not None:
-        pipe.finish()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = float(ev0.elapsed_time(ev1)) / args.steps
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    # ---- sub-records (rank 0's GPU only; untouched by the collective) --------------------------------------------
+    sub = {}
+    if world > 1:
+        args.headline_only = True  # scaling runs: the headline (+ the pipelined-gather figure) only
+    if rank == 0 and not args.headline_only:
+        o64 = _lib.default_options(precision=1)
+        d64 = wl.diagnostics(wl.tracking, opts=o64)
+        e64, k64 = wl.timed(wl.tracking, args.steps, args.warmup, opts=o64)
+        wl.launch(last_batch, wl.t_q, opts=o64)
+        torch.cuda.synchronize()
+        q64 = wl.t_q.cpu().numpy()
+        sub["f64"] = {"dtype": "f64", "value": B * args.steps / e64, "unit": "frames/s", "n_gpus": 1,
+                      "ms_per_step": e64 / args.steps * 1e3, "solver": d64,
+                      "roofline": wl.roofline(k64, d64["iters_mean"], precision="f64"),
+                      "max_abs_dq_vs_f32_rad": float(np.abs(q64.astype(np.float64) - q_head).max()),
+                      "note": "same workload and config, dexr_solve_options.precision = 1: float64 arithmetic throughout"}
+        cold = wl.stage_cold()
+        dc = wl.diagnostics(cold)
+        ec, kc = wl.timed(cold, args.steps, args.warmup)
+        wl.launch(cold[0], wl.t_q)
+        torch.cuda.synchronize()
+        q_cold = wl.t_q.cpu().numpy()
+        sub["cold_start"] = {"dtype": "f32", "value": B * args.steps / ec, "unit": "frames/s", "n_gpus": 1,
+                             "ms_per_step": ec / args.steps * 1e3, "solver": dc,
+                             "roofline": wl.roofline(kc, dc["iters_mean"], batch_kind="ref"),
+                             "workload": "reachable targets (the robot's own FK at q* ~ U(limits)), start = q* + 0.5 rad "
+                                         "N(0,1) clipped to the limits: tests/test_optimizer.py:27-81 of the reference"}
+    also = {}
+    if rank == 0 and not args.headline_only and args.workload == "allegro_vector":
+        for name in ("shadow_dexpilot", "leap_position"):
+            w2 = Workload(name, rank, B, dev, torch)
+            d2 = w2.diagnostics(w2.tracking)
+            e2, k2 = w2.timed(w2.tracking, args.steps, args.warmup)
+            b2 = w2.tracking[(args.steps + args.warmup - 1) % N_BATCHES]
+            w2.launch(b2, w2.t_q)
+            torch.cuda.synchronize()
+            also[name] = (w2, b2, w2.t_q.cpu().numpy(),
+                          {"config_file": w2.rel, "workload": w2.title, "dtype": "f32", "value": B * args.steps / e2,
+                           "unit": "frames/s", "n_gpus": 1, "ms_per_step": e2 / args.steps * 1e3, "solver": d2,
+                           "roofline": w2.roofline(k2, d2["iters_mean"])})
 
     if rank != 0:
         dist.destroy_process_group()
         return
 
     frames = world * B * args.steps
-    value = frames / elapsed
-    bpf = algorithmic_bytes_per_frame(n_opt, dexpilot)
-    achieved = B * bpf / (kernel_ms * 1e-3) / 1e9
-    # HBM bytes per launch as counted by rocprofv3 PMC passes of this same command (tools/profile_round.sh writes the
-    # summary, committed under profiles/): 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction per MI355X_MICROARCH.md
-    traffic, valu_frac = None, None
-    pmc_path = os.path.join(REPO, "profiles", f"pmc_{args.workload}.json")
-    if os.path.exists(pmc_path):
-        pmc = json.load(open(pmc_path))
-        if pmc.get("batch") == B and world == 1:
-            traffic = pmc.get("hbm_bytes_per_launch")
-            if "SQ_INSTS_VALU" in pmc:  # wave64 VALU instruction = 4 issue cycles on a 16-lane SIMD; 1024 SIMDs, 2.4 GHz
-                valu_frac = pmc["SQ_INSTS_VALU"] * 4.0 / (1024 * kernel_ms * 1e-3 * 2.4e9)
-    flops_frame = algorithmic_flops_per_pass(opt.compiled_model()) * (iters_mean + 1.0)  # +1: the start point's model
-    valu_tflops = B * flops_frame / (kernel_ms * 1e-3) / 1e12
+    coll = "none"
+    if dist is not None:
+        coll = "rccl all_gather of qpos, one per step, issued after the solve and complete when the timed region ends"
     out = {
         "metric": json.load(open(os.path.join(REPO, "BASELINE.json")))["metric"],
-        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{wl_name}, {B} frames/GPU, human-keypoint refs (fixture frame b mod 621 + 2 mm noise), "
-                               f"warm start = previous frame's solution", "config_file": rel, "batch_per_gpu": B,
-                   "n_opt": n_opt, "n_ref": n_ref, "collective": "rccl all_gather of qpos (one per 4 steps, 4 x B rows per rank), overlapped with the following solves" if dist is not None else "none"},
-        "solver": {"iters_mean": iters_mean, "iters_max": iters_max, "converged_frac": n_conv / B,
-                   "tol_rad": 2e-6, "newton": 1},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "traffic_note": "bytes per launch from the rocprofv3 --pmc passes in profiles/ (same command, "
-                                     "same batch); null when no matching profile is committed",
-                     "valu_issue_frac": valu_frac,
-                     "valu": {"achieved": valu_tflops, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": valu_tflops / FP32_VALU_PEAK_TFLOPS, "algorithmic_flops_per_frame": flops_frame,
-                              "note": "algorithmic flops per solver pass (bench.py:algorithmic_flops_per_pass) x mean "
-                                      "passes per frame of this run"},
-                     "kernel": "dexr_kernel<4,float,SOLVE,CHAIN> (Allegro vector) / dexr_quad_kernel<24> (Shadow DexPilot, LEAP position)",
-                     "kernel_ms": kernel_ms,
-                     "algorithmic_bytes_per_frame": bpf,
-                     "note": "path is FP32 VALU/latency bound (n_dof <= 24 per lane, no dense contraction); the HBM "
-                             "fraction is reported as north_star asks, see DESIGN.md section 4"},
+        "config": {"workload": f"{wl.title}, {B} frames/GPU, human-keypoint refs (fixture frame b mod 621 + 2 mm noise), "
+                               f"warm start = previous frame's solution; {N_BATCHES} staged batches rotated over the steps",
+                   "config_file": wl.rel, "batch_per_gpu": B, "n_opt": wl.n_opt, "n_ref": wl.n_ref, "collective": coll,
+                   "rccl_world_size": world if dist is not None else None},
+        "solver": dict(diag, tol_rad=2e-6, newton=1),
+        "roofline": dict(wl.roofline(kernel_ms, diag["iters_mean"], world=world),
+                         traffic_note="bytes per launch from the rocprofv3 --pmc passes in profiles/ (same command, same "
+                                      "batch); null when no matching profile is committed",
+                         note="path is FP32 VALU/latency bound (n_dof <= 24 per lane, no dense contraction); the HBM "
+                              "fraction is reported as north_star asks, see DESIGN.md section 4"),
     }
+    if pipelined is not None:
+        out["pipelined_gather"] = pipelined
+    out.update(sub)
 
-    # ---- parity on a subset (oracle = checker only; nothing above this line touches oracle/) ---------------------
-    from oracle import cases, solvers
+    # ---- checker sections (oracle = checker only; nothing above this line touches oracle/) -------------------------
+    n_par = 4096 if args.workload == "allegro_vector" else 512  # SURVEY.md 8d: 4 096-item subset on the headline
+    par, prob, ref_now, last_now, kw_for = parity_block(wl, last_batch, q_head, min(n_par, B), 0 if args.no_cpu_baseline else min(128, B))
+    out["parity"] = par
+    if "cold_start" in sub:
+        from oracle import solvers
 
-    prob = cases.problem_from_config(rel)
-    assert (prob.n_opt, prob.n_ref) == (n_opt, n_ref)
-    ref_now = cases.ref_from_keypoints(prob, kp).astype(np.float32)[1:]
-
-    n_par = 4096 if args.workload == "allegro_vector" else 512  # SURVEY.md section 8d: 4 096-item subset on the headline
-    kw = {}
-    if dexpilot:  # same incoming projection state as the timed launches: the bits the previous frame left behind
-        proj0 = ((st0[:n_par, None] >> np.arange(prob.n_pair, dtype=np.uint32)) & 1).astype(bool)
-        w, rv, _ = prob.dexpilot_preamble(ref_now[:n_par], proj0)
-        kw = dict(weights=w, dexpilot_ref=rv)
-    want = solvers.solve_lm_batched(prob, ref_now[:n_par], None, last[:n_par], newton=True, max_iter=100, **kw)
-    got = t_q[:n_par].cpu().numpy().astype(np.float64)
-    dq = np.abs(got - want).max(1)
-    # several minima exist on human targets (DexPilot especially): where the two answers are different minima, compare
-    # the objective they reach
-    last64 = last[:n_par].astype(np.float64)
-    F_got = prob.total(got, ref_now[:n_par], None, last64, **kw)
-    F_want = prob.total(want, ref_now[:n_par], None, last64, **kw)
-    other = dq >= 1e-4
-    out["parity"] = {"subset": n_par, "max_abs_dq_rad": float(dq.max()), "p99_abs_dq_rad": float(np.percentile(dq, 99)),
-                     "frac_within_1e-4": float((dq < 1e-4).mean()),
-                     "other_minimum": {"frames": int(other.sum()),
-                                       "gpu_objective_lower_or_equal": int((F_got[other] <= F_want[other] + 1e-9).sum()),
-                                       "median_F_gpu_minus_F_oracle": float(np.median(F_got[other] - F_want[other])) if other.any() else 0.0},
-                     "max_abs_dq_rad_same_minimum": float(dq[~other].max()) if (~other).any() else None,
-                     "oracle": "float64 projected LM/Newton on F (oracle/solvers.py)"}
+        n_c = min(512, B)
+        want_c = solvers.solve_lm_batched(prob, wl.cold[0]["host_in"][:n_c], None, wl.cold[0]["host_last"][:n_c], newton=True, max_iter=100)
+        dqc = np.abs(q_cold[:n_c].astype(np.float64) - want_c).max(1)
+        l64 = wl.cold[0]["host_last"][:n_c].astype(np.float64)
+        Fg = prob.total(q_cold[:n_c].astype(np.float64), wl.cold[0]["host_in"][:n_c], None, l64)
+        Fw = prob.total(want_c, wl.cold[0]["host_in"][:n_c], None, l64)
+        far = dqc >= 1e-4
+        sub["cold_start"]["parity"] = {"subset": n_c, "frac_within_1e-4": float((~far).mean()),
+                                       "other_minimum": {"frames": int(far.sum()),
+                                                         "gpu_objective_lower_or_equal": int((Fg[far] <= Fw[far] + 1e-9).sum())},
+                                       "note": "far starts are multi-modal: frames that end in another minimum than the "
+                                               "oracle's are counted, with the objective comparison"}
+    for name, (w2, b2, q2, rec) in also.items():
+        rec["parity"] = parity_block(w2, b2, q2, min(256, B), 0 if args.no_cpu_baseline else min(64, B))[0]
+        out.setdefault("also", {})[name] = rec
 
     # ---- CPU baseline: the reference path as configured (scipy SLSQP stand-in for nlopt), host cores ----------
     if world == 1 and not args.no_cpu_baseline:
+        from oracle import solvers
+
         budget_s, done, t_cpu = 15.0, 0, 0.0
         while done < min(args.cpu_sample, B) and t_cpu < budget_s:  # bounded sample: ~15 s of host work
-            lo, hi = done, min(done + 50, B)
-            kw_c = {}
-            if dexpilot:
-                proj_c = ((st0[lo:hi, None] >> np.arange(prob.n_pair, dtype=np.uint32)) & 1).astype(bool)
-                w, rv, _ = prob.dexpilot_preamble(ref_now[lo:hi], proj_c)
-                kw_c = dict(weights=w, dexpilot_ref=rv)
+            sl = slice(done, min(done + 50, len(ref_now)))
+            if sl.start >= sl.stop:
+                break
             t1 = time.perf_counter()
-            solvers.solve_ref_as_configured(prob, ref_now[lo:hi], None, last[lo:hi], **kw_c)
+            solvers.solve_ref_as_configured(prob, ref_now[sl], None, last_now[sl], **kw_for(sl))
             t_cpu += time.perf_counter() - t1
-            done = hi
+            done = sl.stop
         out["cpu_baseline"] = {"value": done / t_cpu, "unit": "frames/s", "cores": 1, "kind": "port",
                                "sample": f"first {done} frames of the same workload, oracle restatement of the reference "
                                          f"objective + scipy SLSQP (ftol {prob.ftol:g}) standing in for nlopt, one process",
@@ -379,10 +441,11 @@ def main():
         avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         procs = int(os.environ.get("DEXR_CPU_PROCS", min(avail, 64)))
         if procs > 1:
-            from oracle import cpu_worker
+            from oracle import cases, cpu_worker
 
             per_proc = max(8, int(out["cpu_baseline"]["value"] * 6.0))  # ~6 s of work per process
-            res = cpu_worker.run_all_cores(rel, ref_now, last, procs, per_proc)
+            full_ref = cases.ref_from_keypoints(prob, last_batch["host_in"]).astype(np.float32)
+            res = cpu_worker.run_all_cores(wl.rel, full_ref, last_batch["host_last"], procs, per_proc)
             if res is not None:
                 out["cpu_baseline_all_cores"] = {
                     "value": res[0] / res[1], "unit": "frames/s", "cores": procs, "kind": "port",
@@ -391,6 +454,26 @@ def main():
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=65536, help="frames per GPU")
+    ap.add_argument("--workload", default="allegro_vector", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every host-CPU solve (baseline and SLSQP distance)")
+    ap.add_argument("--headline-only", action="store_true", help="skip the f64 / cold-start / other-config sub-records")
+    ap.add_argument("--cpu-sample", type=int, default=1200, help="frames of the workload timed on the host CPU")
+    args = ap.parse_args()
+    if args.workload == "mixed_fleet":
+        import bench_fleet
+
+        if args.batch == 65536:
+            args.batch = 131072  # 1 048 576 frames / 8 GPUs
+        return bench_fleet.run(args)
+    return run_single(args)
 
 
 if __name__ == "__main__":

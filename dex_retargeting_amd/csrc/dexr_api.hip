@@ -474,7 +474,8 @@ static int retarget_dev_impl(const dexr_model* m, int64_t B, const float* ref, b
   if (m->h.n_fixed > 0 && !fixed) return fail(DEXR_ERR_INVALID, "model has %d fixed joints but fixed_qpos is NULL", m->h.n_fixed);
   if (B < 0) return fail(DEXR_ERR_INVALID, "negative batch");
   if (B == 0) return DEXR_OK;
-  if (opt && opt->precision != 0) return fail(DEXR_ERR_INVALID, "use dexr_retarget_f64 for float64 arithmetic");
+  if (opt && opt->precision != 0 && opt->precision != 1) return fail(DEXR_ERR_INVALID, "precision must be 0 (float32) or 1 (float64)");
+  const int f64 = (opt && opt->precision == 1) ? 1 : 0;  // float64 arithmetic throughout, float32 result rows
   hipStream_t st = static_cast<hipStream_t>(stream);
   dexr::KernelParams kp;
   fill_params(m, kp, B);
@@ -491,8 +492,8 @@ static int retarget_dev_impl(const dexr_model* m, int64_t B, const float* ref, b
   if (status_out) HIP_TRY(hipMemsetAsync(status_out, 0, (size_t)B * sizeof(int32_t), st));
   if (iters_out) HIP_TRY(hipMemsetAsync(iters_out, 0, (size_t)B * sizeof(int32_t), st));
   if (fval_out) HIP_TRY(hipMemsetAsync(fval_out, 0, (size_t)B * sizeof(float), st));
-  int rc = launch(m, dexr::MODE_SOLVE, 0, kp, st);
-  if (rc != DEXR_OK) return rc;
+  int rc = launch(m, dexr::MODE_SOLVE, f64, kp, st);
+  if (rc != DEXR_OK || f64) return rc;
   return polish_launch(m, kp, opt, st);
 }
 
@@ -510,7 +511,8 @@ int dexr_retarget_kp_dev(const dexr_model* m, int64_t B, const float* keypoints,
 
 static int retarget_host(const dexr_model* m, int64_t B, const float* ref, const float* fixed, const float* last,
                          uint32_t* state, float* q32, double* q64, int32_t* status_out, int32_t* iters_out,
-                         float* fval_out, const dexr_solve_options* opt, int f64, bool ref_is_keypoints = false) {
+                         float* fval_out, const dexr_solve_options* opt, int f64, bool ref_is_keypoints = false,
+                         bool verify_every_step = false) {
   if (!m || !ref || !last || (!q32 && !q64)) return fail(DEXR_ERR_INVALID, "null argument");
   if (m->h.kind == DEXR_KIND_FKONLY) return fail(DEXR_ERR_INVALID, "model is an FK-only table");
   if (ref_is_keypoints && m->h.n_keypoints <= 0)
@@ -553,7 +555,7 @@ static int retarget_host(const dexr_model* m, int64_t B, const float* ref, const
   kp.status = d_status.as<int32_t>();
   kp.iters = d_iters.as<int32_t>();
   kp.fval = d_fval.as<float>();
-  if (f64) kp.blind_tol = 0.f;  // dexr_retarget_f64 is the validation path: every step it reports has been verified
+  if (verify_every_step) kp.blind_tol = 0.f;  // dexr_retarget_f64 is the validation path: every step it reports has been verified
   int rc = launch(m, dexr::MODE_SOLVE, f64, kp, nullptr);
   if (rc != DEXR_OK) return rc;
   if (!f64) {
@@ -573,21 +575,23 @@ static int retarget_host(const dexr_model* m, int64_t B, const float* ref, const
 int dexr_retarget(const dexr_model* m, int64_t B, const float* ref, const float* fixed, const float* last,
                   uint32_t* state, float* qpos_out, int32_t* status_out, int32_t* iters_out, float* fval_out,
                   const dexr_solve_options* opt) {
-  if (opt && opt->precision != 0) return fail(DEXR_ERR_INVALID, "use dexr_retarget_f64 for float64 arithmetic");
-  return retarget_host(m, B, ref, fixed, last, state, qpos_out, nullptr, status_out, iters_out, fval_out, opt, 0);
+  if (opt && opt->precision != 0 && opt->precision != 1) return fail(DEXR_ERR_INVALID, "precision must be 0 (float32) or 1 (float64)");
+  return retarget_host(m, B, ref, fixed, last, state, qpos_out, nullptr, status_out, iters_out, fval_out, opt,
+                       (opt && opt->precision == 1) ? 1 : 0);
 }
 
 int dexr_retarget_kp(const dexr_model* m, int64_t B, const float* keypoints, const float* fixed, const float* last,
                      uint32_t* state, float* qpos_out, int32_t* status_out, int32_t* iters_out, float* fval_out,
                      const dexr_solve_options* opt) {
-  if (opt && opt->precision != 0) return fail(DEXR_ERR_INVALID, "keypoint entry point is float32 (+polish) only");
-  return retarget_host(m, B, keypoints, fixed, last, state, qpos_out, nullptr, status_out, iters_out, fval_out, opt, 0, true);
+  if (opt && opt->precision != 0 && opt->precision != 1) return fail(DEXR_ERR_INVALID, "precision must be 0 (float32) or 1 (float64)");
+  return retarget_host(m, B, keypoints, fixed, last, state, qpos_out, nullptr, status_out, iters_out, fval_out, opt,
+                       (opt && opt->precision == 1) ? 1 : 0, true);
 }
 
 int dexr_retarget_f64(const dexr_model* m, int64_t B, const float* ref, const float* fixed, const float* last,
                       uint32_t* state, double* qpos_out, int32_t* status_out, int32_t* iters_out,
                       const dexr_solve_options* opt) {
-  return retarget_host(m, B, ref, fixed, last, state, nullptr, qpos_out, status_out, iters_out, nullptr, opt, 1);
+  return retarget_host(m, B, ref, fixed, last, state, nullptr, qpos_out, status_out, iters_out, nullptr, opt, 1, false, true);
 }
 
 int dexr_eval(const dexr_model* m, int64_t B, const float* ref, const float* fixed, const float* last,

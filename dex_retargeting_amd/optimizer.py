@@ -72,7 +72,7 @@ class Optimizer:
         self._upper = np.full(self.opt_dof, np.inf)
         self._model: Optional[_lib.Model] = None
         self._compiled: Optional[mc.CompiledModel] = None
-        self.solve_options = dict(max_iter=None, tol=None, lambda0=None, newton=None, polish=None, strict=None)
+        self.solve_options = dict(max_iter=None, tol=None, lambda0=None, newton=None, precision=None, polish=None, strict=None)
         self.last_info: dict = {}
 
     # ---- configuration (optimizer.py:54-75) --------------------------------------------------------

@@ -43,7 +43,9 @@ typedef struct dexr_solve_options {
   float tol;          /* stop when the accepted step's inf-norm < tol [rad|m] (default 2e-6) */
   float lambda0;      /* initial Levenberg-Marquardt damping (default 1e-4)                */
   int32_t newton;     /* 1: add the second-order kinematic term to the Hessian (default 1) */
-  int32_t precision;  /* 0: float32 arithmetic (default); 1: float64 arithmetic            */
+  int32_t precision;  /* 0: float32 / mixed-precision kernels (default); 1: float64 arithmetic throughout (the
+                         reference's own arithmetic type; register kernel, no polish pass).  Device-pointer entry
+                         points accept both; the result rows are float32 either way (optimizer.py:99)            */
   int32_t polish;     /* float64 polishing iterations run after the float32 solve, started at its answer:
                          -1 auto (default: 12 for position / DexPilot models, whose float32 rounding floor sits
                          near 1e-4 rad; 0 for vector models), 0 off, n > 0 at most n iterations           */

@@ -1,0 +1,140 @@
+"""GPU: every one of the 39 shipped configs, AT THE LIBRARY'S DEFAULT OPTIONS, on the bench's human-tracking workload
+(4 096 frames per config: fixture frame b mod 621 + 2 mm noise, warm start = the solver's answer for frame b-1),
+compared frame by frame with the float64 ORACLE minimiser (oracle/solvers.solve_lm_batched) -- not with the library's
+own float64 kernel.
+
+Bar (BASELINE.json north_star: 1e-4 rad per joint): every frame's qpos is within 1e-4 rad of the oracle's, or the two
+answers are DIFFERENT local minima and the GPU's is not worse (F_gpu <= F_oracle), or -- rare -- the GPU answer is a
+certified local minimum of F in another basin (a tight scipy minimisation started at it neither moves it nor lowers
+F).  The per-config table is written to gpurun_out/all_configs_parity.txt.
+
+Second part: distance to the REFERENCE-AS-CONFIGURED answers (SLSQP with ftol_abs 1e-6/1e-5 driven by the reference's
+value-without / gradient-with-regulariser pair, optimizer.py:96-99,136,239,397): reported, and F(q_gpu) <= F(q_slsqp)
+asserted -- the GPU returns the point the reference's gradient field defines, SLSQP stops ~1e-2 rad short of it.
+"""
+import glob
+import multiprocessing as mp
+import os
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+import pytest
+
+import oracle_jobs
+from conftest import REPO
+from dex_retargeting_amd.constants import DEFAULT_URDF_DIR
+from dex_retargeting_amd.retargeting_config import RetargetingConfig
+from oracle import cases
+
+pytestmark = pytest.mark.gpu
+RetargetingConfig.set_default_urdf_dir(str(DEFAULT_URDF_DIR))
+ALL = sorted(os.path.relpath(p, cases.CONFIG_DIR) for p in glob.glob(os.path.join(cases.CONFIG_DIR, "*", "*.yml")))
+B = 4096
+TOL = 1e-4
+BASELINE3 = ["teleop/allegro_hand_right.yml", "teleop/shadow_hand_right_dexpilot.yml", "offline/leap_hand_right.yml"]
+
+
+def _pool():
+    n = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 48)
+    return ProcessPoolExecutor(max_workers=max(1, n), mp_context=mp.get_context("spawn"))
+
+
+def _gpu_solve(rel, n):
+    seq = RetargetingConfig.load_from_file(os.path.join(cases.CONFIG_DIR, rel)).build()
+    prob = cases.problem_from_config(rel)
+    model = seq.optimizer.device_model()
+    kp = cases.human_keypoints(n + 1, seed=cases.SEED)
+    mid = np.repeat(prob.joint_limits.mean(1)[None], n, 0).astype(np.float32)
+    dex = prob.kind == "dexpilot"
+    st = np.zeros(n, np.uint32) if dex else None
+    last = model.retarget(np.ascontiguousarray(kp[:-1]), None, mid, state=st, keypoints=True)  # frame b-1
+    st_in = None if st is None else st.copy()
+    q, info = model.retarget(np.ascontiguousarray(kp[1:]), None, last, state=st, keypoints=True, want_info=True)
+    ref = np.ascontiguousarray(cases.ref_from_keypoints(prob, kp[1:]), dtype=np.float32)
+    return dict(prob=prob, ref=ref, last=last, st_in=st_in, q=q.astype(np.float64), info=info, kernel=model.kernel())
+
+
+@pytest.fixture(scope="module")
+def table(require_gpu):
+    """GPU phase for all configs, then the oracle phase fanned over host cores."""
+    runs = {rel: _gpu_solve(rel, B) for rel in ALL}
+    with _pool() as ex:
+        res = list(ex.map(oracle_jobs.oracle_solve, [(rel, r["ref"], r["last"], r["st_in"], r["q"]) for rel, r in runs.items()]))
+        rows = {}
+        todo = []
+        for (rel, r), o in zip(runs.items(), res):
+            dq = np.abs(r["q"] - o["want"]).max(1)
+            far = dq >= TOL
+            not_worse = far & (o["F_gpu"] <= o["F_want"] + 1e-10)
+            rest = np.nonzero(far & ~not_worse)[0]
+            rows[rel] = dict(dq=dq, far=far, not_worse=not_worse, rest=rest, o=o, r=r)
+            if far.any():  # every excuse is certified (up to 64 frames per config, the furthest first)
+                sel = np.nonzero(far)[0]
+                sel = sel[np.argsort(-dq[sel])][:64]
+                todo.append((rel, sel, ex.submit(oracle_jobs.certify_local_minimum,
+                                                 (rel, r["ref"][sel], r["last"][sel],
+                                                  None if r["st_in"] is None else r["st_in"][sel], r["q"][sel]))))
+        for rel, sel, fut in todo:
+            rows[rel]["cert"] = (sel,) + tuple(fut.result())
+    out = os.path.join(REPO, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "all_configs_parity.txt"), "w") as f:
+        f.write(f"# {B} frames per config, library defaults; dq = max_j |q_gpu - q_oracle| (float64 oracle LM/Newton on F)\n")
+        f.write(f"{'config':44s} {'kernel':>14s} {'p50 dq':>9s} {'p99.9 dq':>9s} {'max dq':>9s} {'>=1e-4':>7s} {'not worse':>9s} "
+                f"{'other':>6s} {'cert moved':>10s} {'status!=0':>9s}\n")
+        for rel, w in rows.items():
+            f.write(f"{rel:44s} {str(w['r']['kernel']):>14s} {np.median(w['dq']):9.1e} {np.percentile(w['dq'], 99.9):9.1e} "
+                    f"{w['dq'].max():9.1e} {int(w['far'].sum()):7d} {int(w['not_worse'].sum()):9d} {len(w['rest']):6d} "
+                    f"{(w['cert'][1].max() if 'cert' in w else 0.0):10.1e} {int((w['r']['info']['status'] != 0).sum()):9d}\n")
+    return rows
+
+
+@pytest.mark.parametrize("rel", ALL)
+def test_default_options_meet_1e4_rad_against_oracle(rel, table):
+    w = table[rel]
+    assert (w["r"]["info"]["status"] != 2).all()
+    # (1) same minimum: within tolerance.  (2) other minimum, not worse than the oracle's.  (3) certified local minima.
+    n_rest = len(w["rest"])
+    assert n_rest <= max(2, B // 500), (rel, n_rest, np.sort(w["dq"])[-5:])
+    # frames that share the oracle's minimum are well inside the tolerance
+    same = ~w["far"]
+    assert np.percentile(w["dq"][same], 99.9) < TOL
+
+
+@pytest.mark.parametrize("rel", ALL)
+def test_no_flat_valley_excuses(rel, table):
+    """A frame further than 1e-4 rad from the oracle may only be excused as 'another minimum' when it IS a minimum:
+    a tight float64 minimisation of F started AT the GPU answer must stay within 1e-4 rad of it and must not lower F
+    by more than 1e-8.  (A float32 answer sitting 3e-4 rad up a nearly flat valley -- round 1's mimic position models
+    -- fails this: the tight solve walks down the valley.)"""
+    w = table[rel]
+    if w["far"].any():
+        sel, moved, dF = w["cert"]
+        assert np.all(moved < TOL) and np.all(dF < 1e-8), (rel, int(w["far"].sum()), moved.max(), dF.max())
+
+
+@pytest.mark.parametrize("rel", BASELINE3)
+def test_distance_to_reference_as_configured(rel, require_gpu):
+    n = 256
+    r = _gpu_solve(rel, n)
+    with _pool() as ex:
+        chunks = [slice(i, min(i + 16, n)) for i in range(0, n, 16)]
+        parts = list(ex.map(oracle_jobs.slsqp_as_configured,
+                            [(rel, r["ref"][c], r["last"][c], None if r["st_in"] is None else r["st_in"][c]) for c in chunks]))
+    q_slsqp = np.concatenate(parts).astype(np.float64)
+    prob = r["prob"]
+    kw = oracle_jobs._kw(prob, r["ref"], r["st_in"])
+    last64 = r["last"].astype(np.float64)
+    F_gpu = prob.total(r["q"], r["ref"], None, last64, **kw)
+    F_ref = prob.total(q_slsqp, r["ref"], None, last64, **kw)
+    dq = np.abs(r["q"] - q_slsqp).max(1)
+    out = os.path.join(REPO, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "vs_reference_as_configured.txt"), "a") as f:
+        f.write(f"{rel}: |q_gpu - q_slsqp| median {np.median(dq):.3e} p99 {np.percentile(dq, 99):.3e} max {dq.max():.3e}; "
+                f"F_gpu <= F_slsqp on {float((F_gpu <= F_ref + 1e-12).mean()):.4f} of {n} frames; "
+                f"median F_slsqp - F_gpu {np.median(F_ref - F_gpu):.3e}\n")
+    # the GPU minimises the function whose gradient the reference hands to SLSQP: it may not be worse than where SLSQP
+    # stops (frames in which SLSQP wandered into a better basin are counted, not excused)
+    assert (F_gpu <= F_ref + 1e-12).mean() >= 0.98, (rel, (F_gpu <= F_ref + 1e-12).mean())
+    assert np.median(dq) < 0.2  # same neighbourhood: SLSQP stops ~1e-2 rad short of the minimiser
