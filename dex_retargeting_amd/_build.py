@@ -61,6 +61,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     objs.append(prep_o)
     if force or _stale(prep_o, [prep_s, os.path.join(INCLUDE, "dexr.h")]):
         jobs.append((prep_s, prep_o, []))
+    aux_s, aux_o = os.path.join(CSRC, "dexr_aux.hip"), os.path.join(BUILD, "dexr_aux.o")
+    objs.append(aux_o)
+    if force or _stale(aux_o, [aux_s, os.path.join(INCLUDE, "dexr.h")]):
+        jobs.append((aux_s, aux_o, []))
     inst_s = os.path.join(CSRC, "dexr_inst.hip")
     # developer shortcut: DEXR_BUILD_ONLY="4,8" rebuilds only those buckets and reuses the other objects as they are
     # (only valid while KernelParams / the launcher signature are unchanged)
@@ -93,6 +97,16 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             continue
         if force or _stale(o, [quad_s, QUAD_HEADER, BIG_HEADER] + HEADERS):
             jobs.append((quad_s, o, NO_SLP + [f"-DDEXR_NMAX={n}"]))
+    for n, f64 in ((4, 0), (8, 0), (4, 1), (8, 1)):  # small components with fleet / sequence addressing (EXT)
+        o = os.path.join(BUILD, f"dexr_inst_ext_{n}_{f64}_0.o")
+        objs.append(o)
+        if force or _stale(o, [inst_s] + HEADERS):
+            jobs.append((inst_s, o, NO_SLP + [f"-DDEXR_NMAX={n}", f"-DDEXR_F64={f64}", "-DDEXR_MODE=0", "-DDEXR_EXT=1"]))
+    for n in CHAIN_BUCKETS:
+        o = os.path.join(BUILD, f"dexr_inst_ext_chain_{n}_0_0.o")
+        objs.append(o)
+        if force or _stale(o, [inst_s] + HEADERS):
+            jobs.append((inst_s, o, NO_SLP + [f"-DDEXR_NMAX={n}", "-DDEXR_F64=0", "-DDEXR_MODE=0", "-DDEXR_CHAIN=1", "-DDEXR_EXT=1"]))
     for n in CHAIN_BUCKETS:  # serial-chain specialisation, float32 solve only
         o = os.path.join(BUILD, f"dexr_inst_chain_{n}_0_0.o")
         objs.append(o)

@@ -36,7 +36,8 @@ KERNEL_AUTO, KERNEL_REGISTER, KERNEL_QUAD, KERNEL_LDS = -1, 0, 1, 2
 
 EXPORTS = ["dexr_last_error", "dexr_version", "dexr_device_count", "dexr_default_options", "dexr_model_create",
            "dexr_model_destroy", "dexr_model_info", "dexr_model_get_tuning", "dexr_model_set_tuning", "dexr_model_kernel",
-           "dexr_retarget_dev", "dexr_retarget", "dexr_retarget_f64",
+           "dexr_retarget_dev", "dexr_retarget_seq_dev", "dexr_seq_compose_dev", "dexr_fleet_workspace_bytes",
+           "dexr_retarget_multi_dev", "dexr_retarget", "dexr_retarget_f64",
            "dexr_retarget_kp_dev", "dexr_retarget_kp", "dexr_eval", "dexr_fk", "dexr_mano_keypoints_dev",
            "dexr_mano_keypoints"]
 
@@ -73,6 +74,13 @@ def load() -> C.CDLL:
     lib.dexr_model_set_tuning.argtypes = [vp, C.POINTER(Tuning)]
     lib.dexr_model_kernel.argtypes = [vp, i32p, i32p, i32p]
     lib.dexr_retarget_dev.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, optp, vp]
+    lib.dexr_retarget_seq_dev.argtypes = [vp, i64, C.c_int32, vp, C.c_int32, vp, vp, vp, vp, vp, C.c_float, optp, vp]
+    lib.dexr_seq_compose_dev.argtypes = [i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, f64p, f64p, vp, vp,
+                                         C.c_double, vp, C.c_int32, vp, vp]
+    lib.dexr_fleet_workspace_bytes.argtypes = [i64]
+    lib.dexr_fleet_workspace_bytes.restype = C.c_size_t
+    lib.dexr_retarget_multi_dev.argtypes = [C.POINTER(vp), C.c_int32, i64, vp, vp, vp, C.c_int32, vp, vp, vp, optp, vp,
+                                            C.c_size_t, vp]
     lib.dexr_retarget.argtypes = [vp, i64, f32p, f32p, f32p, u32p, f32p, i32p, i32p, f32p, optp]
     lib.dexr_retarget_kp_dev.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, optp, vp]
     lib.dexr_retarget_kp.argtypes = [vp, i64, f32p, f32p, f32p, u32p, f32p, i32p, i32p, f32p, optp]
@@ -205,6 +213,14 @@ class Model:
         check(lib.dexr_fk(self._h, B, _ptr(q, C.c_double), _ptr(out, C.c_double)))
         return out
 
+    def retarget_seq_dev(self, B: int, T: int, inputs_ptr: int, fixed_ptr: int, last_ptr: int, state_ptr: int,
+                         qraw_ptr: int, status_ptr: int = 0, joint_limit_eps: float = 1e-3,
+                         opts: Optional[SolveOptions] = None, stream: int = 0, keypoints: bool = True):
+        """T frames of B sequences in one launch (dexr_retarget_seq_dev); device addresses of C-contiguous arrays."""
+        check(load().dexr_retarget_seq_dev(self._h, B, T, inputs_ptr or None, 1 if keypoints else 0, fixed_ptr or None,
+                                           last_ptr or None, state_ptr or None, qraw_ptr or None, status_ptr or None,
+                                           joint_limit_eps, C.byref(opts) if opts is not None else None, stream or None))
+
     # device-pointer entry point (torch tensors on the current device) ------------------------------
     def retarget_dev(self, B: int, ref_ptr: int, fixed_ptr: int, last_ptr: int, state_ptr: int, q_ptr: int,
                      status_ptr: int = 0, iters_ptr: int = 0, fval_ptr: int = 0,
@@ -215,3 +231,32 @@ class Model:
         check(fn(self._h, B, ref_ptr or None, fixed_ptr or None, last_ptr or None,
                  state_ptr or None, q_ptr or None, status_ptr or None, iters_ptr or None,
                  fval_ptr or None, C.byref(opts) if opts is not None else None, stream or None))
+
+
+def seq_compose_dev(B: int, T: int, dof_kind, dof_idx, dof_mult, dof_off, n_opt: int, n_fixed: int, qraw_ptr: int,
+                    fixed_ptr: int, alpha: float, filter_ptr: int, first_frame_initialises: bool, out_ptr: int,
+                    stream: int = 0):
+    """robot-qpos composition + mimic fill + low-pass filter for T x B frames (dexr_seq_compose_dev)."""
+    kind = np.ascontiguousarray(dof_kind, dtype=np.int32)
+    idx = np.ascontiguousarray(dof_idx, dtype=np.int32)
+    mult = np.ascontiguousarray(dof_mult, dtype=np.float64)
+    off = np.ascontiguousarray(dof_off, dtype=np.float64)
+    check(load().dexr_seq_compose_dev(B, T, len(kind), n_opt, n_fixed, _ptr(kind, C.c_int32), _ptr(idx, C.c_int32),
+                                      _ptr(mult, C.c_double), _ptr(off, C.c_double), qraw_ptr or None, fixed_ptr or None,
+                                      float(alpha), filter_ptr or None, 1 if first_frame_initialises else 0,
+                                      out_ptr or None, stream or None))
+
+
+def fleet_workspace_bytes(B: int) -> int:
+    return int(load().dexr_fleet_workspace_bytes(B))
+
+
+def retarget_multi_dev(models, B: int, model_id_ptr: int, kp_ptr: int, last_ptr: int, ld: int, state_ptr: int,
+                       q_ptr: int, status_ptr: int, ws_ptr: int, ws_bytes: int, opts: Optional[SolveOptions] = None,
+                       stream: int = 0):
+    """Mixed-fleet batch (dexr_retarget_multi_dev): `models` is a list of Model handles."""
+    arr = (C.c_void_p * len(models))(*[m.handle for m in models])
+    check(load().dexr_retarget_multi_dev(arr, len(models), B, model_id_ptr or None, kp_ptr or None, last_ptr or None, ld,
+                                         state_ptr or None, q_ptr or None, status_ptr or None,
+                                         C.byref(opts) if opts is not None else None, ws_ptr or None, ws_bytes,
+                                         stream or None))

@@ -107,6 +107,7 @@ void fill_params(const dexr_model* m, dexr::KernelParams& kp, int64_t B) {
   kp.lds_frames = m->lds_frames;
   kp.lds_terms = m->lds_terms;
   kp.n_kp = h.n_keypoints;
+  kp.ld = h.n_opt;  // plain batches: rows of last / qout are n_opt long
   for (int i = 0; i < DEXR_MAXT; ++i) {
     kp.h_origin[i] = h.human_origin[i];
     kp.h_task[i] = h.human_task[i];
@@ -169,6 +170,8 @@ int launch_quad(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
 
 int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStream_t st) {
   if (kp.B <= 0) return DEXR_OK;
+  // fleet buckets / frame sequences / padded rows need the kernels with extended addressing (KernelParams)
+  const bool ext = kp.perm != nullptr || kp.bucket != nullptr || kp.T > 0 || kp.ld != kp.n_opt;
   if (mode == dexr::MODE_SOLVE && !f64 && m->quad) {
     return launch_quad(m, kp, st);
   }
@@ -207,7 +210,7 @@ int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStr
   }
   const int64_t blocks = (waves + wpb - 1) / wpb;
   if (blocks > 0x7fffffffLL) return fail(DEXR_ERR_INVALID, "batch too large for one launch");
-  dexr::launch_fn fn = dexr::find_launcher(m->bucket, f64, mode, m->chain);
+  dexr::launch_fn fn = dexr::find_launcher(m->bucket, f64, mode, m->chain, ext);
   if (!fn) return fail(DEXR_ERR_UNSUPPORTED, "no kernel for bucket %d / f64=%d / mode=%d", m->bucket, f64, mode);
   hipError_t e = fn(kp, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, st);
   if (e != hipSuccess) return fail(DEXR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -232,11 +235,13 @@ void default_tuning(dexr_model* m) {
   t.stall_from = 2;
   t.stall_ratio = 0.9f;
   t.stall_cap = 20.f;
-  t.lam_jump = m->bucket <= 8 ? 1.0f : 0.3f;
+  t.lam_jump = m->bucket <= 8 ? 3.0f : 0.3f;
   t.lam_fastdec = m->bucket <= 8 ? 0.1f : 0.f;
   t.floor_scale = 1e-12f;
   t.step_cap = 0.3f;
-  t.blind_tol_scale = 10.f;
+  // small components: a verified, undamped Newton step below 100 tol (2e-4 rad) leaves an error of ~C s^2 < 1e-6 rad
+  // (tools/lm_lab.py: max 8.6e-7 over 1 863 frames) and saves the confirming pass: mean 4.3 -> 3.9 passes per frame
+  t.blind_tol_scale = m->bucket <= 8 ? 100.f : 10.f;
 }
 
 // Which float32 solve kernel serves the model.  Measured on MI355X (65 536 frames, tools/all_configs.py,
@@ -288,15 +293,31 @@ void apply_options(const dexr_model* m, dexr::KernelParams& kp, const dexr_solve
 
 // Optional float64 polish: same kernel in double precision, started at the float32 answer (x0 = qout, in place),
 // regularised towards the ORIGINAL last_qpos.  Stream-ordered after the float32 launch.
-int polish_launch(const dexr_model* m, dexr::KernelParams kp, const dexr_solve_options* opt, hipStream_t st) {
+bool polish_wanted(const dexr_model* m, const dexr_solve_options* opt) {
   int polish = opt ? opt->polish : -1;
   if (polish < 0) polish = (m->h.kind == DEXR_KIND_POSITION || m->h.kind == DEXR_KIND_DEXPILOT) ? 12 : 0;
-  if (polish == 0 || m->bucket == 32) return DEXR_OK;
-  if ((m->big || m->quad) && !(opt && opt->strict)) return DEXR_OK;  // those ran with float64 kinematics
+  if (polish == 0 || m->bucket == 32) return false;
+  const int strict = opt ? opt->strict : 0;
+  if ((m->big || m->quad) && !(strict > 0 || (strict == 0 && m->has_mimic))) return false;
+  return true;
+}
+
+// The mixed-precision kernels (float64 kinematics, float32 gradient / Hessian) need no polish -- except on models
+// with mimic joints, whose objective has nearly flat valleys (net curvature ~3e-4: the indefinite second-order term
+// almost cancels the regulariser) in which a float32 gradient error of 1e-7 moves the stationary point by up to
+// 4e-4 rad (round 1: Ability / Inspire / SVH position models had 0.01-0.6 % of frames between 1e-4 and 4e-4 rad of
+// the float64 minimiser).  Those models get the float64 polish by default (polish_wanted); strict = 1 forces it for
+// every model, strict = -1 never polishes after the mixed-precision kernels.
+int polish_launch(const dexr_model* m, dexr::KernelParams kp, const dexr_solve_options* opt, hipStream_t st) {
+  if (!polish_wanted(m, opt)) return DEXR_OK;
+  int polish = opt ? opt->polish : -1;
+  if (polish < 0) polish = 12;
   kp.x0 = kp.qout;
   kp.max_iter = polish;
   kp.tol *= 0.25f;
+  kp.blind_tol = 10.f * kp.tol;  // the polish pass confirms its steps down to its own (tighter) tolerance
   kp.fval = nullptr;  // fval/iters keep the float32 launch's diagnostics; status is the polish pass's verdict
+  if (kp.perm) kp.status = nullptr;  // fleet batches share one status array: it keeps the first launch's verdict
   if (kp.status) HIP_TRY(hipMemsetAsync(kp.status, 0, (size_t)kp.B * sizeof(int32_t), st));
   return launch(m, dexr::MODE_SOLVE, 1, kp, st);
 }
@@ -305,6 +326,13 @@ int polish_launch(const dexr_model* m, dexr::KernelParams kp, const dexr_solve_o
 
 // dexr_prep.hip
 int dexr_prep_launch(int64_t B, const float* kp, const float* op9, float* out, float* rot, hipStream_t st);
+// dexr_aux.hip
+size_t dexr_fleet_ws_ints();
+hipError_t dexr_fleet_bucket_launch(int n_models, int64_t B, const int32_t* model_id, int32_t* ws, hipStream_t st);
+hipError_t dexr_seq_compose_launch(int64_t B, int T, int n_q, int n_opt, int n_fixed, const int32_t* kind,
+                                   const int32_t* idx, const double* mult, const double* off, const float* qraw,
+                                   const float* fixed, double alpha, int use_filter, int first_frame_initialises,
+                                   double* filt, double* out, hipStream_t st);
 
 extern "C" {
 
@@ -658,6 +686,118 @@ int dexr_fk(const dexr_model* m, int64_t B, const double* q, double* pos_out) {
   if (rc != DEXR_OK) return rc;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(pos_out, d_p.p, p_b, hipMemcpyDeviceToHost));
+  return DEXR_OK;
+}
+
+int dexr_retarget_seq_dev(const dexr_model* m, int64_t B, int32_t T, const float* inputs, int32_t inputs_are_keypoints,
+                          const float* fixed, float* last_inout, uint32_t* state_inout, float* qpos_raw_out,
+                          int32_t* status_out, float joint_limit_eps, const dexr_solve_options* opt, void* stream) {
+  if (!m || !inputs || !last_inout || !qpos_raw_out) return fail(DEXR_ERR_INVALID, "null argument");
+  if (m->h.kind == DEXR_KIND_FKONLY) return fail(DEXR_ERR_INVALID, "model is an FK-only table");
+  if (inputs_are_keypoints && m->h.n_keypoints <= 0)
+    return fail(DEXR_ERR_INVALID, "model carries no target_link_human_indices: keypoint input not available");
+  if (m->h.n_fixed > 0 && !fixed) return fail(DEXR_ERR_INVALID, "model has %d fixed joints but fixed_qpos is NULL", m->h.n_fixed);
+  if (B < 0 || T < 0) return fail(DEXR_ERR_INVALID, "negative batch or sequence length");
+  if (!(joint_limit_eps >= 0.f)) return fail(DEXR_ERR_INVALID, "joint_limit_eps must be >= 0");
+  if (B == 0 || T == 0) return DEXR_OK;
+  if ((int64_t)T * B > 0x7fffffffLL) return fail(DEXR_ERR_INVALID, "T x B too large for one launch");
+  if (opt && opt->precision != 0 && opt->precision != 1) return fail(DEXR_ERR_INVALID, "precision must be 0 (float32) or 1 (float64)");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  dexr::KernelParams kp;
+  fill_params(m, kp, B);
+  apply_options(m, kp, opt);
+  if (inputs_are_keypoints) kp.kpts = inputs;
+  else kp.ref = inputs;
+  kp.fixed = fixed;
+  kp.last = last_inout;
+  kp.state = state_inout;
+  kp.qout = qpos_raw_out;
+  kp.status = status_out;
+  kp.T = T;
+  kp.seq_stride = B;
+  kp.clip_eps = joint_limit_eps;
+  if (status_out) HIP_TRY(hipMemsetAsync(status_out, 0, (size_t)T * (size_t)B * sizeof(int32_t), st));
+  // a polish launch cannot be interleaved with the carry: models that need it solve in float64 throughout
+  const int f64 = ((opt && opt->precision == 1) || polish_wanted(m, opt)) ? 1 : 0;
+  int rc = launch(m, dexr::MODE_SOLVE, f64, kp, st);
+  if (rc != DEXR_OK) return rc;
+  // SeqRetargeting.last_qpos after the last frame = its raw answer (seq_retarget.py:124)
+  HIP_TRY(hipMemcpyAsync(last_inout, qpos_raw_out + (size_t)(T - 1) * (size_t)B * m->h.n_opt,
+                         (size_t)B * m->h.n_opt * sizeof(float), hipMemcpyDeviceToDevice, st));
+  return DEXR_OK;
+}
+
+int dexr_seq_compose_dev(int64_t B, int32_t T, int32_t n_q, int32_t n_opt, int32_t n_fixed, const int32_t* dof_kind,
+                         const int32_t* dof_idx, const double* dof_mult, const double* dof_off, const float* qpos_raw,
+                         const float* fixed, double alpha, double* filter_inout, int32_t first_frame_initialises,
+                         double* robot_qpos_out, void* stream) {
+  if (!dof_kind || !dof_idx || !dof_mult || !dof_off || !qpos_raw || !robot_qpos_out) return fail(DEXR_ERR_INVALID, "null argument");
+  if (n_q < 1 || n_q > DEXR_MAX_DOF) return fail(DEXR_ERR_INVALID, "n_q=%d outside 1..%d", n_q, DEXR_MAX_DOF);
+  if (B < 0 || T < 0 || n_opt < 0 || n_fixed < 0) return fail(DEXR_ERR_INVALID, "negative size");
+  const bool use_filter = alpha >= 0.0 && alpha <= 1.0;
+  if (use_filter && !filter_inout) return fail(DEXR_ERR_INVALID, "a low-pass coefficient was given but filter_inout is NULL");
+  for (int j = 0; j < n_q; ++j) {
+    const int k = dof_kind[j], i = dof_idx[j];
+    const bool bad = k < 0 || k > 2 || i < 0 || (k == 0 && i >= n_opt) || (k == 1 && i >= n_fixed) ||
+                     (k == 2 && (i >= n_q || dof_kind[i] == 2));
+    if (bad) return fail(DEXR_ERR_INVALID, "dof %d: malformed source (kind %d, idx %d)", j, k, i);
+    if (k == 1 && !fixed) return fail(DEXR_ERR_INVALID, "dof %d is a fixed joint but fixed is NULL", j);
+  }
+  if (B == 0 || T == 0) return DEXR_OK;
+  const hipError_t e = dexr_seq_compose_launch(B, T, n_q, n_opt, n_fixed, dof_kind, dof_idx, dof_mult, dof_off, qpos_raw, fixed,
+                                               alpha, use_filter ? 1 : 0, first_frame_initialises ? 1 : 0, filter_inout,
+                                               robot_qpos_out, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(DEXR_ERR_HIP, "compose kernel launch failed: %s", hipGetErrorString(e));
+  return DEXR_OK;
+}
+
+size_t dexr_fleet_workspace_bytes(int64_t B) { return (dexr_fleet_ws_ints() + (size_t)(B > 0 ? B : 0)) * sizeof(int32_t); }
+
+int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, int64_t B, const int32_t* model_id,
+                            const float* keypoints, const float* last, int32_t ld, uint32_t* state, float* qpos_out,
+                            int32_t* status_out, const dexr_solve_options* opt, void* workspace, size_t workspace_bytes,
+                            void* stream) {
+  if (!models || !model_id || !keypoints || !last || !qpos_out || !workspace) return fail(DEXR_ERR_INVALID, "null argument");
+  if (n_models < 1 || n_models > DEXR_FLEET_MAX_MODELS) return fail(DEXR_ERR_INVALID, "n_models=%d outside 1..%d", n_models, DEXR_FLEET_MAX_MODELS);
+  if (B < 0) return fail(DEXR_ERR_INVALID, "negative batch");
+  if (B > 0x7fffffffLL) return fail(DEXR_ERR_INVALID, "batch too large for one call");
+  if (workspace_bytes < dexr_fleet_workspace_bytes(B)) return fail(DEXR_ERR_INVALID, "workspace of %zu B, %zu B needed", workspace_bytes, dexr_fleet_workspace_bytes(B));
+  if (opt && opt->precision != 0) return fail(DEXR_ERR_INVALID, "fleet batches run the float32 / mixed-precision kernels");
+  for (int i = 0; i < n_models; ++i) {
+    const dexr_model* m = models[i];
+    if (!m) return fail(DEXR_ERR_INVALID, "models[%d] is NULL", i);
+    if (m->h.kind == DEXR_KIND_FKONLY) return fail(DEXR_ERR_INVALID, "models[%d] is an FK-only table", i);
+    if (m->h.n_keypoints <= 0) return fail(DEXR_ERR_INVALID, "models[%d] carries no target_link_human_indices", i);
+    if (m->h.n_fixed > 0) return fail(DEXR_ERR_INVALID, "models[%d] has caller-supplied fixed joints: not supported in fleet batches", i);
+    if (m->h.n_opt > ld) return fail(DEXR_ERR_INVALID, "models[%d] optimises %d joints but rows are %d long", i, m->h.n_opt, ld);
+    if (m->h.kind == DEXR_KIND_DEXPILOT && !state) return fail(DEXR_ERR_INVALID, "models[%d] is a DexPilot model but state is NULL", i);
+  }
+  if (B == 0) return DEXR_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int32_t* ws = static_cast<int32_t*>(workspace);
+  hipError_t e = dexr_fleet_bucket_launch(n_models, B, model_id, ws, st);
+  if (e != hipSuccess) return fail(DEXR_ERR_HIP, "fleet bucketing launch failed: %s", hipGetErrorString(e));
+  if (status_out) HIP_TRY(hipMemsetAsync(status_out, 0, (size_t)B * sizeof(int32_t), st));
+  const int32_t* bucket = ws + 2 * DEXR_FLEET_MAX_MODELS;
+  const int32_t* perm = ws + dexr_fleet_ws_ints();
+  for (int i = 0; i < n_models; ++i) {
+    const dexr_model* m = models[i];
+    dexr::KernelParams kp;
+    fill_params(m, kp, B);  // B: upper bound of the bucket size (launch geometry); the kernel reads the real count
+    apply_options(m, kp, opt);
+    kp.kpts = keypoints;
+    kp.last = last;
+    kp.state = m->h.kind == DEXR_KIND_DEXPILOT ? state : nullptr;
+    kp.qout = qpos_out;
+    kp.status = status_out;
+    kp.ld = ld;
+    kp.perm = perm;
+    kp.bucket = bucket + 2 * i;
+    int rc = launch(m, dexr::MODE_SOLVE, 0, kp, st);
+    if (rc != DEXR_OK) return rc;
+    rc = polish_launch(m, kp, opt, st);
+    if (rc != DEXR_OK) return rc;
+  }
   return DEXR_OK;
 }
 

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
   const int64_t tile = wave_global / kp.n_comp;  // this wave's index among the waves of its component
   // PERSISTENT LANES (as in dexr_quad.hpp): a lane that finishes its frame stores it and takes the next one -- wave w
   // starts with the static tile [64 w, 64 w + 64), frames from kp.q0 on are handed out by the per-component queue.
-  int64_t item = 0;     // frame this lane is working on
+  int64_t item = 0;     // work item (frame, or sequence) this lane is working on
   bool active = false;  // the lane holds a frame
 
   float* Hl = reinterpret_cast<float*>(lds_raw) + lane;                                 // H(r,c) at Hl[hidx(r,c)*64]
@@ -60,6 +60,15 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
   const dexr_comp_table& tb = comps[comp];
   const int nj = tb.n_joint, nt = tb.n_term;
   const float delta = kp.norm_delta;
+  // number of work items and their rows: fleet buckets are sized and listed on the device (see KernelParams)
+  const int64_t nB = kp.bucket ? (int64_t)kp.bucket[1] : kp.B;
+  const int64_t pbase = kp.bucket ? (int64_t)kp.bucket[0] : 0;
+  auto row_of = [&](int64_t it) -> int64_t { return kp.perm ? (int64_t)kp.perm[pbase + it] : it; };
+  const int ld = kp.ld;
+  const bool seq = kp.T > 0;  // sequence mode: a work item is a sequence of kp.T frames solved in order by this lane
+  int64_t lrow = 0, irow = 0;  // row of the item's `last` / `state`; row of the current frame's inputs and outputs
+  int t_seq = 0;               // frame of the sequence being solved
+  const float* lastp = kp.last;
 
   uint32_t vmask = 0, optmask = 0;
   uint32_t revmask = 0;  // revolute joints: a wave-uniform bit mask, so the loops below test a bit instead of loading jtype
@@ -79,10 +88,10 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
 
   auto ref_row = [&](int row, float (&rv)[3]) {
     if (kp.kpts) {
-      const float* a = kp.kpts + (item * kp.n_kp + kp.h_task[row]) * 3;
+      const float* a = kp.kpts + (irow * kp.n_kp + kp.h_task[row]) * 3;
       const int o = kp.h_origin[row];
       if (o >= 0) {
-        const float* b = kp.kpts + (item * kp.n_kp + o) * 3;
+        const float* b = kp.kpts + (irow * kp.n_kp + o) * 3;
 #pragma unroll
         for (int i = 0; i < 3; ++i) rv[i] = a[i] - b[i];
       } else {
@@ -90,36 +99,51 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
         for (int i = 0; i < 3; ++i) rv[i] = a[i];
       }
     } else {
-      const float* r = kp.ref + (item * kp.n_ref + row) * 3;
+      const float* r = kp.ref + (irow * kp.n_ref + row) * 3;
 #pragma unroll
       for (int i = 0; i < 3; ++i) rv[i] = r[i];
     }
   };
-  auto xl = [&](int k) -> float { return kp.last[item * kp.n_opt + tb.api[k]]; };  // regularisation target (L1/L2 hit)
+  // regularisation target = start point of the frame (L1/L2 hit): `last` of the item, or -- sequence mode, frame
+  // t > 0 -- the previous frame's raw solution, which this lane has just stored to qout; clipped to the joint limits
+  // in sequence mode (seq_retarget.py:118-120)
+  auto xl = [&](int k) -> float {
+    float v;
+    if (seq && t_seq > 0)  // written by this wave a moment ago: read it coherently (bypassing the vector L1)
+      v = __hip_atomic_load(const_cast<float*>(lastp) + tb.api[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      v = lastp[tb.api[k]];
+    return seq ? fminf(fmaxf(v, tb.lo[k] + kp.clip_eps), tb.hi[k] - kp.clip_eps) : v;
+  };
 
   // DexPilot projection bits (optimizer.py:466-476) of the current frame
   uint32_t nst = 0;
   const bool dexpilot = kp.kind == DEXR_KIND_DEXPILOT;
   const int F_ = kp.num_fingers, n_pair = F_ * (F_ - 1) / 2, len_s1 = F_ - 1;
   // ---- load a frame -------------------------------------------------------------------------------------------
-  auto load_frame = [&](int64_t it) {
+  // it: work item; t: frame of the sequence (0 unless sequence mode)
+  auto load_frame = [&](int64_t it, int t) {
   item = it;
+  t_seq = t;
+  lrow = row_of(it);
+  irow = seq ? (int64_t)t * kp.seq_stride + lrow : lrow;
+  lastp = (seq && t > 0) ? kp.qout + (irow - kp.seq_stride) * ld : kp.last + lrow * ld;
 #pragma unroll
   for (int k = 0; k < NMAX; ++k) {
     x[k] = 0;
     if (k < nj) {
       const int sk = tb.src_kind[k];
       if (sk == DEXR_SRC_OPT) {
-        const float v = kp.x0 ? kp.x0[item * kp.n_opt + tb.api[k]] : kp.last[item * kp.n_opt + tb.api[k]];
+        const float v = (kp.x0 && !(seq && t_seq > 0)) ? kp.x0[lrow * ld + tb.api[k]] : xl(k);
         x[k] = fminf(fmaxf(v, tb.lo[k]), tb.hi[k]);
       } else if (sk == DEXR_SRC_FIXED) {
-        x[k] = tb.mult[k] * kp.fixed[item * kp.n_fixed + tb.src_idx[k]] + tb.off[k];
+        x[k] = tb.mult[k] * kp.fixed[irow * kp.n_fixed + tb.src_idx[k]] + tb.off[k];
       }
     }
   }
-  nst = 0;
   if (dexpilot) {
-    const uint32_t st = kp.state ? kp.state[item] : 0u;
+    const uint32_t st = (seq && t_seq > 0) ? nst : (kp.state ? kp.state[lrow] : 0u);  // carried bits in sequence mode
+    nst = 0;
     for (int i = 0; i < len_s1; ++i) {
       float rv[3];
       ref_row(i, rv);
@@ -527,9 +551,9 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
   bool ok = true;
   const int max_pass = 2 * kp.max_iter + 2;
   // wave-uniform pool of unassigned frames
-  const bool in_static = tile * 64 < (int64_t)kp.q0 && tile * 64 < kp.B;
+  const bool in_static = tile * 64 < (int64_t)kp.q0 && tile * 64 < nB;
   unsigned pool_next = in_static ? (unsigned)(tile * 64) : 0u;
-  unsigned pool_end = in_static ? (unsigned)((tile * 64 + 64 < kp.B) ? tile * 64 + 64 : kp.B) : 0u;
+  unsigned pool_end = in_static ? (unsigned)((tile * 64 + 64 < nB) ? tile * 64 + 64 : nB) : 0u;
   bool dry = false;  // the queue is exhausted
   unsigned* queue = kp.queue + comp;
   for (;;) {
@@ -540,11 +564,11 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
         unsigned base = 0;
         if (lane == 0) base = atomicAdd(queue, 64u);
         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + kp.q0;
-        if ((int64_t)base >= kp.B) {
+        if ((int64_t)base >= nB) {
           dry = true;
         } else {
           pool_next = base;
-          pool_end = (unsigned)(((int64_t)base + 64 < kp.B) ? base + 64 : kp.B);
+          pool_end = (unsigned)(((int64_t)base + 64 < nB) ? base + 64 : nB);
         }
       }
       if (pool_next < pool_end) {
@@ -553,7 +577,7 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
         const bool got = !active && cand < pool_end;
         pool_next += (unsigned)__popcll(__ballot(got));
         if (got) {
-          load_frame((int64_t)cand);
+          load_frame((int64_t)cand, 0);
           active = true;
           done = false;
           pending = false;
@@ -687,15 +711,33 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
       for (int k = 0; k < NMAX; ++k) {
         if ((optmask >> k) & 1u) {
           const float v = bad ? xl(k) : x[k];
-          kp.qout[item * kp.n_opt + tb.api[k]] = v;
-          if (kp.qout64) kp.qout64[item * kp.n_opt + tb.api[k]] = (double)v;
+          kp.qout[irow * ld + tb.api[k]] = v;
+          if (kp.qout64) kp.qout64[irow * ld + tb.api[k]] = (double)v;
         }
       }
-      if (dexpilot && kp.state && comp == 0) kp.state[item] = nst;
-      if (kp.status) atomicMax(&kp.status[item], status);
-      if (kp.iters) atomicMax(&kp.iters[item], my_iters);
-      if (kp.fval) atomicAdd(&kp.fval[item], (float)F);
-      active = false;
+      if (kp.status) atomicMax(&kp.status[irow], status);
+      if (kp.iters) atomicMax(&kp.iters[irow], my_iters);
+      if (kp.fval) atomicAdd(&kp.fval[irow], (float)F);
+      if (seq && t_seq + 1 < kp.T) {
+        // next frame of this lane's sequence: start point / regularisation target = the row just written
+        load_frame(item, t_seq + 1);
+        done = false;
+        pending = false;
+        lam = kp.lam0;
+        nu = 2.f;
+        sprev = 1e30f;
+        status = ST_MAXITER;
+        my_iters = 0;
+        blind = 0;
+        my_pass = 0;
+        F = 0;
+        smax = 0;
+        pred = 0;
+        ok = true;
+      } else {
+        if (dexpilot && kp.state && comp == 0) kp.state[lrow] = nst;
+        active = false;
+      }
     }
   }
 }

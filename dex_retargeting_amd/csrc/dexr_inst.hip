@@ -8,6 +8,9 @@
 #ifndef DEXR_CHAIN
 #define DEXR_CHAIN 0
 #endif
+#ifndef DEXR_EXT
+#define DEXR_EXT 0  // small-component buckets only: the variant with fleet / sequence addressing (see KernelParams)
+#endif
 
 namespace dexr {
 #if DEXR_F64
@@ -19,15 +22,20 @@ typedef float inst_real;
 #define DEXR_CAT_(a, b, c, d) a##b##_##c##_##d
 #define DEXR_CAT(a, b, c, d) DEXR_CAT_(a, b, c, d)
 
-#if DEXR_CHAIN
+#if DEXR_CHAIN && DEXR_EXT
+#define DEXR_PREFIX launch_ext_chain_
+#elif DEXR_CHAIN
 #define DEXR_PREFIX launch_chain_
+#elif DEXR_EXT
+#define DEXR_PREFIX launch_ext_
 #else
 #define DEXR_PREFIX launch_
 #endif
 
 hipError_t DEXR_CAT(DEXR_PREFIX, DEXR_NMAX, DEXR_F64, DEXR_MODE)(const KernelParams& kp, dim3 grid, dim3 block, size_t lds,
                                                               hipStream_t st) {
-  hipLaunchKernelGGL((dexr_kernel<DEXR_NMAX, inst_real, DEXR_MODE, (DEXR_CHAIN != 0)>), grid, block, lds, st, kp, kp.comps);
+  hipLaunchKernelGGL((dexr_kernel<DEXR_NMAX, inst_real, DEXR_MODE, (DEXR_CHAIN != 0), (DEXR_EXT != 0) || (DEXR_NMAX > 8)>), grid, block, lds, st,
+                     kp, kp.comps);
   return hipGetLastError();
 }
 }  // namespace dexr

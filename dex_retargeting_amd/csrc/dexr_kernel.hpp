@@ -68,6 +68,20 @@ struct KernelParams {
   int32_t n_kp;                   // keypoints per frame (21 for MediaPipe/MANO hands)
   int32_t h_origin[DEXR_MAXT];    // target_link_human_indices[0] per ref row (-1: position row = kp[h_task])
   int32_t h_task[DEXR_MAXT];      // target_link_human_indices[1] per ref row
+  // ---- extended addressing (kernels instantiated with EXT = true; ignored otherwise) -------------------------------
+  // Mixed-fleet batches: work item i of this launch is row perm[bucket[0] + i] of the batch arrays and the launch has
+  // bucket[1] items -- both read from DEVICE memory, so the host never waits for the bucketing kernels.
+  const int32_t* __restrict__ perm;    // NULL: item i is row i
+  const int32_t* __restrict__ bucket;  // NULL: offset 0, B items
+  int32_t ld;                          // row length of last / x0 / qout (>= n_opt; rows of a fleet batch are padded)
+  // Frame sequences (SeqRetargeting.retarget semantics, seq_retarget.py:112-134): a work item is a SEQUENCE; the lane
+  // (quad) that owns it solves its T frames in order and carries the raw solution, clipped to the joint limits
+  // [lo + clip_eps, hi - clip_eps] (tables hold the optimiser's box, widened by clip_eps), as start point and
+  // regularisation target of the next frame, and the DexPilot projection bits.  Frame t of sequence b reads input row
+  // t * seq_stride + b and writes output row t * seq_stride + b; `last` and `state` have one row per sequence.
+  int32_t T;                           // frames per sequence; 0 = independent frames (no clipping of `last`)
+  int64_t seq_stride;                  // rows between consecutive frames of one sequence
+  float clip_eps;
 };
 
 enum { MODE_SOLVE = 0, MODE_EVAL = 1, MODE_FK = 2 };
@@ -475,8 +489,13 @@ struct LaneSolver {
   }
 
   // ---- in-place Cholesky of H (lower) + solve H d = -g --------------------------------------------------------
-  // Returns false where a pivot was not positive (indefinite Newton Hessian: caller raises the damping).
-  __device__ __forceinline__ bool chol_solve(real (&d)[NMAX]) {
+  // Returns false where a pivot was not positive (indefinite Newton Hessian).  MODIFY = false: the step is then
+  // meaningless and the caller raises the damping (one wasted pass).  MODIFY = true: modified Cholesky -- the offending
+  // pivot is replaced by max(|pivot|, pivot_floor), i.e. negative curvature along that pivot direction is reflected,
+  // and d is a descent direction of the model H + E: the pass is not wasted (far starts spent 4-7 of their 15 passes on
+  // failed factorisations, tools/lm_lab.py); the caller must not treat such a step as a verified Newton step.
+  template <bool MODIFY = false>
+  __device__ __forceinline__ bool chol_solve(real (&d)[NMAX], real pivot_floor = 1) {
     bool ok = true;
     real inv[NMAX];
 #pragma unroll
@@ -484,9 +503,9 @@ struct LaneSolver {
       real dj = H[hidx(j, j)];
 #pragma unroll
       for (int k = 0; k < j; ++k) dj -= H[hidx(j, k)] * H[hidx(j, k)];
-      if (!(dj > (real)1e-30)) {
+      if (!(dj > (MODIFY ? (real)1e-6 * pivot_floor : (real)1e-30))) {
         ok = false;
-        dj = 1;
+        dj = MODIFY ? fmax(fabs(dj), pivot_floor) : (real)1;
       }
       const real iv = RT::rsqrt(dj);
       inv[j] = iv;
@@ -522,7 +541,10 @@ struct LaneSolver {
 // ------------------------------------------------------------------------------------------------------------
 // Kernel: one wave = 64 items x one component.  blockDim.x = 64 * waves_per_block; dynamic LDS =
 // waves_per_block * 64 * sizeof(real) * (3*lds_frames + 4*lds_terms).
-template <int NMAX, typename real, int MODE, bool CHAIN = false>
+// EXT = true adds the extended addressing of KernelParams (fleet buckets, frame sequences).  The small-component
+// kernels are instantiated both ways so that the plain single-model launch keeps its register budget; the large ones
+// always carry it.
+template <int NMAX, typename real, int MODE, bool CHAIN = false, bool EXT = (NMAX > 8)>
 __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4) ? DEXR_CHAIN_MINW : 1) dexr_kernel(const KernelParams kp, const dexr_comp_table* __restrict__ comps) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   using LS = LaneSolver<NMAX, real, CHAIN>;
@@ -536,10 +558,17 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
   const int comp = (int)(wave_global % kp.n_comp);
   const int64_t tile = wave_global / kp.n_comp;
   constexpr bool PERSISTENT = (MODE == MODE_SOLVE && NMAX <= 8);  // lanes pull frames from a queue (see below)
-  if (!PERSISTENT && tile * 64 >= kp.B) return;
+  // number of work items and their rows (see KernelParams: fleet buckets are sized and listed on the device)
+  const int64_t nB = (EXT && kp.bucket) ? (int64_t)kp.bucket[1] : kp.B;
+  const int64_t pbase = (EXT && kp.bucket) ? (int64_t)kp.bucket[0] : 0;
+  auto row_of = [&](int64_t it) -> int64_t { return (EXT && kp.perm) ? (int64_t)kp.perm[pbase + it] : it; };
+  const int ld = EXT ? kp.ld : kp.n_opt;
+  const bool seq = EXT && MODE == MODE_SOLVE && kp.T > 0;
+  if (nB <= 0) return;
+  if (!PERSISTENT && tile * 64 >= nB) return;
   const int64_t item_raw = tile * 64 + lane;
-  const bool valid = item_raw < kp.B;
-  const int64_t item = valid ? item_raw : kp.B - 1;
+  const bool valid = item_raw < nB;
+  const int64_t item = valid ? item_raw : nB - 1;
 
   const int per_wave = 64 * (3 * kp.lds_frames + 4 * kp.lds_terms);
   real* P = reinterpret_cast<real*>(lds_raw) + (size_t)wave_in_block * per_wave;
@@ -576,7 +605,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
 
   // one row of ref_value for frame `it`: either handed in directly or formed from raw hand keypoints as the callers
   // of the reference do (joint_pos[task] - joint_pos[origin] / joint_pos[idx], profile_online_retargeting.py:24-30)
-  auto ref_row = [&](int64_t it, int row, float (&rv)[3]) {
+  auto ref_row = [&](int64_t it, int row, float (&rv)[3]) {  // `it`: row of the input arrays
     if (kp.kpts) {
       const float* a = kp.kpts + (it * kp.n_kp + kp.h_task[row]) * 3;
       const int o = kp.h_origin[row];
@@ -598,9 +627,16 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
   // Loads everything frame `it` needs into this lane: joint values (start point, regularisation target, fixed
   // joints) into registers, per-term targets / DexPilot weights into the lane's LDS column.  Returns the updated
   // DexPilot projection bits.
-  auto load_item = [&](int64_t it) -> uint32_t {
+  // `item`: work item (frame, or sequence in sequence mode); t > 0 (sequence mode only): frame t of the sequence, whose
+  // start point / regularisation target is the lane's own previous solution (carry) and whose incoming DexPilot bits
+  // are `st_carry`.
+  auto load_item = [&](int64_t item_i, int t = 0, uint32_t st_carry = 0u) -> uint32_t {
+    const int64_t r0 = row_of(item_i);                       // row of `last` / `state` (one per item)
+    const int64_t it = seq ? (int64_t)t * kp.seq_stride + r0 : r0;  // row of this frame's inputs
+    const bool carry = seq && t > 0;
 #pragma unroll
     for (int k = 0; k < NMAX; ++k) {
+      real prev = S.x[k];
       S.x[k] = 0;
       S.xl[k] = 0;
       if (CHAIN || k < nj) {
@@ -608,9 +644,16 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
         if (sk == DEXR_SRC_OPT) {
           real v;
           if (MODE == MODE_EVAL) v = (real)kp.xin[it * kp.n_opt + tb.api[k]];
-          else if (kp.x0) v = (real)kp.x0[it * kp.n_opt + tb.api[k]];
-          else v = (real)kp.last[it * kp.n_opt + tb.api[k]];
-          S.xl[k] = (real)kp.last[it * kp.n_opt + tb.api[k]];
+          else if (carry) v = (real)(float)prev;  // the reference carries the float32 result (optimizer.py:99)
+          else if (kp.x0) v = (real)kp.x0[r0 * ld + tb.api[k]];
+          else v = (real)kp.last[r0 * ld + tb.api[k]];
+          real l = carry ? v : (real)kp.last[r0 * ld + tb.api[k]];
+          if (seq) {  // seq_retarget.py:118-120: last_qpos clipped to the joint limits before every solve
+            const real lo_s = (real)tb.lo[k] + (real)kp.clip_eps, hi_s = (real)tb.hi[k] - (real)kp.clip_eps;
+            l = fmin(fmax(l, lo_s), hi_s);
+            v = l;
+          }
+          S.xl[k] = l;
           S.x[k] = v;
         } else if (sk == DEXR_SRC_FIXED) {
           S.x[k] = (real)tb.mult[k] * (real)kp.fixed[it * kp.n_fixed + tb.src_idx[k]] + (real)tb.off[k];
@@ -625,7 +668,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
       // optimizer.py:462-508.  Terms are the model's vectors in order: pairs first, then wrist->finger.
       const int F = kp.num_fingers;
       const int n_pair = F * (F - 1) / 2, len_s1 = F - 1;
-      const uint32_t st = kp.state ? kp.state[it] : 0u;
+      const uint32_t st = carry ? st_carry : (kp.state ? kp.state[r0] : 0u);
       for (int i = 0; i < len_s1; ++i) {
         float rv[3];
         ref_row(it, i, rv);
@@ -702,7 +745,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
       for (int t = 0; t < nt; ++t) {
         const int f = tb.term_task[t], row = tb.term_ref[t];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) kp.f64out[(item * kp.n_ref + row) * 3 + i] = (double)P[(f * 3 + i) * 64 + lane];
+        for (int i = 0; i < 3; ++i) kp.f64out[(row_of(item) * kp.n_ref + row) * 3 + i] = (double)P[(f * 3 + i) * 64 + lane];
       }
     }
     return;
@@ -715,12 +758,13 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
     const real f = S.template residuals<1>(tb, kp, nt, vmask, P, T, W, lane);
     S.template fold_mimic<false>(tb, nj);
     if (valid) {
-      if (kp.kind == DEXR_KIND_DEXPILOT && kp.state && comp == 0) kp.state[item] = nst_out;
-      atomicAdd(&kp.f64out[item], (double)f);
+      const int64_t r0 = row_of(item);
+      if (kp.kind == DEXR_KIND_DEXPILOT && kp.state && comp == 0) kp.state[r0] = nst_out;
+      atomicAdd(&kp.f64out[r0], (double)f);
 #pragma unroll
       for (int k = 0; k < NMAX; ++k)
         if ((optmask >> k) & 1u)
-          kp.g64out[item * kp.n_opt + tb.api[k]] = (double)(S.g[k] + (real)2 * delta * (S.x[k] - S.xl[k]));
+          kp.g64out[r0 * kp.n_opt + tb.api[k]] = (double)(S.g[k] + (real)2 * delta * (S.x[k] - S.xl[k]));
     }
     return;
   }
@@ -741,18 +785,19 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
     int my_iters = 0, blind = 0;
     bool has = false, fresh = false;
     int64_t my_item = 0;
+    int my_t = 0;  // sequence mode: frame of the lane's sequence being solved
     uint32_t my_nst = 0;
     unsigned pool_next = 0, pool_end = 0;  // wave-uniform
     bool dry = false;                      // wave-uniform: the queue has been exhausted
     if (QCHUNK == 0) {  // tile mode: this wave owns frames [64*tile, 64*tile+64) and never touches the queue
       pool_next = (unsigned)(tile * 64);
-      pool_end = (unsigned)((tile * 64 + 64 < kp.B) ? tile * 64 + 64 : kp.B);
-      if ((int64_t)pool_next >= kp.B) return;
+      pool_end = (unsigned)((tile * 64 + 64 < nB) ? tile * 64 + 64 : nB);
+      if ((int64_t)pool_next >= nB) return;
     } else {  // queue mode: the first tile is static as well (no start-up stampede on the counter).  The grid is rounded
       // up to whole blocks: a surplus wave (tile * 64 >= q0, where the queue's numbering starts) gets no static tile.
-      const bool in_static = tile * 64 < (int64_t)kp.q0 && tile * 64 < kp.B;
+      const bool in_static = tile * 64 < (int64_t)kp.q0 && tile * 64 < nB;
       pool_next = in_static ? (unsigned)(tile * 64) : 0u;
-      pool_end = in_static ? (unsigned)((tile * 64 + 64 < kp.B) ? tile * 64 + 64 : kp.B) : 0u;
+      pool_end = in_static ? (unsigned)((tile * 64 + 64 < nB) ? tile * 64 + 64 : nB) : 0u;
     }
     unsigned* queue = kp.queue + comp;
 
@@ -765,11 +810,11 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
           unsigned base = 0;
           if (lane == 0) base = atomicAdd(queue, QCHUNK);
           base = __builtin_amdgcn_readfirstlane(base) + kp.q0;
-          if ((int64_t)base >= kp.B) {
+          if ((int64_t)base >= nB) {
             dry = true;
           } else {
             pool_next = base;
-            pool_end = (unsigned)(((int64_t)base + QCHUNK < kp.B) ? base + QCHUNK : kp.B);
+            pool_end = (unsigned)(((int64_t)base + QCHUNK < nB) ? base + QCHUNK : nB);
           }
         }
         if (!dry) {
@@ -780,6 +825,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
           pool_next += taken;
           if (got) {
             my_item = (int64_t)cand;
+            my_t = 0;
             my_nst = load_item(my_item);
 #pragma unroll
             for (int k = 0; k < NMAX; ++k)
@@ -825,7 +871,9 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
 #pragma unroll
         for (int k = 0; k < NMAX; ++k) gm[k] = S.g[k];
         real d[NMAX];
-        ok = S.chol_solve(d);
+        // modified Cholesky (see chol_solve): `ok` = no pivot had to be modified, i.e. d is the Newton step of the
+        // damped model; a modified step is still tried (the decrease test below judges it)
+        ok = S.template chol_solve<true>(d, (real)2 * delta + lam);
         const bool stepping = has && !fresh;
         // trust radius: scale the step so that no joint moves more than step_cap (alpha in (0, 1])
         real dmax = 0, gd = 0, dd = 0;
@@ -892,7 +940,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
           const real noise = (real)16 * RT::eps() * fabs(F);
           // below the rounding floor of F the decrease test is meaningless: trust the (small) Newton step
           const bool below_floor = ok && finite && (pred <= noise) && (smax < (real)1e-2);
-          accept = ok && finite && ((Ft <= F) || below_floor);
+          accept = finite && ((Ft <= F) || below_floor);  // (a modified-Cholesky step is judged by the decrease alone)
           ++my_iters;
           if (accept) {
             const real rho = (F - Ft) / fmax(pred, (real)1e-30);
@@ -946,19 +994,37 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
         for (int k = 0; k < NMAX; ++k)
           if ((optmask >> k) & 1u) bad = bad || !(S.x[k] == S.x[k]);
         if (bad) status = ST_FALLBACK;
+        const int64_t r0 = row_of(my_item);
+        const int64_t orow = seq ? (int64_t)my_t * kp.seq_stride + r0 : r0;  // output row of this frame
 #pragma unroll
         for (int k = 0; k < NMAX; ++k) {
           if ((optmask >> k) & 1u) {
             const real v = bad ? S.xl[k] : S.x[k];
-            kp.qout[my_item * kp.n_opt + tbl.api[k]] = (float)v;
-            if (kp.qout64) kp.qout64[my_item * kp.n_opt + tbl.api[k]] = (double)v;
+            S.x[k] = v;  // (sequence mode: the value the next frame starts from)
+            kp.qout[orow * ld + tbl.api[k]] = (float)v;
+            if (kp.qout64) kp.qout64[orow * ld + tbl.api[k]] = (double)v;
           }
         }
-        if (kp.kind == DEXR_KIND_DEXPILOT && kp.state && comp == 0) kp.state[my_item] = my_nst;
-        if (kp.status) atomicMax(&kp.status[my_item], status);
-        if (kp.iters) atomicMax(&kp.iters[my_item], my_iters);
-        if (kp.fval) atomicAdd(&kp.fval[my_item], (float)F);
-        has = false;
+        if (kp.status) atomicMax(&kp.status[orow], status);
+        if (kp.iters) atomicMax(&kp.iters[orow], my_iters);
+        if (kp.fval) atomicAdd(&kp.fval[orow], (float)F);
+        if (seq && my_t + 1 < kp.T) {
+          // next frame of the same sequence: carry the solution (clipped inside load_item) and the projection bits
+          ++my_t;
+          my_nst = load_item(my_item, my_t, my_nst);
+#pragma unroll
+          for (int k = 0; k < NMAX; ++k)
+            if ((optmask >> k) & 1u) S.x[k] = fmin(fmax(S.x[k], (real)tbl.lo[k]), (real)tbl.hi[k]);
+          fresh = true;
+          lam = (real)kp.lam0;
+          nu = 2;
+          sprev = (real)1e30;
+          my_iters = 0;
+          blind = 0;
+        } else {
+          if (kp.kind == DEXR_KIND_DEXPILOT && kp.state && comp == 0) kp.state[r0] = my_nst;
+          has = false;
+        }
       }
     }
     };
@@ -973,6 +1039,10 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
   } else {
   // ---- large components: one tile of 64 frames per wave; the Hessian (up to 300 registers) is rebuilt after a
   // rejected step instead of being kept twice.
+  const int n_frames = seq ? kp.T : 1;
+#pragma clang loop unroll(disable)
+  for (int t_seq = 0; t_seq < n_frames; ++t_seq) {
+  if (t_seq > 0) nst_out = load_item(item, t_seq, nst_out);  // sequence mode: next frame, carried start point / bits
   // start point: last_qpos clipped into the box (nlopt requires lb <= x0 <= ub; seq_retarget.py:118-120 clips)
 #pragma unroll
   for (int k = 0; k < NMAX; ++k)
@@ -1110,20 +1180,26 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
     if ((optmask >> k) & 1u) bad = bad || !(S.x[k] == S.x[k]);
   if (bad) status = 2;
 
-  if (valid) {
+  const int64_t r0 = row_of(item);
+  const int64_t orow = seq ? (int64_t)t_seq * kp.seq_stride + r0 : r0;
 #pragma unroll
-    for (int k = 0; k < NMAX; ++k) {
-      if ((optmask >> k) & 1u) {
-        const real v = bad ? S.xl[k] : S.x[k];
-        kp.qout[item * kp.n_opt + tb.api[k]] = (float)v;
-        if (kp.qout64) kp.qout64[item * kp.n_opt + tb.api[k]] = (double)v;
+  for (int k = 0; k < NMAX; ++k) {
+    if ((optmask >> k) & 1u) {
+      const real v = bad ? S.xl[k] : S.x[k];
+      S.x[k] = v;  // (sequence mode: the value the next frame starts from)
+      if (valid) {
+        kp.qout[orow * ld + tb.api[k]] = (float)v;
+        if (kp.qout64) kp.qout64[orow * ld + tb.api[k]] = (double)v;
       }
     }
-    if (kp.kind == DEXR_KIND_DEXPILOT && kp.state && comp == 0) kp.state[item] = nst_out;
-    if (kp.status) atomicMax(&kp.status[item], status);
-    if (kp.iters) atomicMax(&kp.iters[item], my_iters);
-    if (kp.fval) atomicAdd(&kp.fval[item], (float)F);
   }
+  if (valid) {
+    if (kp.kind == DEXR_KIND_DEXPILOT && kp.state && comp == 0 && t_seq + 1 == n_frames) kp.state[r0] = nst_out;
+    if (kp.status) atomicMax(&kp.status[orow], status);
+    if (kp.iters) atomicMax(&kp.iters[orow], my_iters);
+    if (kp.fval) atomicAdd(&kp.fval[orow], (float)F);
+  }
+  }  // frames of the sequence
   }  // large components
 }
 

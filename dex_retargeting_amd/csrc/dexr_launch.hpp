@@ -25,6 +25,13 @@ DEXR_DECL(32)
 #undef DEXR_DECL
 // serial-chain specialisation (see LaneSolver's CHAIN flag): float32 solve, 4-joint bucket
 hipError_t launch_chain_4_0_0(const KernelParams&, dim3, dim3, size_t, hipStream_t);
+// small-component solve kernels with the extended addressing of KernelParams (fleet buckets, frame sequences); the
+// buckets above 8 joints always carry it
+hipError_t launch_ext_4_0_0(const KernelParams&, dim3, dim3, size_t, hipStream_t);
+hipError_t launch_ext_8_0_0(const KernelParams&, dim3, dim3, size_t, hipStream_t);
+hipError_t launch_ext_4_1_0(const KernelParams&, dim3, dim3, size_t, hipStream_t);
+hipError_t launch_ext_8_1_0(const KernelParams&, dim3, dim3, size_t, hipStream_t);
+hipError_t launch_ext_chain_4_0_0(const KernelParams&, dim3, dim3, size_t, hipStream_t);
 
 // large-component kernel (dexr_big.hpp): float64 kinematics + float32 Hessian in LDS
 hipError_t launch_big_16(const KernelParams&, dim3, dim3, size_t, hipStream_t);
@@ -41,7 +48,12 @@ static inline launch_fn find_quad_launcher(int bucket) {
   return bucket == 16 ? launch_quad_16 : bucket == 24 ? launch_quad_24 : nullptr;
 }
 
-static inline launch_fn find_launcher(int bucket, int f64, int mode, bool chain = false) {
+static inline launch_fn find_launcher(int bucket, int f64, int mode, bool chain = false, bool ext = false) {
+  if (ext && mode == MODE_SOLVE && bucket <= 8) {
+    if (chain && bucket == 4 && !f64) return launch_ext_chain_4_0_0;
+    if (bucket == 4) return f64 ? launch_ext_4_1_0 : launch_ext_4_0_0;
+    return f64 ? launch_ext_8_1_0 : launch_ext_8_0_0;
+  }
   if (chain && bucket == 4 && !f64 && mode == MODE_SOLVE) return launch_chain_4_0_0;
 #define DEXR_CASE(N)                                                  \
   if (bucket == N) {                                                  \

@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
   // finishes its frame pulls the next one instead of idling until the slowest of the wave's 16 frames is done.  Wave w
   // starts with the static tile [16 w, 16 w + 16); frames from kp.q0 on are numbered by a per-component queue counter
   // that a wave advances by 16 whenever its local pool is empty.
-  int64_t item = 0;     // frame this quad is working on
+  int64_t item = 0;     // work item (frame, or sequence) this quad is working on
   bool active = false;  // the quad holds a frame (idle quads still execute the passes, on stale data, and store nothing)
 
   const size_t per_wave = (size_t)64 * (8 * 3 * kp.lds_frames + 4 * 3 * NMAX + 4 * NMAX);
@@ -71,6 +71,15 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
   const dexr_comp_table& tb = comps[comp];
   const int nj = tb.n_joint, nt = tb.n_term;
   const float delta = kp.norm_delta;
+  // number of work items and their rows: fleet buckets are sized and listed on the device (see KernelParams)
+  const int64_t nB = kp.bucket ? (int64_t)kp.bucket[1] : kp.B;
+  const int64_t pbase = kp.bucket ? (int64_t)kp.bucket[0] : 0;
+  auto row_of = [&](int64_t it) -> int64_t { return kp.perm ? (int64_t)kp.perm[pbase + it] : it; };
+  const int ld = kp.ld;
+  const bool seq = kp.T > 0;  // sequence mode: a work item is a sequence of kp.T frames solved in order by this lane
+  int64_t lrow = 0, irow = 0;  // row of the item's `last` / `state`; row of the current frame's inputs and outputs
+  int t_seq = 0;               // frame of the sequence being solved
+  const float* lastp = kp.last;
 
   uint32_t optmask = 0;
   uint32_t revmask = 0;  // revolute joints: a wave-uniform bit mask, so the loops below test a bit instead of loading jtype
@@ -87,10 +96,10 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
 
   auto ref_row = [&](int row, float (&rv)[3]) {
     if (kp.kpts) {
-      const float* a = kp.kpts + (item * kp.n_kp + kp.h_task[row]) * 3;
+      const float* a = kp.kpts + (irow * kp.n_kp + kp.h_task[row]) * 3;
       const int o = kp.h_origin[row];
       if (o >= 0) {
-        const float* b = kp.kpts + (item * kp.n_kp + o) * 3;
+        const float* b = kp.kpts + (irow * kp.n_kp + o) * 3;
 #pragma unroll
         for (int i = 0; i < 3; ++i) rv[i] = a[i] - b[i];
       } else {
@@ -98,36 +107,51 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
         for (int i = 0; i < 3; ++i) rv[i] = a[i];
       }
     } else {
-      const float* r = kp.ref + (item * kp.n_ref + row) * 3;
+      const float* r = kp.ref + (irow * kp.n_ref + row) * 3;
 #pragma unroll
       for (int i = 0; i < 3; ++i) rv[i] = r[i];
     }
   };
-  auto xl = [&](int k) -> float { return kp.last[item * kp.n_opt + tb.api[k]]; };
+  // regularisation target = start point of the frame (L1/L2 hit): `last` of the item, or -- sequence mode, frame
+  // t > 0 -- the previous frame's raw solution, which this lane has just stored to qout; clipped to the joint limits
+  // in sequence mode (seq_retarget.py:118-120)
+  auto xl = [&](int k) -> float {
+    float v;
+    if (seq && t_seq > 0)  // written by this wave a moment ago: read it coherently (bypassing the vector L1)
+      v = __hip_atomic_load(const_cast<float*>(lastp) + tb.api[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      v = lastp[tb.api[k]];
+    return seq ? fminf(fmaxf(v, tb.lo[k] + kp.clip_eps), tb.hi[k] - kp.clip_eps) : v;
+  };
 
   // DexPilot projection bits (optimizer.py:466-476) of the current frame
   uint32_t nst = 0;
   const bool dexpilot = kp.kind == DEXR_KIND_DEXPILOT;
   const int F_ = kp.num_fingers, n_pair = F_ * (F_ - 1) / 2, len_s1 = F_ - 1;
   // ---- load a frame (all four lanes of the quad load the same values) --------------------------------------------
-  auto load_frame = [&](int64_t it) {
+  // it: work item; t: frame of the sequence (0 unless sequence mode)
+  auto load_frame = [&](int64_t it, int t) {
   item = it;
+  t_seq = t;
+  lrow = row_of(it);
+  irow = seq ? (int64_t)t * kp.seq_stride + lrow : lrow;
+  lastp = (seq && t > 0) ? kp.qout + (irow - kp.seq_stride) * ld : kp.last + lrow * ld;
 #pragma unroll
   for (int k = 0; k < NMAX; ++k) {
     x[k] = 0;
     if (k < nj) {
       const int sk = tb.src_kind[k];
       if (sk == DEXR_SRC_OPT) {
-        const float v = kp.x0 ? kp.x0[item * kp.n_opt + tb.api[k]] : kp.last[item * kp.n_opt + tb.api[k]];
+        const float v = (kp.x0 && !(seq && t_seq > 0)) ? kp.x0[lrow * ld + tb.api[k]] : xl(k);
         x[k] = fminf(fmaxf(v, tb.lo[k]), tb.hi[k]);
       } else if (sk == DEXR_SRC_FIXED) {
-        x[k] = tb.mult[k] * kp.fixed[item * kp.n_fixed + tb.src_idx[k]] + tb.off[k];
+        x[k] = tb.mult[k] * kp.fixed[irow * kp.n_fixed + tb.src_idx[k]] + tb.off[k];
       }
     }
   }
-  nst = 0;
   if (dexpilot) {
-    const uint32_t st = kp.state ? kp.state[item] : 0u;
+    const uint32_t st = (seq && t_seq > 0) ? nst : (kp.state ? kp.state[lrow] : 0u);  // carried bits in sequence mode
+    nst = 0;
     for (int i = 0; i < len_s1; ++i) {
       float rv[3];
       ref_row(i, rv);
@@ -455,9 +479,9 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
   bool ok = true;
   const int max_pass = 2 * kp.max_iter + 2;
   // wave-uniform pool of unassigned frames
-  unsigned pool_next = (unsigned)((tile * 16 < (int64_t)kp.q0 && tile * 16 < kp.B) ? tile * 16 : 0);
-  unsigned pool_end = (unsigned)((tile * 16 < (int64_t)kp.q0 && tile * 16 < kp.B)
-                                     ? ((tile * 16 + 16 < kp.B) ? tile * 16 + 16 : kp.B) : 0);
+  unsigned pool_next = (unsigned)((tile * 16 < (int64_t)kp.q0 && tile * 16 < nB) ? tile * 16 : 0);
+  unsigned pool_end = (unsigned)((tile * 16 < (int64_t)kp.q0 && tile * 16 < nB)
+                                     ? ((tile * 16 + 16 < nB) ? tile * 16 + 16 : nB) : 0);
   bool dry = false;  // the queue is exhausted
   unsigned* queue = kp.queue + comp;
   for (;;) {
@@ -468,11 +492,11 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
         unsigned base = 0;
         if (lane == 0) base = atomicAdd(queue, 16u);
         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + kp.q0;
-        if ((int64_t)base >= kp.B) {
+        if ((int64_t)base >= nB) {
           dry = true;
         } else {
           pool_next = base;
-          pool_end = (unsigned)(((int64_t)base + 16 < kp.B) ? base + 16 : kp.B);
+          pool_end = (unsigned)(((int64_t)base + 16 < nB) ? base + 16 : nB);
         }
       }
       if (pool_next < pool_end) {
@@ -482,7 +506,7 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
         const bool got = !active && cand < pool_end;
         pool_next += (unsigned)__popcll(__ballot(got)) >> 2;
         if (got) {
-          load_frame((int64_t)cand);
+          load_frame((int64_t)cand, 0);
           active = true;
           done = false;
           pending = false;
@@ -622,16 +646,36 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
         for (int k = 0; k < NMAX; ++k) {
           if ((optmask >> k) & 1u) {
             const float v = bad ? xl(k) : x[k];
-            kp.qout[item * kp.n_opt + tb.api[k]] = v;
-            if (kp.qout64) kp.qout64[item * kp.n_opt + tb.api[k]] = (double)v;
+            kp.qout[irow * ld + tb.api[k]] = v;
+            if (kp.qout64) kp.qout64[irow * ld + tb.api[k]] = (double)v;
           }
         }
-        if (dexpilot && kp.state && comp == 0) kp.state[item] = nst;
-        if (kp.status) atomicMax(&kp.status[item], status);
-        if (kp.iters) atomicMax(&kp.iters[item], my_iters);
-        if (kp.fval) atomicAdd(&kp.fval[item], (float)F);
+        if (kp.status) atomicMax(&kp.status[irow], status);
+        if (kp.iters) atomicMax(&kp.iters[irow], my_iters);
+        if (kp.fval) atomicAdd(&kp.fval[irow], (float)F);
       }
-      active = false;
+      if (seq && t_seq + 1 < kp.T) {
+        // next frame of this quad's sequence: its start point / regularisation target is the row lane 0 of the quad
+        // has just written (same wave, program order: the loads below come after the stores above)
+        load_frame(item, t_seq + 1);
+        done = false;
+        pending = false;
+        lam = kp.lam0;
+        nu = 2.f;
+        sprev = 1e30f;
+        keff = 0.f;
+        status = ST_MAXITER;
+        my_iters = 0;
+        blind = 0;
+        my_pass = 0;
+        F = 0;
+        smax = 0;
+        pred = 0;
+        ok = true;
+      } else {
+        if (p == 0 && dexpilot && kp.state && comp == 0) kp.state[lrow] = nst;
+        active = false;
+      }
     }
   }
 }

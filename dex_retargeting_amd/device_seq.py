@@ -120,6 +120,62 @@ class DeviceSeqRetargeting:
                                  torch.cuda.current_stream(self.device).cuda_stream)
         return self.retarget(self._kp_mano, fixed_qpos, _keypoints=True)
 
+    def _dof_map(self):
+        """How every robot dof (pinocchio order) is composed from the optimiser's answer (seq_retarget.py:125-130)."""
+        opt = self.optimizer
+        n_q = opt.robot.dof
+        kind, idx = np.ones(n_q, np.int32), np.zeros(n_q, np.int32)
+        mult, off = np.ones(n_q), np.zeros(n_q)
+        for i, p in enumerate(opt.idx_pin2target):
+            kind[p], idx[p] = 0, i
+        for i, p in enumerate(opt.idx_pin2fixed):
+            kind[p], idx[p] = 1, i
+        ad = opt.adaptor
+        if isinstance(ad, MimicJointKinematicAdaptor):
+            for m, s_, a, b in zip(ad.idx_pin2mimic, ad.idx_pin2source, ad.multipliers, ad.offsets):
+                kind[m], idx[m], mult[m], off[m] = 2, s_, a, b
+        return kind, idx, mult, off
+
+    def retarget_sequence(self, inputs_seq, fixed_seq=None, out=None, keypoints: bool = True, raw_out=None,
+                          status_out=None):
+        """T lock-step frames of the B sequences in TWO kernel launches: ``dexr_retarget_seq_dev`` (every lane loops
+        over its sequence's T frames inside the kernel, carrying the clipped last_qpos and the DexPilot bits) and
+        ``dexr_seq_compose_dev`` (robot-qpos composition, mimic fill, low-pass filter for all T x B frames).
+        inputs_seq: (T, B, 21, 3) float32 keypoints (or (T, B, n_ref, 3) ref_value rows with keypoints=False);
+        fixed_seq: (T, B, n_fixed) float32 when the model has caller-supplied fixed joints.
+        Returns the (T, B, dof) float64 tensor SeqRetargeting.retarget would have returned frame by frame; the carried
+        state (last_qpos, filter, DexPilot bits) continues from / for calls of either kind."""
+        torch = self.torch
+        if inputs_seq.dtype != torch.float32 or not inputs_seq.is_contiguous() or inputs_seq.device != self.device:
+            inputs_seq = inputs_seq.to(device=self.device, dtype=torch.float32).contiguous()
+        T, B = int(inputs_seq.shape[0]), self.batch
+        if int(inputs_seq.shape[1]) != B:
+            raise ValueError(f"inputs_seq must have shape (T, {B}, rows, 3), got {tuple(inputs_seq.shape)}")
+        fixed_ptr = 0
+        if self.n_fixed:
+            if fixed_seq is None:
+                raise ValueError(f"Optimizer has {self.n_fixed} joints but non_target_qpos None is given")
+            fixed_seq = fixed_seq.to(device=self.device, dtype=torch.float32).contiguous()
+            fixed_ptr = fixed_seq.data_ptr()
+        n_q = self.robot_qpos.shape[1]
+        if raw_out is None:
+            raw_out = torch.empty((T, B, self.n_opt), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((T, B, n_q), dtype=torch.float64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.model.retarget_seq_dev(B, T, inputs_seq.data_ptr(), fixed_ptr, self.last_qpos.data_ptr(),
+                                    self.state.data_ptr() if self.dexpilot else 0, raw_out.data_ptr(),
+                                    status_ptr=status_out.data_ptr() if status_out is not None else 0,
+                                    joint_limit_eps=1e-3, opts=self._opts, stream=stream, keypoints=keypoints)
+        kind, idx, mult, off = self._dof_map()
+        _lib.seq_compose_dev(B, T, kind, idx, mult, off, self.n_opt, self.n_fixed, raw_out.data_ptr(), fixed_ptr,
+                             -1.0 if self.alpha is None else float(self.alpha), self.filtered.data_ptr(),
+                             not self._filter_init, out.data_ptr(), stream)
+        if self.alpha is not None:
+            self._filter_init = True
+        self.num_retargeting += T
+        return out
+
     def capture(self, keypoints_seq, out=None):
         """Capture T lock-step frames into ONE HIP graph (``torch.cuda.CUDAGraph``): ``keypoints_seq`` is a persistent
         (T, B, 21, 3) float32 CUDA tensor the caller refills before every ``graph.replay()``; ``out`` (T, B, dof)

@@ -49,10 +49,10 @@ typedef struct dexr_solve_options {
   int32_t polish;     /* float64 polishing iterations run after the float32 solve, started at its answer:
                          -1 auto (default: 12 for position / DexPilot models, whose float32 rounding floor sits
                          near 1e-4 rad; 0 for vector models), 0 off, n > 0 at most n iterations           */
-  int32_t strict;     /* 1: polish also after the mixed-precision kernels (float64 kinematics, float32 gradient and
-                         Hessian) that serve large components.  Their answers sit within 1e-6 rad of the float64
-                         minimiser except in nearly flat valleys of mimic position models, where a 1e-7 gradient
-                         error moves the stationary point by up to 4e-4 rad.  Default 0.      */
+  int32_t strict;     /* float64 polish after the mixed-precision kernels (float64 kinematics, float32 gradient and
+                         Hessian) that serve large components.  0 (default): only for models with mimic joints, whose
+                         nearly flat valleys let a 1e-7 gradient error move the stationary point by up to 4e-4 rad
+                         (DESIGN.md section 2); 1: for every model; -1: never.                                      */
 } dexr_solve_options;
 
 /* Per-model launch / damping parameters.  These are the values the launcher derives from the model's shape and from
@@ -138,6 +138,63 @@ int dexr_eval(const dexr_model* m, int64_t B, const float* ref, const float* fix
  * `m` must come from an FK table (kind DEXR_KIND_FKONLY). q: B x n_q float64 (pinocchio dof order);
  * pos_out: B x n_ref x 3 float64.  Host pointers. */
 int dexr_fk(const dexr_model* m, int64_t B, const double* q, double* pos_out);
+
+/* ---- frame sequences: SeqRetargeting.retarget x T frames x B sequences in ONE launch --------
+ * Per sequence exactly what /root/reference/src/dex_retargeting/seq_retarget.py:112-124 does per call: clip the carried
+ * last_qpos to the joint limits, solve from it (start point and regularisation target), carry the UNFILTERED float32
+ * answer -- and the DexPilot projection bits (optimizer.py:466-476) -- to the next frame.  The lane (or quad) that owns
+ * a sequence loops over its T frames inside the kernel; nothing visits the host between frames.
+ *   inputs       T x B x n_keypoints x 3 float32 raw keypoints (inputs_are_keypoints = 1) or T x B x n_ref x 3 ref_value rows
+ *   fixed        T x B x n_fixed float32, or NULL when n_fixed == 0
+ *   last_inout   B x n_opt float32: SeqRetargeting.last_qpos of every sequence before frame 0 / after frame T-1
+ *   state_inout  B uint32 DexPilot bits (may be NULL)
+ *   qpos_raw_out T x B x n_opt float32: the optimiser's answer for every frame (what the reference stores in last_qpos)
+ *   status_out   T x B int32 or NULL
+ *   joint_limit_eps: the epsilon set_joint_limit widened the box by (optimizer.py:54-60; 1e-3 in the reference): the
+ *                carried value is clipped to [lo + eps, hi - eps] of the model's box, i.e. to the joint limits.
+ * Models whose default options include the float64 polish launch run their sequences in float64 arithmetic instead
+ * (a polish pass cannot be interleaved with the carry).  DEVICE pointers; enqueues on `stream`, no synchronisation. */
+int dexr_retarget_seq_dev(const dexr_model* m, int64_t B, int32_t T, const float* inputs, int32_t inputs_are_keypoints,
+                          const float* fixed, float* last_inout, uint32_t* state_inout, float* qpos_raw_out,
+                          int32_t* status_out, float joint_limit_eps, const dexr_solve_options* opt, void* stream);
+
+/* The rest of SeqRetargeting.retarget for T x B frames (seq_retarget.py:125-133): robot_qpos = zeros; [fixed joints] =
+ * fixed_qpos; [target joints] = qpos; mimic joints = source * multiplier + offset (kinematics_adaptor.py:102-105,
+ * float64); then LPFilter.next (optimizer_utils.py:7-13): first frame passes through, afterwards y += alpha (x - y).
+ *   dof_kind / dof_idx / dof_mult / dof_off: HOST arrays of length n_q (<= DEXR_MAX_DOF) describing every robot dof in
+ *     pinocchio order: kind 0 = target joint (idx = column of qpos_raw), 1 = fixed joint (idx = column of fixed),
+ *     2 = mimic joint (idx = source dof, value = mult * value(source) + off)
+ *   qpos_raw T x B x n_opt float32, fixed T x B x n_fixed float32 or NULL                       (DEVICE)
+ *   alpha: low-pass coefficient in [0, 1]; anything else = no filter (retargeting_config.py:232-235)
+ *   filter_inout B x n_q float64 = LPFilter.y of every sequence (DEVICE; ignored without a filter);
+ *   first_frame_initialises: 1 when the filters have not seen a frame yet (LPFilter.is_init == False)
+ *   robot_qpos_out T x B x n_q float64 (DEVICE), the value SeqRetargeting.retarget returns for every frame. */
+#define DEXR_MAX_DOF 64
+int dexr_seq_compose_dev(int64_t B, int32_t T, int32_t n_q, int32_t n_opt, int32_t n_fixed, const int32_t* dof_kind,
+                         const int32_t* dof_idx, const double* dof_mult, const double* dof_off, const float* qpos_raw,
+                         const float* fixed, double alpha, double* filter_inout, int32_t first_frame_initialises,
+                         double* robot_qpos_out, void* stream);
+
+/* ---- mixed-fleet batches (BASELINE.json configs[4]; SURVEY.md section 8b `dexr_retarget_multi`) -------------------------
+ * B frames; frame b is retargeted to models[model_id[b]].  Frames are bucketed by model ON THE DEVICE (count, offsets,
+ * index lists -- wavefronts must be model-uniform because the kinematic tables are scalar operands), every model's
+ * solve kernel is enqueued over its index list, reading its bucket's size from device memory and reading / writing
+ * the caller's rows in place: no gather / scatter copies and no host synchronisation anywhere.
+ *   models     n_models <= DEXR_FLEET_MAX_MODELS handles, each with target_link_human_indices (keypoint input)
+ *              and no caller-supplied fixed joints
+ *   model_id   B int32 in [0, n_models); frames with another id are left untouched
+ *   keypoints  B x 21 x 3 float32: every model forms its own ref_value rows
+ *   last, qpos_out  B x ld float32 rows, ld >= max n_opt; a model reads / writes its first n_opt columns
+ *   state      B uint32 in/out (read and written for frames of DexPilot models only; may be NULL)
+ *   status_out B int32 or NULL
+ *   workspace  dexr_fleet_workspace_bytes(B) bytes of device memory (contents irrelevant)
+ * All pointers except `models` are DEVICE pointers; enqueues on `stream`. */
+#define DEXR_FLEET_MAX_MODELS 16
+size_t dexr_fleet_workspace_bytes(int64_t B);
+int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, int64_t B, const int32_t* model_id,
+                            const float* keypoints, const float* last, int32_t ld, uint32_t* state, float* qpos_out,
+                            int32_t* status_out, const dexr_solve_options* opt, void* workspace, size_t workspace_bytes,
+                            void* stream);
 
 /* The step right before the path: raw detector keypoints -> wrist-centred keypoints in the MANO frame, x B.
  *   kp_c = kp - kp[0];  R = estimate_frame_from_hand_points(kp_c);  joint_pos = kp_c @ R @ operator2mano

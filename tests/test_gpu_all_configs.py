@@ -78,6 +78,19 @@ def table(require_gpu):
             rows[rel]["cert"] = (sel,) + tuple(fut.result())
     out = os.path.join(REPO, "gpurun_out")
     os.makedirs(out, exist_ok=True)
+    # the frames behind every ">= 1e-4" entry, for off-line analysis (inputs, both answers)
+    dump = {}
+    for rel, w in rows.items():
+        sel = np.nonzero(w["far"])[0][:256]
+        if len(sel):
+            k = rel.replace("/", "__").replace(".yml", "")
+            r = w["r"]
+            dump[k + "__idx"], dump[k + "__ref"], dump[k + "__last"] = sel, r["ref"][sel], r["last"][sel]
+            dump[k + "__q_gpu"], dump[k + "__q_oracle"] = r["q"][sel], w["o"]["want"][sel]
+            dump[k + "__iters"] = r["info"]["iters"][sel]
+            if r["st_in"] is not None:
+                dump[k + "__state_in"] = r["st_in"][sel]
+    np.savez_compressed(os.path.join(out, "all_configs_far_frames.npz"), **dump)
     with open(os.path.join(out, "all_configs_parity.txt"), "w") as f:
         f.write(f"# {B} frames per config, library defaults; dq = max_j |q_gpu - q_oracle| (float64 oracle LM/Newton on F)\n")
         f.write(f"{'config':44s} {'kernel':>14s} {'p50 dq':>9s} {'p99.9 dq':>9s} {'max dq':>9s} {'>=1e-4':>7s} {'not worse':>9s} "
