@@ -226,6 +226,78 @@ class Workload:
                 "kernel": kname, "kernel_ms": kernel_ms, "algorithmic_bytes_per_frame": bpf}
 
 
+def sequence_record(wl, torch, T=100, reps=3):
+    """Sequence mode: B lock-step sequences of T frames each.  Fused = two kernel launches
+    per T x B frames (dexr_retarget_seq_dev: every lane loops over its sequence's frames carrying last_qpos;
+    dexr_seq_compose_dev: robot qpos, mimic fill, low-pass filter).  Frame-by-frame = one solve launch + ~10 torch
+    element-wise launches per frame, replayed from a HIP graph.  Keypoints: sequence b plays the human fixture from
+    phase 37 b (+ 2 mm noise), so consecutive frames of a sequence are consecutive fixture frames."""
+    import bench_data
+    from dex_retargeting_amd.retargeting_config import RetargetingConfig
+
+    B, dev = wl.B, wl.dev
+    cfg = RetargetingConfig.load_from_file(os.path.join(bench_data.CONFIG_DIR, wl.rel))
+    fixture = torch.from_numpy(np.load(bench_data.HUMAN_FIXTURE)).to(dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(bench_data.SEED)
+    idx = (torch.arange(B, device=dev)[None, :] * 37 + torch.arange(T + 1, device=dev)[:, None]) % fixture.shape[0]
+    kp = fixture[idx] + 2e-3 * torch.randn((T + 1, B, 21, 3), generator=g, device=dev)
+    kp[:, :, 0] = 0.0
+    kp = kp.contiguous()
+    out = {}
+    fused = cfg.build_device(B)
+    fused.retarget_keypoints(kp[0])  # frame 0: from the limit midpoint (untimed), initialises the filter
+    raw = torch.empty((T, B, fused.n_opt), dtype=torch.float32, device=dev)
+    res = torch.empty((T, B, fused.robot_qpos.shape[1]), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream()
+    state0 = (fused.last_qpos.clone(), fused.filtered.clone(), fused.state.clone())
+
+    def rewind(obj):
+        obj.last_qpos.copy_(state0[0])
+        obj.filtered.copy_(state0[1])
+        obj.state.copy_(state0[2])
+
+    fused.retarget_sequence(kp[1:], out=res, raw_out=raw)  # warm-up
+    ms = []
+    for _ in range(reps):
+        rewind(fused)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        fused.retarget_sequence(kp[1:], out=res, raw_out=raw)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    out["fused"] = {"ms_per_T_frames": float(np.median(ms)), "frames_per_s": B * T / (float(np.median(ms)) * 1e-3),
+                    "launches_per_T_frames": 2}
+    res_fused = res.clone()
+    # frame-by-frame, captured into a HIP graph in chunks of Tg frames (capturing 100 frames x ~12 launches is slow)
+    step = cfg.build_device(B)
+    step.retarget_keypoints(kp[0])
+    Tg = 20
+    buf = torch.empty((Tg, B, 21, 3), dtype=torch.float32, device=dev)
+    graph, gout = step.capture(buf)
+    ms = []
+    for r in range(reps):
+        rewind(step)
+        t_ms = 0.0
+        for c in range(T // Tg):
+            buf.copy_(kp[1 + c * Tg: 1 + (c + 1) * Tg])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            graph.replay()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            t_ms += e0.elapsed_time(e1)
+            if r == 0 and c == T // Tg - 1:
+                diff = (gout - res_fused[c * Tg:(c + 1) * Tg]).abs().amax(dim=2)
+                out["max_abs_diff_fused_vs_stepwise_rad_p99"] = float(torch.quantile(diff.flatten()[:1000000].float(), 0.99))
+        ms.append(t_ms)
+    out["frame_by_frame_hip_graph"] = {"ms_per_T_frames": float(np.median(ms)), "frames_per_s": B * T / (float(np.median(ms)) * 1e-3),
+                                       "launches_per_T_frames": "T x (1 solve + ~10 element-wise), replayed from HIP graphs of 20 frames"}
+    out.update({"T": T, "sequences": B, "unit": "frames/s", "config_file": wl.rel})
+    return out
+
+
 def parity_block(wl, batch, q_gpu, n_par, n_slsqp):
     """Checker (oracle) section: max |dq| against the float64 oracle minimiser of F on the first n_par frames of
     `batch`, and the distance to the reference-as-configured SLSQP answers on the first n_slsqp."""
@@ -355,6 +427,11 @@ def run_single(args):
                              "roofline": wl.roofline(kc, dc["iters_mean"], batch_kind="ref"),
                              "workload": "reachable targets (the robot's own FK at q* ~ U(limits)), start = q* + 0.5 rad "
                                          "N(0,1) clipped to the limits: tests/test_optimizer.py:27-81 of the reference"}
+    if rank == 0 and not args.headline_only:
+        try:
+            sub["sequence_mode"] = sequence_record(wl, torch)
+        except Exception as e:  # never lose the headline line to a sub-record
+            sub["sequence_mode"] = {"error": repr(e)}
     also = {}
     if rank == 0 and not args.headline_only and args.workload == "allegro_vector":
         for name in ("shadow_dexpilot", "leap_position"):

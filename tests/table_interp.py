@@ -62,3 +62,40 @@ def frame_positions(comp, q):
         for f in range(int(comp["fbeg"][k]), int(comp["fend"][k])):
             P[:, f] = p + R @ comp["frame_off"][f].astype(np.float64)
     return P, axes, orgs
+
+
+def solve_vector(compiled, ref, last, iters=6, scaling=None, norm_delta=None):
+    """Test-only CPU solve over the compiled tables of a VECTOR model: `iters` damped Gauss-Newton steps on
+    sum_t |p_task - p_origin - s ref_t|^2 / V + norm_delta |x - last|^2 per component, projected onto the box.  Not the
+    product's algorithm and not the oracle: deterministic per-item work that depends on every input of the item, for
+    tests that need a real table-driven solve on a machine without a GPU (multi-process sharding tests)."""
+    h = compiled.header
+    s = float(h["scaling"]) if scaling is None else scaling
+    nd = float(h["norm_delta"]) if norm_delta is None else norm_delta
+    B = last.shape[0]
+    x = np.array(last, dtype=np.float64)
+    for comp in compiled.comps:
+        nj, nt = int(comp["n_joint"]), int(comp["n_term"])
+        api = comp["api"][:nj].astype(int)
+        lo, hi = comp["lo"][:nj].astype(np.float64), comp["hi"][:nj].astype(np.float64)
+        x[:, api] = np.clip(x[:, api], lo, hi)
+        for _ in range(iters):
+            q = joint_values(comp, x=x, fixed=np.zeros((B, 1)))
+            P, axes, orgs = frame_positions(comp, q)
+            g = np.zeros((B, nj))
+            H = np.zeros((B, nj, nj))
+            for t in range(nt):
+                ft, fo = int(comp["term_task"][t]), int(comp["term_origin"][t])
+                r = P[:, ft] - (P[:, fo] if fo >= 0 else 0.0) - s * ref[:, int(comp["term_ref"][t])].astype(np.float64)
+                J = np.zeros((B, 3, nj))
+                for k in range(nj):
+                    for f, sg in ((ft, 1.0), (fo, -1.0)):
+                        if f >= 0 and (int(comp["frame_anc"][f]) >> k) & 1:
+                            J[:, :, k] += sg * np.cross(axes[k], P[:, f] - orgs[k])
+                g += np.einsum("bck,bc->bk", J, r) / nt
+                H += np.einsum("bck,bcl->bkl", J, J) / nt
+            dx = x[:, api] - last[:, api].astype(np.float64)
+            g = 2 * g + 2 * nd * dx
+            H = 2 * H + (2 * nd + 1e-3) * np.eye(nj)[None]
+            x[:, api] = np.clip(x[:, api] - np.linalg.solve(H, g[..., None])[..., 0], lo, hi)
+    return x.astype(np.float32)

@@ -1,8 +1,12 @@
 """world_size-2 gloo tests (CPU) of the N > 1 path: contiguous sharding + one all-gather reassembles exactly what a
-single process would have produced.  The per-shard solver is injected (the HIP solve needs a GPU); what is
-tested is the partition, padding, ordering and state plumbing that bench.py / ShardedRetargeter rely on."""
+single process would have produced.  The HIP solve needs a GPU, so the per-shard solver injected here is a CPU
+interpreter of the SAME compiled kinematic tables (tests/table_interp.solve_vector: table-driven FK, Jacobians and
+damped Gauss-Newton steps -- real per-item work whose result depends on every input of the item), plus a trivial
+stand-in for the DexPilot state plumbing.  What is tested is the partition, padding, ordering and state handling that
+bench.py / ShardedRetargeter rely on."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -22,10 +26,42 @@ def test_shard_bounds_partition():
         shard_bounds(10, 2, 2)
 
 
-def _fake_solve(ref, fixed, last, state):
+_compiled = {}
+
+
+def _allegro_tables():
+    if "m" not in _compiled:
+        from dex_retargeting_amd.constants import DEFAULT_URDF_DIR
+        from dex_retargeting_amd.retargeting_config import RetargetingConfig
+        from oracle import cases
+
+        RetargetingConfig.set_default_urdf_dir(str(DEFAULT_URDF_DIR))
+        seq = RetargetingConfig.load_from_file(os.path.join(cases.CONFIG_DIR, "teleop/allegro_hand_right.yml")).build()
+        _compiled["m"] = (seq.optimizer.compiled_model(), seq.joint_limits)
+    return _compiled["m"]
+
+
+def _inputs(B):
+    """Same seeded inputs on every rank: human-keypoint vectors and a start inside the joint limits."""
+    from oracle import cases
+
+    _, lim = _allegro_tables()
+    rng = np.random.default_rng(0)
+    kp = cases.human_keypoints(B, seed=1)
+    ref = (kp[:, [4, 8, 12, 16]] - kp[:, [0, 0, 0, 0]]).astype(np.float32)
+    last = rng.uniform(lim[:, 0], lim[:, 1], (B, lim.shape[0])).astype(np.float32)
+    return ref, last
+
+
+def _table_solve(ref, fixed, last, state):
+    """Per-shard solver: CPU interpreter of the compiled Allegro tables (real, input-dependent per-item work)."""
+    import table_interp
+
     if state is not None:
         state[:] = (state + 1) * 3
-    return (last * 2 + ref.reshape(ref.shape[0], -1).sum(1, keepdims=True)).astype(np.float32)
+    if last.shape[0] == 0:
+        return np.zeros_like(last, dtype=np.float32)
+    return table_interp.solve_vector(_allegro_tables()[0], ref, last, iters=3)
 
 
 def _worker(rank, world, port, B, out_dir):
@@ -36,11 +72,10 @@ def _worker(rank, world, port, B, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    rng = np.random.default_rng(0)  # same inputs on every rank
-    ref = rng.standard_normal((B, 4, 3)).astype(np.float32)
-    last = rng.standard_normal((B, 16)).astype(np.float32)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    ref, last = _inputs(B)
     state = np.arange(B, dtype=np.uint32)
-    sr = ShardedRetargeter(solve=_fake_solve, device="cpu")
+    sr = ShardedRetargeter(solve=_table_solve, device="cpu")
     q = sr.retarget(ref, None, last, state)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), q=q, state=state)
     dist.destroy_process_group()
@@ -55,11 +90,10 @@ def test_two_rank_gloo_allgather_equals_single_process(tmp_path, B):
     port = s.getsockname()[1]
     s.close()
     mp.spawn(_worker, args=(2, port, B, str(tmp_path)), nprocs=2, join=True)
-    rng = np.random.default_rng(0)
-    ref = rng.standard_normal((B, 4, 3)).astype(np.float32)
-    last = rng.standard_normal((B, 16)).astype(np.float32)
+    ref, last = _inputs(B)
     st = np.arange(B, dtype=np.uint32)
-    want = _fake_solve(ref, None, last, st)
+    want = _table_solve(ref, None, last, st)
+    assert np.abs(want - last).max() > 1e-2  # the solver moved the joints: real work was sharded
     for r in range(2):
         got = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
         assert np.array_equal(got["q"], want)
