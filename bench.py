@@ -52,7 +52,8 @@ WORKLOADS = {
     "mixed_fleet": (None, "Mixed fleet: Allegro vector + Shadow DexPilot + LEAP vector + Ability vector, frames interleaved"),
 }
 KERNEL_NAMES = {0: "dexr_kernel (one lane per frame and component, Hessian in registers)",
-                1: "dexr_quad_kernel (four lanes per frame)", 2: "dexr_big_kernel (Hessian in LDS)"}
+                1: "dexr_quad_kernel (four lanes per frame)", 2: "dexr_big_kernel (Hessian in LDS)",
+                3: "dexr_red_kernel (reduced variables: Hessian in registers, kinematics in LDS)"}
 
 
 def algorithmic_bytes_per_frame(n_opt: int, dexpilot: bool, n_rows: int, keypoints: bool) -> int:

@@ -97,6 +97,12 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             continue
         if force or _stale(o, [quad_s, QUAD_HEADER, BIG_HEADER] + HEADERS):
             jobs.append((quad_s, o, NO_SLP + [f"-DDEXR_NMAX={n}"]))
+    red_s = os.path.join(CSRC, "dexr_red_inst.hip")
+    for nvb in (8, 16):  # reduced-variable kernel (mimic models): Hessian of the variables in registers
+        o = os.path.join(BUILD, f"dexr_red_{nvb}.o")
+        objs.append(o)
+        if force or _stale(o, [red_s, os.path.join(CSRC, "dexr_red.hpp"), BIG_HEADER] + HEADERS):
+            jobs.append((red_s, o, NO_SLP + [f"-DDEXR_NV={nvb}"]))
     for n, f64 in ((4, 0), (8, 0), (4, 1), (8, 1)):  # small components with fleet / sequence addressing (EXT)
         o = os.path.join(BUILD, f"dexr_inst_ext_{n}_{f64}_0.o")
         objs.append(o)

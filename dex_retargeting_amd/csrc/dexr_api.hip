@@ -55,6 +55,9 @@ struct dexr_model {
   bool chain = false;  // every component is a plain serial chain filling its bucket (CHAIN kernel applies)
   bool quad = false;   // dense 9..24-joint components solved four lanes per frame (dexr_quad_kernel)
   bool big = false;    // components of 9+ joints solved by dexr_big_kernel (Hessian in LDS, float64 kinematics)
+  bool red = false;    // solved in reduced variables by dexr_red_kernel (Hessian of the variables in registers)
+  int red_nv = 0;      // its variable bucket (8 or 16), 0 when the model does not fit
+  int max_joints = 0, max_vars = 0;
   int big_nh_rows = 0; // n_max (n_max + 1) / 2
   // work-queue heads for the persistent-lane kernels: QSLOTS independent sets of n_comp counters handed out
   // round-robin, so launches in flight on different streams never share a queue
@@ -142,6 +145,33 @@ int launch_big(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
   return DEXR_OK;
 }
 
+int launch_red(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
+  const size_t lds = (size_t)64 * (4 * 6 * (size_t)m->max_joints + 8 * 3 * (size_t)m->lds_frames);
+  kp.red_nj = m->max_joints;
+  // persistent lanes as in launch_big: the resident set is what the LDS (160 KB per CU) and the kernel's registers
+  // (NV = 8: two waves per SIMD, NV = 16: one) allow; each wave starts with a static 64-frame tile
+  const int64_t tiles = (kp.B + 63) / 64;
+  int64_t per_cu = (int64_t)((160 * 1024) / (lds > 0 ? lds : 1));
+  const int64_t reg_cap = m->red_nv <= 8 ? 8 : 4;
+  per_cu = per_cu < 1 ? 1 : (per_cu > reg_cap ? reg_cap : per_cu);
+  int64_t resident = (int64_t)m->n_cu * per_cu;
+  if (m->tune.resident_waves > 0) resident = m->tune.resident_waves;
+  int64_t per_comp = (resident + kp.n_comp - 1) / kp.n_comp;
+  if (per_comp > tiles) per_comp = tiles;
+  const int64_t blocks = per_comp * kp.n_comp;
+  if (blocks > 0x7fffffffLL) return fail(DEXR_ERR_INVALID, "batch too large for one launch");
+  kp.q0 = (uint32_t)(per_comp * 64);
+  const unsigned slot = m->qnext.fetch_add(1u) % dexr_model::QSLOTS;
+  kp.queue = m->d_queue + (size_t)slot * kp.n_comp;
+  hipError_t qe = hipMemsetAsync(kp.queue, 0, (size_t)kp.n_comp * sizeof(unsigned), st);
+  if (qe != hipSuccess) return fail(DEXR_ERR_HIP, "queue reset failed: %s", hipGetErrorString(qe));
+  dexr::launch_fn fn = dexr::find_red_launcher(m->red_nv);
+  if (!fn) return fail(DEXR_ERR_UNSUPPORTED, "no reduced-variable kernel for %d variables", m->max_vars);
+  hipError_t e = fn(kp, dim3((unsigned)blocks), dim3(64), lds, st);
+  if (e != hipSuccess) return fail(DEXR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return DEXR_OK;
+}
+
 int launch_quad(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
   const size_t per_wave = (size_t)64 * (8 * 3 * (size_t)m->lds_frames + 4 * 3 * (size_t)m->bucket + 4 * (size_t)m->bucket);
   int wpb = 4;
@@ -172,6 +202,7 @@ int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStr
   if (kp.B <= 0) return DEXR_OK;
   // fleet buckets / frame sequences / padded rows need the kernels with extended addressing (KernelParams)
   const bool ext = kp.perm != nullptr || kp.bucket != nullptr || kp.T > 0 || kp.ld != kp.n_opt;
+  if (mode == dexr::MODE_SOLVE && !f64 && m->red) return launch_red(m, kp, st);
   if (mode == dexr::MODE_SOLVE && !f64 && m->quad) {
     return launch_quad(m, kp, st);
   }
@@ -260,8 +291,16 @@ void select_kernels(dexr_model* m) {
   const bool big_ok = m->bucket >= 16 && h.kind != DEXR_KIND_FKONLY && m->max_slot < 2 && lds <= 160 * 1024;
   const bool quad_wins = h.kind == DEXR_KIND_DEXPILOT || h.kind == DEXR_KIND_POSITION;
   const bool big_wins = h.kind == DEXR_KIND_POSITION || m->bucket == 32;
-  m->quad = quad_ok && (want == DEXR_KERNEL_QUAD || (want == DEXR_KERNEL_AUTO && quad_wins));
-  m->big = !m->quad && big_ok && (want == DEXR_KERNEL_LDS || (want == DEXR_KERNEL_AUTO && big_wins));
+  // reduced variables: the Hessian of the n_var <= 16 optimised variables in registers, the kinematics of the (up to
+  // 32) joints in LDS.  Serves the models with mimic joints whose components outgrow the small kernels (Ability /
+  // Inspire DexPilot and position models, every Schunk SVH model): their joint-space Hessian is 2-3 x the size.
+  m->red_nv = m->max_vars <= 8 ? 8 : (m->max_vars <= 16 ? 16 : 0);
+  const size_t red_lds = (size_t)64 * (4 * 6 * (size_t)m->max_joints + 8 * 3 * (size_t)m->lds_frames);
+  const bool red_ok = m->red_nv > 0 && h.kind != DEXR_KIND_FKONLY && m->max_slot < 2 && red_lds <= 160 * 1024 && m->max_joints > 0;
+  const bool red_wins = m->has_mimic && m->bucket >= 16;
+  m->red = red_ok && (want == DEXR_KERNEL_REDUCED || (want == DEXR_KERNEL_AUTO && red_wins));
+  m->quad = !m->red && quad_ok && (want == DEXR_KERNEL_QUAD || (want == DEXR_KERNEL_AUTO && quad_wins));
+  m->big = !m->red && !m->quad && big_ok && (want == DEXR_KERNEL_LDS || (want == DEXR_KERNEL_AUTO && big_wins));
   // the quad kernel scales its damping jump by the curvature along the failed step (not by mean diag H)
   // serial-chain specialisation (LocalTab keeps LF frames / LT terms in registers): every component must be an
   // unbranched chain of exactly `bucket` revolute optimised joints with at most LF frames and LT terms
@@ -295,9 +334,10 @@ void apply_options(const dexr_model* m, dexr::KernelParams& kp, const dexr_solve
 // regularised towards the ORIGINAL last_qpos.  Stream-ordered after the float32 launch.
 bool polish_wanted(const dexr_model* m, const dexr_solve_options* opt) {
   int polish = opt ? opt->polish : -1;
-  if (polish < 0) polish = (m->h.kind == DEXR_KIND_POSITION || m->h.kind == DEXR_KIND_DEXPILOT) ? 12 : 0;
+  if (polish < 0) polish = (m->h.kind == DEXR_KIND_POSITION || m->h.kind == DEXR_KIND_DEXPILOT) ? 24 : 0;
   if (polish == 0 || m->bucket == 32) return false;
   const int strict = opt ? opt->strict : 0;
+  if (m->red && strict <= 0) return false;  // reduced-variable kernel: float64 kinematics and value, see dexr_red.hpp
   if ((m->big || m->quad) && !(strict > 0 || (strict == 0 && m->has_mimic))) return false;
   return true;
 }
@@ -311,7 +351,7 @@ bool polish_wanted(const dexr_model* m, const dexr_solve_options* opt) {
 int polish_launch(const dexr_model* m, dexr::KernelParams kp, const dexr_solve_options* opt, hipStream_t st) {
   if (!polish_wanted(m, opt)) return DEXR_OK;
   int polish = opt ? opt->polish : -1;
-  if (polish < 0) polish = 12;
+  if (polish < 0) polish = 24;
   kp.x0 = kp.qout;
   kp.max_iter = polish;
   kp.tol *= 0.25f;
@@ -338,7 +378,7 @@ extern "C" {
 
 const char* dexr_last_error(void) { return g_err.c_str(); }
 
-const char* dexr_version(void) { return "dexr 0.1 (gfx950; table v4)"; }
+const char* dexr_version(void) { return "dexr 0.2 (gfx950; table v5)"; }
 
 int dexr_device_count(void) {
   int n = 0;
@@ -407,11 +447,28 @@ int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out) {
         return fail(DEXR_ERR_INVALID, "term record %d malformed", t);
       }
     }
+    {
+      bool bad = c.n_var < 0 || c.n_var > c.n_joint;
+      int n_opt_joints = 0;
+      for (int k = 0; k < c.n_joint && !bad; ++k) {
+        const bool moves = c.src_kind[k] == DEXR_SRC_OPT || c.src_kind[k] == DEXR_SRC_MIMIC;
+        if (c.src_kind[k] == DEXR_SRC_OPT) ++n_opt_joints;
+        bad = moves ? (c.var[k] < 0 || c.var[k] >= c.n_var) : (c.var[k] != -1);
+        if (!bad && c.src_kind[k] == DEXR_SRC_OPT) bad = c.var_joint[c.var[k]] != k || c.vmul[k] != 1.0f;
+        if (!bad && c.src_kind[k] == DEXR_SRC_MIMIC) bad = c.var[k] != c.var[c.src_idx[k]] || c.vmul[k] != c.mult[k];
+      }
+      if (bad || (h.kind != DEXR_KIND_FKONLY && n_opt_joints != c.n_var)) {
+        delete m;
+        return fail(DEXR_ERR_INVALID, "reduced-variable map of a component is malformed");
+      }
+      if (c.n_var > m->max_vars) m->max_vars = c.n_var;
+    }
     if (c.n_joint > maxj) maxj = c.n_joint;
     if (c.n_frame > m->lds_frames) m->lds_frames = c.n_frame;
     if (c.n_term > m->lds_terms) m->lds_terms = c.n_term;
   }
   m->bucket = pick_bucket(maxj > 0 ? maxj : 1);
+  m->max_joints = maxj;
   m->big_nh_rows = maxj * (maxj + 1) / 2;
   for (const dexr_comp_table& c : m->comps)
     for (int k = 0; k < c.n_joint; ++k) {
@@ -474,7 +531,7 @@ int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning) {
   dexr_tuning t = m->tune;  // fields beyond the caller's (older, shorter) struct keep their values
   std::memcpy(&t, tuning, tuning->struct_size);
   t.struct_size = (uint32_t)sizeof(dexr_tuning);
-  if (t.kernel < DEXR_KERNEL_AUTO || t.kernel > DEXR_KERNEL_LDS) return fail(DEXR_ERR_INVALID, "unknown kernel family %d", t.kernel);
+  if (t.kernel < DEXR_KERNEL_AUTO || t.kernel > DEXR_KERNEL_REDUCED) return fail(DEXR_ERR_INVALID, "unknown kernel family %d", t.kernel);
   if (t.persist_from < 0 || t.qchunk < 0 || t.persist_occ < 0 || t.resident_waves < 0 || t.max_blind < 0)
     return fail(DEXR_ERR_INVALID, "negative launch parameter");
   if (!(t.step_cap >= 0) || !(t.lam_jump >= 0) || !(t.lam_fastdec >= 0) || !(t.floor_scale >= 0) || !(t.blind_tol_scale >= 0))
@@ -486,7 +543,7 @@ int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning) {
 
 int dexr_model_kernel(const dexr_model* m, int32_t* family, int32_t* bucket, int32_t* chain) {
   if (!m) return fail(DEXR_ERR_INVALID, "null argument");
-  if (family) *family = m->quad ? DEXR_KERNEL_QUAD : m->big ? DEXR_KERNEL_LDS : DEXR_KERNEL_REGISTER;
+  if (family) *family = m->red ? DEXR_KERNEL_REDUCED : m->quad ? DEXR_KERNEL_QUAD : m->big ? DEXR_KERNEL_LDS : DEXR_KERNEL_REGISTER;
   if (bucket) *bucket = m->bucket;
   if (chain) *chain = m->chain ? 1 : 0;
   return DEXR_OK;

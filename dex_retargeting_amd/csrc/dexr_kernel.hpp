@@ -52,6 +52,7 @@ struct KernelParams {
   int32_t max_blind;  // accepted steps below the rounding floor of F before giving up on further progress
   int32_t lds_frames, lds_terms;  // per-wave LDS rows: max frames / max terms over the model's components
   int32_t big_nh_rows;            // dexr_big_kernel: LDS rows reserved for the Hessian (n_max (n_max + 1) / 2)
+  int32_t red_nj;                 // dexr_red_kernel: joints per component the LDS axis / origin rows are sized for
   float blind_tol;                // a Newton step of a verified, undamped model shorter than this is taken without a
                                   // further evaluation of the objective and ends the solve (0: off)
   float step_cap;                 // trust radius: a step whose largest component exceeds it is scaled down to it (0: off)
@@ -899,7 +900,10 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
         // The model at the accepted point is verified and (lambda back at its floor) undamped: a Newton step this short
         // is the converged answer to well below the tolerance, evaluating the objective there once more could only
         // confirm it.  Take it and retire the frame one pass earlier.
-        last_step = stepping && ok && smax < (real)kp.blind_tol && lam <= (real)kp.lam0;
+        // Beyond 10 tol this is only trusted on the fast (quadratic) tail of a Newton iteration: the step must be at most a
+        // tenth of the previous accepted one -- in a nearly flat valley steps shrink slowly and C s^2 is not small.
+        last_step = stepping && ok && smax < (real)kp.blind_tol && lam <= (real)kp.lam0 &&
+                    (smax < (real)10 * (real)kp.tol || smax < (real)0.1 * sprev);
       }
 
       // (3) forward kinematics + fused value / gradient / Hessian at S.x

@@ -48,6 +48,13 @@ static inline launch_fn find_quad_launcher(int bucket) {
   return bucket == 16 ? launch_quad_16 : bucket == 24 ? launch_quad_24 : nullptr;
 }
 
+// reduced-variable kernel (dexr_red.hpp): Hessian of the n_var <= NV optimised variables in registers, kinematics in LDS
+hipError_t launch_red_8(const KernelParams&, dim3, dim3, size_t, hipStream_t);
+hipError_t launch_red_16(const KernelParams&, dim3, dim3, size_t, hipStream_t);
+static inline launch_fn find_red_launcher(int nv_bucket) {
+  return nv_bucket == 8 ? launch_red_8 : nv_bucket == 16 ? launch_red_16 : nullptr;
+}
+
 static inline launch_fn find_launcher(int bucket, int f64, int mode, bool chain = false, bool ext = false) {
   if (ext && mode == MODE_SOLVE && bucket <= 8) {
     if (chain && bucket == 4 && !f64) return launch_ext_chain_4_0_0;

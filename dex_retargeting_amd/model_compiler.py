@@ -25,7 +25,7 @@ import numpy as np
 from .urdf import KinematicModel
 
 MAXJ, MAXF, MAXT, NSLOT = 32, 16, 16, 3
-MAGIC, VERSION = 0x52584544, 4
+MAGIC, VERSION = 0x52584544, 5
 KIND_VECTOR, KIND_POSITION, KIND_DEXPILOT, KIND_FKONLY = 0, 1, 2, 3
 SRC_OPT, SRC_FIXED, SRC_MIMIC, SRC_DIRECT = 0, 1, 2, 3
 
@@ -38,6 +38,7 @@ COMP_DTYPE = np.dtype([
     ("mult", "<f4", (MAXJ,)), ("off", "<f4", (MAXJ,)), ("lo", "<f4", (MAXJ,)), ("hi", "<f4", (MAXJ,)),
     ("frame_joint", "<i4", (MAXF,)), ("frame_off", "<f4", (MAXF, 3)), ("frame_anc", "<u4", (MAXF,)),
     ("term_task", "<i4", (MAXT,)), ("term_origin", "<i4", (MAXT,)), ("term_ref", "<i4", (MAXT,)),
+    ("n_var", "<i4"), ("var", "<i4", (MAXJ,)), ("vmul", "<f4", (MAXJ,)), ("var_joint", "<i4", (MAXJ,)),
 ])
 HEADER_DTYPE = np.dtype([
     ("magic", "<u4"), ("version", "<u4"), ("kind", "<i4"), ("n_opt", "<i4"), ("n_fixed", "<i4"),
@@ -209,6 +210,20 @@ def _build_component(model: KinematicModel, joint_set: Sequence[int], frames: Li
             rec["mult"][k], rec["off"][k] = 1.0, 0.0
     rec["restore"][:nj] = restore
     rec["save"][:nj] = save
+    # reduced variables: optimised joints in joint order; mimic joints ride on their source's variable
+    rec["var"][:] = -1
+    rec["var_joint"][:] = -1
+    nv = 0
+    for k in range(nj):
+        if int(rec["src_kind"][k]) == SRC_OPT:
+            rec["var"][k], rec["vmul"][k] = nv, 1.0
+            rec["var_joint"][nv] = k
+            nv += 1
+    for k in range(nj):
+        if int(rec["src_kind"][k]) == SRC_MIMIC:
+            rec["var"][k] = rec["var"][int(rec["src_idx"][k])]
+            rec["vmul"][k] = rec["mult"][k]
+    rec["n_var"] = nv
 
     # frames sorted by attached local joint (base first), remember permutation for terms
     order = sorted(range(len(frames)), key=lambda i: (local[frames[i][1]] if frames[i][1] >= 0 else -1, i))

@@ -47,7 +47,7 @@ typedef struct dexr_solve_options {
                          reference's own arithmetic type; register kernel, no polish pass).  Device-pointer entry
                          points accept both; the result rows are float32 either way (optimizer.py:99)            */
   int32_t polish;     /* float64 polishing iterations run after the float32 solve, started at its answer:
-                         -1 auto (default: 12 for position / DexPilot models, whose float32 rounding floor sits
+                         -1 auto (default: up to 24 for position / DexPilot models, whose float32 rounding floor sits
                          near 1e-4 rad; 0 for vector models), 0 off, n > 0 at most n iterations           */
   int32_t strict;     /* float64 polish after the mixed-precision kernels (float64 kinematics, float32 gradient and
                          Hessian) that serve large components.  0 (default): only for models with mimic joints, whose
@@ -64,6 +64,8 @@ typedef struct dexr_solve_options {
 #define DEXR_KERNEL_REGISTER 0 /* one lane per (frame, component), Hessian in registers (dexr_kernel.hpp)            */
 #define DEXR_KERNEL_QUAD 1     /* four lanes per frame, distributed Hessian rows (dexr_quad.hpp)                      */
 #define DEXR_KERNEL_LDS 2      /* one lane per frame, Hessian in LDS (dexr_big.hpp)                                   */
+#define DEXR_KERNEL_REDUCED 3  /* one lane per frame, Hessian of the optimised VARIABLES (mimic joints folded while the
+                                  Jacobian is formed) in registers, kinematics in LDS (dexr_red.hpp)                   */
 typedef struct dexr_tuning {
   uint32_t struct_size; /* sizeof(dexr_tuning) of the caller's header: lets the struct grow compatibly          */
   int32_t kernel;       /* DEXR_KERNEL_*: float32 solve kernel family (AUTO: measured policy, dexr_api.hip)      */

@@ -22,7 +22,7 @@
 #include <stdint.h>
 
 #define DEXR_MAGIC 0x52584544u /* "DEXR" */
-#define DEXR_TABLE_VERSION 4u
+#define DEXR_TABLE_VERSION 5u
 
 #define DEXR_MAXJ 32  /* joints per component (bitmask width) */
 #define DEXR_MAXF 16  /* frames (target links) per component  */
@@ -65,6 +65,15 @@ typedef struct dexr_comp_table {
   int32_t term_task[DEXR_MAXT];   /* frame index                                                  */
   int32_t term_origin[DEXR_MAXT]; /* frame index, -1 for position terms                           */
   int32_t term_ref[DEXR_MAXT];    /* row of ref_value this term is compared with                  */
+  /* Reduced variables (kinematics_adaptor.py:102-113 folded at compile time): the component's optimised variables
+   * are numbered 0..n_var-1 in joint order; joint k moves with variable var[k] (its own for an optimised joint, its
+   * source's for a mimic joint, -1 for fixed-valued joints) as q_k = vmul[k] * x[var[k]] + off[k], so that
+   * dq_k/dx = vmul[k] and the Jacobian column of a variable is the vmul-weighted sum over its joint family.
+   * var_joint[v] is the local joint that IS variable v (its api / lo / hi apply). */
+  int32_t n_var;
+  int32_t var[DEXR_MAXJ];
+  float vmul[DEXR_MAXJ];
+  int32_t var_joint[DEXR_MAXJ];
 } dexr_comp_table;
 
 typedef struct dexr_model_header {

@@ -99,3 +99,67 @@ def solve_vector(compiled, ref, last, iters=6, scaling=None, norm_delta=None):
             H = 2 * H + (2 * nd + 1e-3) * np.eye(nj)[None]
             x[:, api] = np.clip(x[:, api] - np.linalg.solve(H, g[..., None])[..., 0], lo, hi)
     return x.astype(np.float32)
+
+
+def reduced_model(comp, header, P, axes, orgs, targets, weights, newton=True):
+    """Test-only numpy statement of the reduced-variable assembly of csrc/dexr_red.hpp for ONE frame (B = 1 arrays as
+    returned by frame_positions): gradient and Hessian of the data term in the component's variables, with mimic
+    joints folded while the Jacobian columns are formed and the second-order term accumulated from running per-variable
+    axis sums.  targets (n_term, 3), weights (n_term,) incl. the 1/V (or 1/3P) factor."""
+    nj, nt, nv = int(comp["n_joint"]), int(comp["n_term"]), int(comp["n_var"])
+    kind = int(header["kind"])
+    beta = float(header["huber_delta"])
+    g = np.zeros(nv)
+    H = np.zeros((nv, nv))
+    F = 0.0
+    for t in range(nt):
+        ft, fo = int(comp["term_task"][t]), int(comp["term_origin"][t])
+        pt = P[0, ft]
+        po = P[0, fo] if fo >= 0 else np.zeros(3)
+        r = pt - po - targets[t]
+        w = weights[t]
+        if kind == 1:  # position: SmoothL1 per coordinate
+            quad = np.abs(r) < beta
+            F += w * np.where(quad, 0.5 * r * r / beta, np.abs(r) - 0.5 * beta).sum()
+            f = w * np.where(quad, r / beta, np.sign(r))
+            hw = w * np.where(quad, 1.0 / beta, 0.0 if newton else 1.0 / np.maximum(np.abs(r), 1e-30))
+            kap = 0.0
+        else:
+            d = np.linalg.norm(r)
+            quad = d < beta
+            F += w * (0.5 * d * d / beta if quad else d - 0.5 * beta)
+            idd = 1.0 / beta if quad else 1.0 / d
+            psi = w * idd
+            f, hw = psi * r, np.full(3, psi)
+            kap = 0.0 if quad else psi * idd * idd
+        colv = np.zeros((nv, 3))
+        for chain, (fr, sg, pf) in enumerate(((ft, 1.0, pt), (fo, -1.0, po))):
+            if fr < 0:
+                continue
+            A = np.zeros((nv, 3))
+            seen = set()
+            for k in range(nj):
+                if not (int(comp["frame_anc"][fr]) >> k) & 1 or int(comp["var"][k]) < 0:
+                    continue
+                a, o = axes[k][0], orgs[k][0]
+                rev = int(comp["jtype"][k]) == 0
+                col = sg * (np.cross(a, pf - o) if rev else a)
+                v, m = int(comp["var"][k]), float(comp["vmul"][k])
+                e = np.cross(col, f)
+                if newton:
+                    for vv in seen:
+                        h = m * (A[vv] @ e)
+                        if vv == v:
+                            H[v, v] += 2 * h
+                        else:
+                            H[vv, v] += h
+                            H[v, vv] += h
+                    if rev:
+                        H[v, v] += m * m * (a @ e)
+                        A[v] += m * a
+                colv[v] += m * col
+                seen.add(v)
+        g += colv @ f
+        u = colv @ r
+        H += (colv * hw) @ colv.T - kap * np.outer(u, u)
+    return F, g, H

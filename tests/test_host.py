@@ -80,7 +80,7 @@ def test_table_struct_sizes_match_header():
     assert int(re.search(r"#define DEXR_MAXF (\d+)", h).group(1)) == mc.MAXF
     assert int(re.search(r"#define DEXR_MAXT (\d+)", h).group(1)) == mc.MAXT
     assert int(re.search(r"#define DEXR_TABLE_VERSION (\d+)u", h).group(1)) == mc.VERSION
-    words = 4 + mc.MAXJ * 12 + 8 * mc.MAXJ + 4 * mc.MAXJ + mc.MAXF * 5 + 3 * mc.MAXT
+    words = 4 + mc.MAXJ * 12 + 8 * mc.MAXJ + 4 * mc.MAXJ + mc.MAXF * 5 + 3 * mc.MAXT + 1 + 3 * mc.MAXJ
     assert mc.COMP_DTYPE.itemsize == 4 * words
     assert mc.HEADER_DTYPE.itemsize == 4 * (18 + 1 + 2 * mc.MAXT)
 
@@ -321,3 +321,46 @@ def test_table_blob_round_trip(tmp_path):
     assert int(back.header["n_keypoints"]) == 21 and back.header["human_task"][:3].tolist() == [4, 4, 4]
     with pytest.raises(ValueError):
         mc.CompiledModel.from_blob(cm.to_blob()[:-4])
+
+
+@pytest.mark.parametrize("rel", ["teleop/inspire_hand_right_dexpilot.yml", "teleop/schunk_svh_hand_right.yml",
+                                 "offline/ability_hand_right.yml", "offline/schunk_svh_hand_right.yml",
+                                 "teleop/allegro_hand_right_dexpilot.yml", "teleop/panda_gripper.yml"])
+def test_reduced_variable_assembly_matches_oracle_model(rel):
+    """The reduced-variable formulation of csrc/dexr_red.hpp (mimic joints folded while the Jacobian columns are formed;
+    second-order term from running per-variable axis sums; both kinematic chains of a vector term swept separately),
+    stated in numpy over the compiled tables (tests/table_interp.reduced_model), reproduces the oracle's gradient and
+    full Newton Hessian of the data term in the optimiser's variables."""
+    import table_interp as ti
+    from oracle import solvers
+
+    seq = RetargetingConfig.load_from_file(os.path.join(cases.CONFIG_DIR, rel)).build()
+    prob = cases.problem_from_config(rel)
+    cm = seq.optimizer.compiled_model()
+    B = 3
+    d = cases.human_set(prob, B, seed=5, sigma=0.3)
+    x = d["last"].astype(np.float64)
+    kw = {}
+    targets_all = (d["ref"].astype(np.float32) * np.float32(prob.scaling)).astype(np.float64) if prob.kind == "vector" else d["ref"].astype(np.float64)
+    w_all = np.full((B, prob.n_ref), 1.0 / (3 * prob.n_ref) if prob.kind == "position" else 1.0 / prob.n_ref)
+    if prob.kind == "dexpilot":
+        w, rv, _ = prob.dexpilot_preamble(d["ref"], np.zeros((B, prob.n_pair), bool))
+        kw = dict(weights=w, dexpilot_ref=rv)
+        targets_all, w_all = rv, w / prob.n_ref
+    F, g, H = solvers._model(prob, x, d["ref"], None, x, kw, newton=True)  # last = x: no regulariser in g
+    H = H - 2 * prob.norm_delta * np.eye(prob.n_opt)[None]
+    for b in range(B):
+        gg, HH, FF = np.zeros(prob.n_opt), np.zeros((prob.n_opt, prob.n_opt)), 0.0
+        for comp in cm.comps:
+            q = ti.joint_values(comp, x=x[b:b + 1], fixed=np.zeros((1, 1)))
+            P, axes, orgs = ti.frame_positions(comp, q)
+            nt, nv = int(comp["n_term"]), int(comp["n_var"])
+            rows = comp["term_ref"][:nt].astype(int)
+            f_, g_, H_ = ti.reduced_model(comp, cm.header, P, axes, orgs, targets_all[b][rows], w_all[b][rows])
+            api = np.array([int(comp["api"][int(comp["var_joint"][v])]) for v in range(nv)])
+            gg[api] += g_
+            HH[np.ix_(api, api)] += H_
+            FF += f_
+        assert abs(FF - F[b]) < 1e-6 * max(1.0, abs(F[b]))
+        assert np.abs(gg - g[b]).max() < 2e-6 * max(1.0, np.abs(g[b]).max()), rel   # float32 table entries
+        assert np.abs(HH - H[b]).max() < 2e-5 * max(1.0, np.abs(H[b]).max()), rel

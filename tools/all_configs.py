@@ -20,13 +20,15 @@ from oracle import cases  # noqa: E402  (input recipes only)
 
 RetargetingConfig.set_default_urdf_dir(str(DEFAULT_URDF_DIR))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 else None  # substrings of config paths to run
+ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 and sys.argv[2] != "all" else None  # substrings of config paths to run
+KERNEL = sys.argv[3] if len(sys.argv) > 3 else "auto"  # force a kernel family (auto|register|quad|lds|reduced) where it applies
 dev = torch.device("cuda:0")
 kp = cases.human_keypoints(B + 1, seed=cases.SEED)
 t_kp = torch.from_numpy(np.ascontiguousarray(kp[1:])).to(dev)
 s = torch.cuda.current_stream()
 print(f"# {B} frames per launch, one MI355X; dq = max_j |q_f32 - q_f64| per frame over all frames")
-print(f"{'config':44s} {'n_opt':>5s} {'comps':>5s} {'ms':>8s} {'Mframes/s':>9s} {'it mean':>7s} {'it max':>6s} {'conv':>6s} {'p99.9 dq':>9s} {'>1e-4':>6s}")
+print(f"# kernel = {KERNEL}; kernel column: (family 0 register / 1 quad / 2 LDS / 3 reduced, joint bucket, chain)")
+print(f"{'config':44s} {'kernel':>14s} {'n_opt':>5s} {'comps':>5s} {'ms':>8s} {'Mframes/s':>9s} {'it mean':>7s} {'it max':>6s} {'conv':>6s} {'p99.9 dq':>9s} {'>1e-4':>6s}")
 for path in sorted(glob.glob(os.path.join(cases.CONFIG_DIR, "*", "*.yml"))):
     rel = os.path.relpath(path, cases.CONFIG_DIR)
     if ONLY is not None and not any(o in rel for o in ONLY):
@@ -34,6 +36,10 @@ for path in sorted(glob.glob(os.path.join(cases.CONFIG_DIR, "*", "*.yml"))):
     prob = cases.problem_from_config(rel)
     seq = RetargetingConfig.load_from_file(path).build()
     model = seq.optimizer.device_model()
+    if KERNEL != "auto":
+        from dex_retargeting_amd import _lib
+        model.tune(kernel={"register": _lib.KERNEL_REGISTER, "quad": _lib.KERNEL_QUAD, "lds": _lib.KERNEL_LDS,
+                           "reduced": _lib.KERNEL_REDUCED}[KERNEL])
     dex = prob.kind == "dexpilot"
     mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
     st = (lambda: np.zeros(B, np.uint32)) if dex else (lambda: None)
@@ -67,5 +73,5 @@ for path in sorted(glob.glob(os.path.join(cases.CONFIG_DIR, "*", "*.yml"))):
     it = t_it.cpu().numpy()
     dq = np.abs(t_q.cpu().numpy().astype(np.float64) - q64).max(1)
     ncomp = len(seq.optimizer.compiled_model().comps)
-    print(f"{rel:44s} {prob.n_opt:5d} {ncomp:5d} {ms:8.3f} {B / ms / 1e3:9.2f} {it.mean():7.2f} {it.max():6d} "
+    print(f"{rel:44s} {str(model.kernel()):>14s} {prob.n_opt:5d} {ncomp:5d} {ms:8.3f} {B / ms / 1e3:9.2f} {it.mean():7.2f} {it.max():6d} "
           f"{float((t_status == 0).float().mean()):6.4f} {np.percentile(dq, 99.9):9.1e} {int((dq > 1e-4).sum()):6d}", flush=True)
