@@ -957,9 +957,13 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
             const bool stalled = below_floor && blind >= kp.stall_from && smax > (real)kp.stall_ratio * sprev && smax < (real)kp.stall_cap * (real)kp.tol;
             blind = below_floor ? blind + 1 : 0;
             sprev = smax;
-            if (smax < (real)kp.tol || stalled || blind >= kp.max_blind) {
+            // a step below tol only means convergence when the damping is not what made it small (see dexr_big.hpp)
+            const real lam_ok = fmax((real)2 * delta, (real)10 * (real)kp.lam0);
+            if ((smax < (real)kp.tol && lam <= lam_ok) || stalled || blind >= kp.max_blind) {
               finished = true;
               status = ST_CONVERGED;
+            } else if (smax < (real)kp.tol) {
+              lam = fmax((real)0.1 * lam, (real)0.5 * lam_ok);
             }
           } else {
             lam = fmax(lam, (real)1e-6) * nu;
@@ -1155,9 +1159,13 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
         const bool stalled = below_floor && blind >= kp.stall_from && smax > (real)kp.stall_ratio * sprev && smax < (real)kp.stall_cap * (real)kp.tol;
         blind = below_floor ? blind + 1 : 0;
         sprev = smax;
-        if (smax < (real)kp.tol || stalled || blind >= kp.max_blind) {
+        // a step below tol only means convergence when the damping is not what made it small (see dexr_big.hpp)
+        const real lam_ok = fmax((real)2 * delta, (real)10 * (real)kp.lam0);
+        if ((smax < (real)kp.tol && lam <= lam_ok) || stalled || blind >= kp.max_blind) {
           done = true;
           status = ST_CONVERGED;
+        } else if (smax < (real)kp.tol) {
+          lam = fmax((real)0.1 * lam, (real)0.5 * lam_ok);
         }
       } else {
         lam = fmax(lam, (real)1e-6) * nu;

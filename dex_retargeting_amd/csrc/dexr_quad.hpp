@@ -553,9 +553,16 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
           const bool stalled = below_floor && blind >= kp.stall_from && smax > kp.stall_ratio * sprev && smax < kp.stall_cap * kp.tol;
           blind = below_floor ? blind + 1 : 0;
           sprev = smax;
-          if (smax < kp.tol || stalled || blind >= kp.max_blind) {
+          // A step below tol only means convergence when the damping is not what made it small: with lambda far above
+          // the weakest curvature the model can have (the regulariser's 2 delta) a step of 1e-8 says nothing about the
+          // distance to the minimiser (mimic DexPilot models: frames stopped 1e-4..8e-4 rad short after a rejected step
+          // had raised lambda).  Such a step shrinks lambda tenfold instead and the iteration goes on.
+          const float lam_ok = fmaxf(2.f * delta, 10.f * kp.lam0);
+          if ((smax < kp.tol && lam <= lam_ok) || stalled || blind >= kp.max_blind) {
             done = true;
             status = ST_CONVERGED;
+          } else if (smax < kp.tol) {
+            lam = fmaxf(0.1f * lam, 0.5f * lam_ok);
           }
         } else {
           lam = fmaxf(lam, 1e-6f) * nu;

@@ -450,9 +450,11 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
       float dj = H[hidx(j, j)];
 #pragma unroll
       for (int k = 0; k < j; ++k) dj -= H[hidx(j, k)] * H[hidx(j, k)];
-      if (!(dj > 1e-30f)) {
+      // modified Cholesky (see LaneSolver::chol_solve): a non-positive pivot -- indefinite Newton model, frequent with
+      // mimic families -- is reflected instead of failing the pass; `ok` then only says "unmodified Newton step"
+      if (!(dj > 1e-6f * (2.f * delta + lam))) {
         ok = false;
-        dj = 1.f;
+        dj = fmaxf(fabsf(dj), 2.f * delta + lam);
       }
       const float iv = __frsqrt_rn(dj);
       inv[j] = iv;
@@ -548,7 +550,7 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
         const double noise = (double)kp.floor_scale * fabs(F);
         const bool finite = (Fe == Fe) && (smax == smax) && (fabs(Fe) < 1e30);
         const bool below_floor = ok && finite && ((double)pred <= noise) && (smax < 1e-2f);
-        const bool accept = ok && finite && ((Fe <= F) || below_floor);
+        const bool accept = finite && ((Fe <= F) || below_floor);  // (a modified-Cholesky step is judged by the decrease)
         ++my_iters;
         pending = false;
         if (accept) {
@@ -562,9 +564,16 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
           const bool stalled = below_floor && blind >= kp.stall_from && smax > kp.stall_ratio * sprev && smax < kp.stall_cap * kp.tol;
           blind = below_floor ? blind + 1 : 0;
           sprev = smax;
-          if (smax < kp.tol || stalled || blind >= kp.max_blind) {
+          // A step below tol only means convergence when the damping is not what made it small: with lambda far above
+          // the weakest curvature the model can have (the regulariser's 2 delta) a step of 1e-8 says nothing about the
+          // distance to the minimiser (mimic DexPilot models: frames stopped 1e-4..8e-4 rad short after a rejected step
+          // had raised lambda).  Such a step shrinks lambda tenfold instead and the iteration goes on.
+          const float lam_ok = fmaxf(2.f * delta, 10.f * kp.lam0);
+          if ((smax < kp.tol && lam <= lam_ok) || stalled || blind >= kp.max_blind) {
             done = true;
             status = ST_CONVERGED;
+          } else if (smax < kp.tol) {
+            lam = fmaxf(0.1f * lam, 0.5f * lam_ok);
           }
         } else {
           lam = fmaxf(lam, 1e-6f) * nu;

@@ -49,10 +49,9 @@ typedef struct dexr_solve_options {
   int32_t polish;     /* float64 polishing iterations run after the float32 solve, started at its answer:
                          -1 auto (default: up to 24 for position / DexPilot models, whose float32 rounding floor sits
                          near 1e-4 rad; 0 for vector models), 0 off, n > 0 at most n iterations           */
-  int32_t strict;     /* float64 polish after the mixed-precision kernels (float64 kinematics, float32 gradient and
-                         Hessian) that serve large components.  0 (default): only for models with mimic joints, whose
-                         nearly flat valleys let a 1e-7 gradient error move the stationary point by up to 4e-4 rad
-                         (DESIGN.md section 2); 1: for every model; -1: never.                                      */
+  int32_t strict;     /* float64 polish after the mixed-precision kernels (float64 kinematics and value, float32
+                         gradient and Hessian) that serve large components.  0 (default): only after the quad / LDS
+                         kernels on models with mimic joints; 1: after every mixed-precision kernel; -1: never.      */
 } dexr_solve_options;
 
 /* Per-model launch / damping parameters.  These are the values the launcher derives from the model's shape and from

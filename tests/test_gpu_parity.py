@@ -547,9 +547,9 @@ def test_raw_keypoints_to_qpos_on_device_equals_host_pipeline():
 
 
 def test_strict_option_polishes_mixed_precision_answers():
-    """Mimic position models run on the LDS kernel (float64 kinematics, float32 gradient): in nearly flat valleys its
-    stationary point sits up to a few 1e-4 rad from the float64 one.  The float64 polish launch that removes this is
-    on by default for models with mimic joints (strict = 0), forced by strict = 1 and suppressed by strict = -1."""
+    """The mixed-precision kernels (float64 kinematics and value, float32 gradient / Hessian) that serve large components
+    return the float64 kernel's answer to well below the tolerance; `strict = 1` adds a float64 polish launch after
+    them for callers who want the float64 stationary point to 1e-5 regardless."""
     seq, prob = build("offline/ability_hand_right.yml")
     opt = seq.optimizer
     B = 8192
@@ -557,15 +557,16 @@ def test_strict_option_polishes_mixed_precision_answers():
     ref = np.ascontiguousarray(cases.ref_from_keypoints(prob, kp), dtype=np.float32)
     mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
     model = opt.device_model()
+    assert model.kernel()[0] == _lib.KERNEL_REDUCED
     last = model.retarget(ref[:-1], None, mid)
     q64 = model.retarget_f64(ref[1:], None, last)
     dq = {}
-    for strict in (-1, 0, 1):
+    for strict in (0, 1):
         q = model.retarget(ref[1:], None, last, opts=_lib.default_options(strict=strict))
         dq[strict] = np.abs(q.astype(np.float64) - q64).max(1)
-    assert (dq[1] > 1e-4).sum() <= (dq[-1] > 1e-4).sum()
-    assert np.array_equal(dq[0], dq[1])  # this model has mimic joints: polished by default
-    assert np.percentile(dq[0], 99.9) < 1e-5, np.percentile(dq[0], [99, 99.9, 100])
+    assert np.percentile(dq[0], 99.9) < 1e-4, np.percentile(dq[0], [99, 99.9, 100])
+    assert (dq[1] > 1e-4).sum() <= (dq[0] > 1e-4).sum()
+    assert np.percentile(dq[1], 99.9) < 1e-5, np.percentile(dq[1], [99, 99.9, 100])
 
 
 # ---- less common configuration paths ---------------------------------------------------------------------------------

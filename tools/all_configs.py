@@ -28,7 +28,7 @@ t_kp = torch.from_numpy(np.ascontiguousarray(kp[1:])).to(dev)
 s = torch.cuda.current_stream()
 print(f"# {B} frames per launch, one MI355X; dq = max_j |q_f32 - q_f64| per frame over all frames")
 print(f"# kernel = {KERNEL}; kernel column: (family 0 register / 1 quad / 2 LDS / 3 reduced, joint bucket, chain)")
-print(f"{'config':44s} {'kernel':>14s} {'n_opt':>5s} {'comps':>5s} {'ms':>8s} {'Mframes/s':>9s} {'it mean':>7s} {'it max':>6s} {'conv':>6s} {'p99.9 dq':>9s} {'>1e-4':>6s}")
+print(f"{'config':44s} {'kernel':>14s} {'n_opt':>5s} {'comps':>5s} {'ms':>8s} {'Mframes/s':>9s} {'it mean':>7s} {'it max':>6s} {'conv':>6s} {'p99.9 dq':>9s} {'>1e-4':>6s} {'it p99':>6s} {'tile max':>8s}")
 for path in sorted(glob.glob(os.path.join(cases.CONFIG_DIR, "*", "*.yml"))):
     rel = os.path.relpath(path, cases.CONFIG_DIR)
     if ONLY is not None and not any(o in rel for o in ONLY):
@@ -74,4 +74,5 @@ for path in sorted(glob.glob(os.path.join(cases.CONFIG_DIR, "*", "*.yml"))):
     dq = np.abs(t_q.cpu().numpy().astype(np.float64) - q64).max(1)
     ncomp = len(seq.optimizer.compiled_model().comps)
     print(f"{rel:44s} {str(model.kernel()):>14s} {prob.n_opt:5d} {ncomp:5d} {ms:8.3f} {B / ms / 1e3:9.2f} {it.mean():7.2f} {it.max():6d} "
-          f"{float((t_status == 0).float().mean()):6.4f} {np.percentile(dq, 99.9):9.1e} {int((dq > 1e-4).sum()):6d}", flush=True)
+          f"{float((t_status == 0).float().mean()):6.4f} {np.percentile(dq, 99.9):9.1e} {int((dq > 1e-4).sum()):6d} {np.percentile(it, 99):6.0f} "
+          f"{it[: B // 64 * 64].reshape(-1, 64).max(1).mean():8.2f}", flush=True)  # hist99
