@@ -644,6 +644,13 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
             done = true;
             status = finite ? ST_CONVERGED : ST_FALLBACK;
           }
+          // a step shorter than tol that does not decrease F: the decrease along the (damped) descent direction is below
+          // the resolution of F -- converged at the rounding floor (and no livelock between tiny accepted steps that
+          // shrink lambda and rounding-level rejections that raise it again)
+          if (finite && smax < kp.tol) {
+            done = true;
+            status = ST_CONVERGED;
+          }
           rebuild = true;  // the model in g/H belongs to the rejected point: rebuilt at xo in the next pass
         }
         if (!done && my_iters >= kp.max_iter) done = true;

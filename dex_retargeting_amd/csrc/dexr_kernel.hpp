@@ -983,6 +983,10 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
               finished = true;
               status = finite ? ST_CONVERGED : ST_FALLBACK;
             }
+            if (finite && smax < (real)kp.tol) {  // rejected step below tol: converged at the rounding floor of F
+              finished = true;
+              status = ST_CONVERGED;
+            }
           }
           if (!finished && my_iters >= kp.max_iter) finished = true;  // status stays ST_MAXITER
         }
@@ -1174,6 +1178,10 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
         if (lam > (real)1e10) {  // no descent direction resolvable any more
           done = true;
           status = finite ? ST_CONVERGED : ST_FALLBACK;
+        }
+        if (finite && smax < (real)kp.tol) {  // rejected step below tol: converged at the rounding floor of F
+          done = true;
+          status = ST_CONVERGED;
         }
         redo = !done;
       }

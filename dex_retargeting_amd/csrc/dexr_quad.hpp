@@ -576,6 +576,13 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
             done = true;
             status = finite ? ST_CONVERGED : ST_FALLBACK;
           }
+          // a step shorter than tol that does not decrease F: the decrease along the (damped) descent direction is below
+          // the resolution of F -- converged at the rounding floor (and no livelock between tiny accepted steps that
+          // shrink lambda and rounding-level rejections that raise it again)
+          if (finite && smax < kp.tol) {
+            done = true;
+            status = ST_CONVERGED;
+          }
           rebuild = true;
         }
         if (!done && my_iters >= kp.max_iter) done = true;

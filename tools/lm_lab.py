@@ -207,7 +207,9 @@ def kernel_lm(cm, *, lam0=1e-4, tol=2e-6, max_iter=64, step_cap=0.3, lam_jump=1.
             shrink = np.where(rho > 0.9, lam_fastdec, shrink)
         stalled = below & (blind >= stall_from) & (smax > stall_ratio * sprev) & (smax < stall_cap * tol)
         newblind = np.where(below, blind + 1, 0)
-        fin_acc = acc & ((smax < tol) | stalled | (newblind >= max_blind))
+        lam_ok = max(2 * delta, 10 * lam0)
+        fin_acc = acc & (((smax < tol) & (lam <= lam_ok)) | stalled | (newblind >= max_blind))
+        overdamped = acc & ~fin_acc & (smax < tol)  # tiny step because of the damping: shrink it, go on
         rej = live & ~accept & ~take_last
         lam_rej = np.maximum(lam, 1e-6) * nu
         if lam_jump > 0:
@@ -227,10 +229,11 @@ def kernel_lm(cm, *, lam0=1e-4, tol=2e-6, max_iter=64, step_cap=0.3, lam_jump=1.
         gs = np.where(upd[..., None], gt, gs)
         Hs = np.where(upd[..., None, None], Ht, Hs)
         lam = np.where(acc, np.maximum(lam * shrink, lam_floor), np.where(rej, lam_rej, lam))
+        lam = np.where(overdamped, np.maximum(0.1 * lam, 0.5 * lam_ok), lam)
         nu = np.where(acc, 2.0, np.where(rej, nu * 2, nu))
         blind = np.where(acc, newblind, blind)
         sprev = np.where(acc, smax, sprev)
-        done = done | take_last | fin_acc | (rej & (lam > 1e10)) | (live & (iters >= max_iter))
+        done = done | take_last | fin_acc | (rej & (lam > 1e10)) | (rej & finite & (smax < tol)) | (live & (iters >= max_iter))
     return x, iters
 
 
