@@ -1179,7 +1179,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
           done = true;
           status = finite ? ST_CONVERGED : ST_FALLBACK;
         }
-        if (finite && smax < (real)kp.tol) {  // rejected step below tol: converged at the rounding floor of F
+        if (ok && finite && smax < (real)kp.tol) {  // rejected (valid) step below tol: converged at the rounding floor of F
           done = true;
           status = ST_CONVERGED;
         }

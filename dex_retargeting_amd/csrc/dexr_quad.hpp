@@ -579,7 +579,7 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
           // a step shorter than tol that does not decrease F: the decrease along the (damped) descent direction is below
           // the resolution of F -- converged at the rounding floor (and no livelock between tiny accepted steps that
           // shrink lambda and rounding-level rejections that raise it again)
-          if (finite && smax < kp.tol) {
+          if (ok && finite && smax < kp.tol) {  // (ok: the step came from a valid factorisation)
             done = true;
             status = ST_CONVERGED;
           }

@@ -27,8 +27,8 @@
 
 namespace dexr {
 
-// blockDim.x = 64 (one wave per block); dynamic LDS = 64 * (4 * 6 * red_nj + 8 * 3 * lds_frames) bytes:
-// float32 axes + origins of red_nj joints, float64 positions of lds_frames frames, [row][lane].
+// blockDim.x = 64 (one wave per block); dynamic LDS = 64 * ((4 + 8) * 3 * red_nj + 8 * 3 * lds_frames) bytes:
+// float32 axes and float64 origins of red_nj joints, float64 positions of lds_frames frames, [row][lane].
 template <int NV>
 __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_kernel(const KernelParams kp, const dexr_comp_table* __restrict__ comps) {
   constexpr int NH = NV * (NV + 1) / 2;
@@ -41,9 +41,13 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
   bool active = false;
 
   const int NJL = kp.red_nj;  // joints per component the LDS rows were sized for
-  float* AXl = reinterpret_cast<float*>(lds_raw) + lane;                       // axis of joint k: AXl[(3k+i)*64]
-  float* OGl = AXl + (size_t)3 * NJL * 64;                                      // origin (relative to c0)
-  double* Pl = reinterpret_cast<double*>(lds_raw + (size_t)6 * NJL * 64 * 4) + lane;  // frame f at Pl[(3f+i)*64]
+  // Lever arms (frame position - joint origin) are formed in float64 and only then cast: with DexPilot's projection
+  // weights the forces on a frame reach ~10 while they cancel to ~0 in the gradient, so a lever arm rounded to float32
+  // at the 0.2 m scale of the hand (1e-8 m) leaves a gradient error of 2e-7 -- which a mimic hand's nearly flat valley
+  // (curvature ~5e-3) turns into 4e-5..2e-4 rad.  Origins therefore stay float64 in LDS, like the frame positions.
+  double* OGl = reinterpret_cast<double*>(lds_raw) + lane;                                // origin of joint k: OGl[(3k+i)*64]
+  double* Pl = OGl + (size_t)3 * NJL * 64;                                                // frame f at Pl[(3f+i)*64]
+  float* AXl = reinterpret_cast<float*>(lds_raw + (size_t)(3 * NJL + 3 * kp.lds_frames) * 64 * 8) + lane;  // axis of joint k
   constexpr auto hidx = [](int r, int c) constexpr { return r * (r + 1) / 2 + c; };
 
   const dexr_comp_table& tb = comps[comp];
@@ -188,9 +192,7 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
   };
 
   // ---- float64 forward kinematics, rolled over the joints -----------------------------------------------------------
-  double c0[3] = {0, 0, 0};  // origin of the first revolute joint: reference point of the float32 lever arms
   auto fk = [&]() {
-    bool c0_set = false;
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
     double sR[BIG_NSLOT][9], sp[BIG_NSLOT][3];
 #pragma unroll
@@ -248,15 +250,10 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
 #pragma unroll
         for (int i = 0; i < 3; ++i) p[i] += q * Rn[3 * i + 2];
       }
-      if (!c0_set && rev) {
-        c0_set = true;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) c0[i] = p[i];
-      }
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         AXl[(3 * k + i) * 64] = (float)R[3 * i + 2];
-        OGl[(3 * k + i) * 64] = (float)(p[i] - c0[i]);
+        OGl[(3 * k + i) * 64] = p[i];
       }
       const int sv = tb.save[k];
       if (sv >= 0) {
@@ -286,10 +283,11 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
   // ---- fused value / gradient / Hessian in the reduced variables at the FK state --------------------------------------
   auto assemble = [&]() -> double {
     double Fv = 0;
+    double gd_[NV];  // gradient of the data term, accumulated in float64 (see OGl)
 #pragma unroll
     for (int i = 0; i < NH; ++i) H[i] = 0.f;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) g[v] = 0.f;
+    for (int v = 0; v < NV; ++v) gd_[v] = 0.0;
 #pragma clang loop unroll(disable) vectorize(disable)
     for (int t = 0; t < nt; ++t) {
       const int ft = tb.term_task[t], fo = tb.term_origin[t];
@@ -302,13 +300,12 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
 #pragma unroll
         for (int i = 0; i < 3; ++i) pod[i] = Pl[(fo * 3 + i) * 64];
       }
-      float r[3], pt[3], po[3], fvec[3], hw[3], kap = 0.f;
+      float r[3], fvec[3], hw[3], kap = 0.f;
+      double fd[3];  // force dF/dr in float64 for the gradient
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         rd[i] = ptd[i] - pod[i] - (double)tv[i];
         r[i] = (float)rd[i];
-        pt[i] = (float)(ptd[i] - c0[i]);
-        po[i] = (float)(pod[i] - c0[i]);
       }
       const double w = (double)kp.inv_norm * (double)wt;
       if (per_coord) {  // SmoothL1 per coordinate (optimizer.py:130,166)
@@ -317,7 +314,8 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
           const double ee = rd[i], ae = fabs(ee);
           const bool quad = ae < beta;
           Fv += w * (quad ? 0.5 * ee * ee * ibeta : ae - 0.5 * beta);
-          fvec[i] = (float)(w * (quad ? ee * ibeta : (ee > 0 ? 1.0 : -1.0)));
+          fd[i] = w * (quad ? ee * ibeta : (ee > 0 ? 1.0 : -1.0));
+          fvec[i] = (float)fd[i];
           hw[i] = (float)(w * (quad ? ibeta : (newton ? 0.0 : 1.0 / ae)));  // exact curvature in Newton mode
         }
       } else {  // SmoothL1 of the vector norm (optimizer.py:272-273, 534-541)
@@ -329,7 +327,8 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
         const double psi = w * id;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          fvec[i] = (float)(psi * rd[i]);
+          fd[i] = psi * rd[i];
+          fvec[i] = (float)fd[i];
           hw[i] = (float)psi;
         }
         kap = quad ? 0.f : (float)(psi * id * id);
@@ -348,7 +347,7 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
         if (chain == 1 && fo < 0) break;
         const int fr = chain == 0 ? ft : fo;
         const float sg = chain == 0 ? 1.f : -1.f;
-        const float pf0 = chain == 0 ? pt[0] : po[0], pf1 = chain == 0 ? pt[1] : po[1], pf2 = chain == 0 ? pt[2] : po[2];
+        const double pf0 = chain == 0 ? ptd[0] : pod[0], pf1 = chain == 0 ? ptd[1] : pod[1], pf2 = chain == 0 ? ptd[2] : pod[2];
         uint32_t todo = tb.frame_anc[fr] & movmask;
         // running sums A[v] = sum over the chain joints j visited so far that move with variable v of vmul[j] * axis_j
         // (revolute joints only: a prismatic joint has no second derivative of its own)
@@ -365,7 +364,8 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
           const bool rev = (revmask >> k) & 1u;
           float c0_, c1_, c2_;
           if (rev) {
-            const float v0 = pf0 - OGl[(3 * k) * 64], v1 = pf1 - OGl[(3 * k + 1) * 64], v2 = pf2 - OGl[(3 * k + 2) * 64];
+            const float v0 = (float)(pf0 - OGl[(3 * k) * 64]), v1 = (float)(pf1 - OGl[(3 * k + 1) * 64]),
+                        v2 = (float)(pf2 - OGl[(3 * k + 2) * 64]);
             c0_ = sg * (a1 * v2 - a2 * v1);
             c1_ = sg * (a2 * v0 - a0 * v2);
             c2_ = sg * (a0 * v1 - a1 * v0);
@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         if ((vterm >> v) & 1u) {
-          g[v] += colv[v][0] * fvec[0] + colv[v][1] * fvec[1] + colv[v][2] * fvec[2];
+          gd_[v] += (double)colv[v][0] * fd[0] + (double)colv[v][1] * fd[1] + (double)colv[v][2] * fd[2];
           const float ku = kap * (colv[v][0] * r[0] + colv[v][1] * r[1] + colv[v][2] * r[2]);
           const float cw0 = hw[0] * colv[v][0] - ku * r[0], cw1 = hw[1] * colv[v][1] - ku * r[1],
                       cw2 = hw[2] * colv[v][2] - ku * r[2];
@@ -418,11 +418,14 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
       }
     }
 #pragma unroll
-    for (int v = 0; v < NV; ++v)
+    for (int v = 0; v < NV; ++v) {
+      g[v] = 0.f;
       if (v < nv) {
         const double dx = (double)x[v] - (double)xl(v);
         Fv += (double)delta * dx * dx;
+        g[v] = (float)(gd_[v] + 2.0 * (double)delta * dx);  // regulariser's gradient added here, in float64
       }
+    }
     return Fv;
   };
 
@@ -600,8 +603,7 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
     uint32_t freemask = 0;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      if ((varmask >> v) & 1u) {
-        g[v] += 2.f * delta * (x[v] - xl(v));
+      if ((varmask >> v) & 1u) {  // (g already holds data term + regulariser, see assemble)
         const bool act = (x[v] <= lo_v[v] && g[v] > 0) || (x[v] >= hi_v[v] && g[v] < 0);
         if (!act) freemask |= 1u << v;
       } else {

