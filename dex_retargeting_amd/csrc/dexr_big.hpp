@@ -242,16 +242,17 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
 #pragma unroll
           for (int j = 0; j < 3; ++j)
             Rn[3 * i + j] = R[3 * i] * (double)Xk[j] + R[3 * i + 1] * (double)Xk[3 + j] + R[3 * i + 2] * (double)Xk[6 + j];
-        float qf = x[k];
+        double q = (double)x[k];
         if (tb.src_kind[k] == DEXR_SRC_MIMIC) {  // kinematics_adaptor.py:102-105
           const int si = tb.src_idx[k];
           float v = 0;
 #pragma unroll
           for (int s = 0; s < NMAX; ++s) v += (s == si ? 1.f : 0.f) * x[s];
-          qf = tb.mult[k] * v + tb.off[k];
-          x[k] = qf;
+          // in float64: rounded to float32 the mimic joint's value would make F a step function of x at the 1e-9
+          // level, enough to reject every Newton step in the last 1e-4 rad of a flat valley
+          q = (double)tb.mult[k] * (double)v + (double)tb.off[k];
+          x[k] = (float)q;
         }
-        const double q = (double)qf;
         if ((revmask >> k) & 1u) {
           double s, c;
           sincos_f64(q, &s, &c);

@@ -228,11 +228,12 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
         for (int j = 0; j < 3; ++j)
           Rn[3 * i + j] = R[3 * i] * (double)Xk[j] + R[3 * i + 1] * (double)Xk[3 + j] + R[3 * i + 2] * (double)Xk[6 + j];
       // joint value: variable (own or mimicked, kinematics_adaptor.py:102-105) or caller-supplied fixed value
+      // (in float64: a mimic joint's value rounded to float32 would make F a step function of x at the 1e-9 level --
+      // enough to reject every Newton step in the last 1e-4 rad of a flat valley)
       const int var = tb.var[k];
-      float qf;
-      if (var >= 0) qf = tb.vmul[k] * pick_x(var) + tb.off[k];
-      else qf = tb.mult[k] * kp.fixed[irow * kp.n_fixed + tb.src_idx[k]] + tb.off[k];
-      const double q = (double)qf;
+      double q;
+      if (var >= 0) q = (double)tb.vmul[k] * (double)pick_x(var) + (double)tb.off[k];
+      else q = (double)tb.mult[k] * (double)kp.fixed[irow * kp.n_fixed + tb.src_idx[k]] + (double)tb.off[k];
       const bool rev = (revmask >> k) & 1u;
       if (rev) {
         double s, c;
