@@ -941,7 +941,10 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
           ++my_iters;
           F = Ft;
         } else {
-          const real noise = (real)16 * RT::eps() * fabs(F);
+          // resolution of F in this arithmetic: rounding of the sum (16 eps |F|) and, when F itself is small, of the frame
+          // positions behind it (1e-8 m x a force of ~0.1: ~2e-9 in float32 -- a Newton step whose predicted decrease is
+          // below that cannot be verified, only trusted)
+          const real noise = (real)16 * RT::eps() * fmax(fabs(F), (real)2e-3);
           // below the rounding floor of F the decrease test is meaningless: trust the (small) Newton step
           const bool below_floor = ok && finite && (pred <= noise) && (smax < (real)1e-2);
           accept = finite && ((Ft <= F) || below_floor);  // (a modified-Cholesky step is judged by the decrease alone)
@@ -1137,7 +1140,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
     for (int k = 0; k < NMAX; ++k)
       if ((optmask >> k) & 1u) Ft += delta * (S.x[k] - S.xl[k]) * (S.x[k] - S.xl[k]);
 
-    const real noise = (real)16 * RT::eps() * fabs(F);
+    const real noise = (real)16 * RT::eps() * fmax(fabs(F), (real)2e-3);  // see the small-component path
     const bool finite = (Ft == Ft) && (smax == smax) && (fabs(Ft) < (real)1e30);
     // below the rounding floor of F the decrease test is meaningless: trust the (small) Newton step
     const bool below_floor = ok && finite && (pred <= noise) && (smax < (real)1e-2);

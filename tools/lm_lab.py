@@ -103,7 +103,7 @@ class WholeModel:
 
 def kernel_lm(cm, *, lam0=1e-4, tol=2e-6, max_iter=64, step_cap=0.3, lam_jump=1.0, lam_fastdec=0.1, blind_tol_scale=10.0,
               max_blind=8, stall_from=2, stall_ratio=0.9, stall_cap=20.0, newton=True, eps=5.96e-8, gn_when=None,
-              cap_mode="inf", lam_floor=1e-9, trace=None, inner_retry=0, cap_grow=0.0, cap_max=1.2, gersh_at=99, retry_mult=None, pivot_rule=None, pivot_floor=1e-3, blind_contract=0.0):
+              cap_mode="inf", lam_floor=1e-9, trace=None, inner_retry=0, cap_grow=0.0, cap_max=1.2, gersh_at=99, retry_mult=None, pivot_rule=None, pivot_floor=1e-3, blind_contract=0.0, neg_boost=0.0):
     """Returns (x (B,T,m), iters (B,T)).  `eps`: rounding unit of the kernel's arithmetic (float32) for the
     below-the-floor logic.  gn_when: optional callable(F, lam, it) -> bool mask selecting Gauss-Newton models."""
     B, T, m = cm.B, cm.T, cm.m
@@ -182,6 +182,8 @@ def kernel_lm(cm, *, lam0=1e-4, tol=2e-6, max_iter=64, step_cap=0.3, lam_jump=1.
             cap = np.full((B, T), step_cap)
         capv = cap if cap_grow > 0 else step_cap
         alpha = np.where((step_cap > 0) & (dmax > capv), capv / np.maximum(dmax, 1e-300), 1.0)
+        if neg_boost > 0 and pivot_rule is not None:  # indefinite model (modified pivot): go to the trust radius
+            alpha = np.where(~ok & (step_cap > 0), np.minimum(capv / np.maximum(dmax, 1e-300), neg_boost), alpha)
         pred = alpha * (1 - 0.5 * alpha) * gd + 0.5 * alpha * alpha * lam * dd
         xt = np.where(vm, np.clip(x + alpha[..., None] * d, cm.lo[None], cm.hi[None]), x)
         smax = np.abs(xt - x).max(-1)

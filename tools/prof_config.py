@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""GPU: launch one config's solve kernel a few times on the bench workload (for rocprofv3 to wrap).
+
+    python tools/prof_config.py <config.yml> [kernel family: auto|register|quad|lds|reduced] [batch] [launches]
+"""
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch  # noqa: E402
+
+import bench_data  # noqa: E402
+from dex_retargeting_amd import _lib  # noqa: E402
+from dex_retargeting_amd.constants import DEFAULT_URDF_DIR  # noqa: E402
+from dex_retargeting_amd.retargeting_config import RetargetingConfig  # noqa: E402
+
+rel = sys.argv[1]
+kernel = sys.argv[2] if len(sys.argv) > 2 else "auto"
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
+n = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+RetargetingConfig.set_default_urdf_dir(str(DEFAULT_URDF_DIR))
+seq = RetargetingConfig.load_from_file(os.path.join(bench_data.CONFIG_DIR, rel)).build()
+model = seq.optimizer.device_model()
+if kernel != "auto":
+    model.tune(kernel={"register": _lib.KERNEL_REGISTER, "quad": _lib.KERNEL_QUAD, "lds": _lib.KERNEL_LDS,
+                       "reduced": _lib.KERNEL_REDUCED}[kernel])
+dex = seq.optimizer.retargeting_type == "DEXPILOT"
+kp = bench_data.human_keypoints(B + 1)
+mid = np.repeat(seq.joint_limits.mean(1)[None], B, 0).astype(np.float32)
+st = np.zeros(B, np.uint32) if dex else None
+last = model.retarget(np.ascontiguousarray(kp[:-1]), None, mid, state=st, keypoints=True)
+dev = torch.device("cuda:0")
+t_kp = torch.from_numpy(np.ascontiguousarray(kp[1:])).to(dev)
+t_last = torch.from_numpy(last).to(dev)
+t_q = torch.empty_like(t_last)
+t_st0 = torch.from_numpy(st.astype(np.int32)).to(dev) if dex else None
+t_st = t_st0.clone() if dex else None
+t_it = torch.zeros(B, dtype=torch.int32, device=dev)
+s = torch.cuda.current_stream()
+ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+for a, b in ev:
+    if dex:
+        t_st.copy_(t_st0)
+    a.record(s)
+    model.retarget_dev(B, t_kp.data_ptr(), 0, t_last.data_ptr(), t_st.data_ptr() if dex else 0, t_q.data_ptr(),
+                       iters_ptr=t_it.data_ptr(), stream=s.cuda_stream, keypoints=True)
+    b.record(s)
+torch.cuda.synchronize()
+it = t_it.cpu().numpy()
+print(f"{rel} kernel={model.kernel()} B={B}: ms {np.median([a.elapsed_time(b) for a, b in ev]):.3f}; iters mean {it.mean():.2f} "
+      f"p99 {np.percentile(it, 99):.0f} max {it.max()}; hist {np.bincount(it).tolist()}")
