@@ -146,13 +146,13 @@ int launch_big(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
 }
 
 int launch_red(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
-  const size_t lds = (size_t)64 * ((4 + 8) * 3 * (size_t)m->max_joints + 8 * 3 * (size_t)m->lds_frames);
+  const size_t lds = (size_t)64 * (4 * 6 * (size_t)m->max_joints + 8 * 3 * (size_t)m->lds_frames);
   kp.red_nj = m->max_joints;
   // persistent lanes as in launch_big: the resident set is what the LDS (160 KB per CU) and the kernel's registers
-  // (NV = 8: two waves per SIMD, NV = 16: one) allow; each wave starts with a static 64-frame tile
+  // (one wave per SIMD) allow; each wave starts with a static 64-frame tile
   const int64_t tiles = (kp.B + 63) / 64;
   int64_t per_cu = (int64_t)((160 * 1024) / (lds > 0 ? lds : 1));
-  const int64_t reg_cap = m->red_nv <= 8 ? 8 : 4;
+  const int64_t reg_cap = 4;  // both instantiations are built for one wave per SIMD
   per_cu = per_cu < 1 ? 1 : (per_cu > reg_cap ? reg_cap : per_cu);
   int64_t resident = (int64_t)m->n_cu * per_cu;
   if (m->tune.resident_waves > 0) resident = m->tune.resident_waves;
@@ -295,7 +295,7 @@ void select_kernels(dexr_model* m) {
   // 32) joints in LDS.  Serves the models with mimic joints whose components outgrow the small kernels (Ability /
   // Inspire DexPilot and position models, every Schunk SVH model): their joint-space Hessian is 2-3 x the size.
   m->red_nv = m->max_vars <= 8 ? 8 : (m->max_vars <= 16 ? 16 : 0);
-  const size_t red_lds = (size_t)64 * ((4 + 8) * 3 * (size_t)m->max_joints + 8 * 3 * (size_t)m->lds_frames);
+  const size_t red_lds = (size_t)64 * (4 * 6 * (size_t)m->max_joints + 8 * 3 * (size_t)m->lds_frames);
   const bool red_ok = m->red_nv > 0 && h.kind != DEXR_KIND_FKONLY && m->max_slot < 2 && red_lds <= 160 * 1024 && m->max_joints > 0;
   const bool red_wins = m->has_mimic && m->bucket >= 16;
   m->red = red_ok && (want == DEXR_KERNEL_REDUCED || (want == DEXR_KERNEL_AUTO && red_wins));

@@ -22,13 +22,13 @@
 #include "dexr_big.hpp"  // sincos_f64, BIG_NSLOT
 
 #ifndef DEXR_RED_MINW8
-#define DEXR_RED_MINW8 2  // waves per SIMD the NV = 8 instantiation must leave room for
+#define DEXR_RED_MINW8 1  // waves per SIMD the NV = 8 instantiation must leave room for (2: 120 B of scratch per lane)
 #endif
 
 namespace dexr {
 
-// blockDim.x = 64 (one wave per block); dynamic LDS = 64 * ((4 + 8) * 3 * red_nj + 8 * 3 * lds_frames) bytes:
-// float32 axes and float64 origins of red_nj joints, float64 positions of lds_frames frames, [row][lane].
+// blockDim.x = 64 (one wave per block); dynamic LDS = 64 * (4 * 6 * red_nj + 8 * 3 * lds_frames) bytes:
+// float32 axes + origins of red_nj joints, float64 positions of lds_frames frames, [row][lane].
 template <int NV>
 __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_kernel(const KernelParams kp, const dexr_comp_table* __restrict__ comps) {
   constexpr int NH = NV * (NV + 1) / 2;
@@ -41,13 +41,11 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
   bool active = false;
 
   const int NJL = kp.red_nj;  // joints per component the LDS rows were sized for
-  // Lever arms (frame position - joint origin) are formed in float64 and only then cast: with DexPilot's projection
-  // weights the forces on a frame reach ~10 while they cancel to ~0 in the gradient, so a lever arm rounded to float32
-  // at the 0.2 m scale of the hand (1e-8 m) leaves a gradient error of 2e-7 -- which a mimic hand's nearly flat valley
-  // (curvature ~5e-3) turns into 4e-5..2e-4 rad.  Origins therefore stay float64 in LDS, like the frame positions.
-  double* OGl = reinterpret_cast<double*>(lds_raw) + lane;                                // origin of joint k: OGl[(3k+i)*64]
-  double* Pl = OGl + (size_t)3 * NJL * 64;                                                // frame f at Pl[(3f+i)*64]
-  float* AXl = reinterpret_cast<float*>(lds_raw + (size_t)(3 * NJL + 3 * kp.lds_frames) * 64 * 8) + lane;  // axis of joint k
+  // Joint axes and origins in float32 (origins relative to c0, the float64 origin of the first revolute joint: the hand
+  // may sit 0.5 m from the world origin, its lever arms are centimetres); frame positions in float64.
+  float* AXl = reinterpret_cast<float*>(lds_raw) + lane;                                 // axis of joint k: AXl[(3k+i)*64]
+  float* OGl = AXl + (size_t)3 * NJL * 64;                                                // origin - c0
+  double* Pl = reinterpret_cast<double*>(lds_raw + (size_t)6 * NJL * 64 * 4) + lane;      // frame f at Pl[(3f+i)*64]
   constexpr auto hidx = [](int r, int c) constexpr { return r * (r + 1) / 2 + c; };
 
   const dexr_comp_table& tb = comps[comp];
@@ -192,7 +190,9 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
   };
 
   // ---- float64 forward kinematics, rolled over the joints -----------------------------------------------------------
+  double c0[3] = {0, 0, 0};  // origin of the first revolute joint: reference point of the float32 lever arms
   auto fk = [&]() {
+    bool c0_set = false;
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
     double sR[BIG_NSLOT][9], sp[BIG_NSLOT][3];
 #pragma unroll
@@ -251,10 +251,15 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
 #pragma unroll
         for (int i = 0; i < 3; ++i) p[i] += q * Rn[3 * i + 2];
       }
+      if (!c0_set && rev) {
+        c0_set = true;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) c0[i] = p[i];
+      }
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         AXl[(3 * k + i) * 64] = (float)R[3 * i + 2];
-        OGl[(3 * k + i) * 64] = p[i];
+        OGl[(3 * k + i) * 64] = (float)(p[i] - c0[i]);
       }
       const int sv = tb.save[k];
       if (sv >= 0) {
@@ -284,7 +289,7 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
   // ---- fused value / gradient / Hessian in the reduced variables at the FK state --------------------------------------
   auto assemble = [&]() -> double {
     double Fv = 0;
-    double gd_[NV];  // gradient of the data term, accumulated in float64 (see OGl)
+    double gd_[NV];  // gradient of the data term, accumulated in float64 (forces of ~10 cancel to ~0 with DexPilot's weights)
 #pragma unroll
     for (int i = 0; i < NH; ++i) H[i] = 0.f;
 #pragma unroll
@@ -348,7 +353,8 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
         if (chain == 1 && fo < 0) break;
         const int fr = chain == 0 ? ft : fo;
         const float sg = chain == 0 ? 1.f : -1.f;
-        const double pf0 = chain == 0 ? ptd[0] : pod[0], pf1 = chain == 0 ? ptd[1] : pod[1], pf2 = chain == 0 ? ptd[2] : pod[2];
+        const float pf0 = (float)((chain == 0 ? ptd[0] : pod[0]) - c0[0]), pf1 = (float)((chain == 0 ? ptd[1] : pod[1]) - c0[1]),
+                    pf2 = (float)((chain == 0 ? ptd[2] : pod[2]) - c0[2]);
         uint32_t todo = tb.frame_anc[fr] & movmask;
         // running sums A[v] = sum over the chain joints j visited so far that move with variable v of vmul[j] * axis_j
         // (revolute joints only: a prismatic joint has no second derivative of its own)
@@ -365,8 +371,7 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
           const bool rev = (revmask >> k) & 1u;
           float c0_, c1_, c2_;
           if (rev) {
-            const float v0 = (float)(pf0 - OGl[(3 * k) * 64]), v1 = (float)(pf1 - OGl[(3 * k + 1) * 64]),
-                        v2 = (float)(pf2 - OGl[(3 * k + 2) * 64]);
+            const float v0 = pf0 - OGl[(3 * k) * 64], v1 = pf1 - OGl[(3 * k + 1) * 64], v2 = pf2 - OGl[(3 * k + 2) * 64];
             c0_ = sg * (a1 * v2 - a2 * v1);
             c1_ = sg * (a2 * v0 - a0 * v2);
             c2_ = sg * (a0 * v1 - a1 * v0);
@@ -626,7 +631,11 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
         gd -= g[v] * d[v];
         dd += d[v] * d[v];
       }
-    const float alpha = (kp.step_cap > 0 && dmax > kp.step_cap) ? kp.step_cap / dmax : 1.f;
+    // trust radius: a step whose largest component exceeds step_cap is scaled down to it; a step from a MODIFIED
+    // factorisation (negative curvature along the way: the quadratic model has no minimiser in that direction) is scaled
+    // UP to it -- near a degenerate saddle the reflected-pivot step is ~g / (2 delta) with g -> 0 and would crawl for
+    // dozens of passes (one such frame in 65 536 set the duration of a whole launch)
+    const float alpha = (kp.step_cap > 0 && (dmax > kp.step_cap || (!okf && dmax > 0.f))) ? kp.step_cap / dmax : 1.f;
     if (stepping) pred = alpha * (1.f - 0.5f * alpha) * gd + 0.5f * alpha * alpha * lam * dd;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {

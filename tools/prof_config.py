@@ -50,5 +50,10 @@ for a, b in ev:
     b.record(s)
 torch.cuda.synchronize()
 it = t_it.cpu().numpy()
+slow = np.nonzero(it >= max(30, int(np.percentile(it, 99.99))))[0][:32]
+if len(slow) and len(sys.argv) > 5:  # dump the slowest frames for off-line analysis
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    np.savez(os.path.join(REPO, "gpurun_out", sys.argv[5]), idx=slow, kp=kp[1:][slow], last=last[slow], iters=it[slow],
+             state=(st[slow] if dex else np.zeros(len(slow), np.uint32)), q=t_q.cpu().numpy()[slow])
 print(f"{rel} kernel={model.kernel()} B={B}: ms {np.median([a.elapsed_time(b) for a, b in ev]):.3f}; iters mean {it.mean():.2f} "
       f"p99 {np.percentile(it, 99):.0f} max {it.max()}; hist {np.bincount(it).tolist()}")
