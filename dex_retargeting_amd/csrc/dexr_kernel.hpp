@@ -885,8 +885,8 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
             gd -= gm[k] * d[k];
             dd += d[k] * d[k];
           }
-        // (a step from a modified factorisation -- negative curvature -- goes all the way to the trust radius, see dexr_red.hpp)
-        const real alpha = (kp.step_cap > 0 && (dmax > (real)kp.step_cap || (!ok && dmax > (real)0))) ? (real)kp.step_cap / dmax : (real)1;
+        // (a step from a modified factorisation -- negative curvature -- is stretched (up to 8 x) towards the trust radius, see dexr_red.hpp)
+        const real alpha = (kp.step_cap > 0 && (dmax > (real)kp.step_cap || (!ok && dmax > (real)0))) ? fmin((real)kp.step_cap / dmax, (real)8) : (real)1;
         // predicted decrease of the damped model along alpha*d:  alpha (1 - alpha/2) (-g.d) + alpha^2/2 lam d.d
         pred = alpha * ((real)1 - (real)0.5 * alpha) * gd + (real)0.5 * alpha * alpha * lam * dd;
 #pragma unroll

@@ -633,9 +633,9 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
       }
     // trust radius: a step whose largest component exceeds step_cap is scaled down to it; a step from a MODIFIED
     // factorisation (negative curvature along the way: the quadratic model has no minimiser in that direction) is scaled
-    // UP to it -- near a degenerate saddle the reflected-pivot step is ~g / (2 delta) with g -> 0 and would crawl for
+    // UP towards it (at most 8 x: an unbounded stretch overshoots on the SVH hand's saddles) -- near a degenerate saddle the reflected-pivot step is ~g / (2 delta) with g -> 0 and would crawl for
     // dozens of passes (one such frame in 65 536 set the duration of a whole launch)
-    const float alpha = (kp.step_cap > 0 && (dmax > kp.step_cap || (!okf && dmax > 0.f))) ? kp.step_cap / dmax : 1.f;
+    const float alpha = (kp.step_cap > 0 && (dmax > kp.step_cap || (!okf && dmax > 0.f))) ? fminf(kp.step_cap / dmax, 8.f) : 1.f;
     if (stepping) pred = alpha * (1.f - 0.5f * alpha) * gd + 0.5f * alpha * alpha * lam * dd;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
