@@ -493,8 +493,7 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
         cj[i] = Hl[(act ? hidx(i, j) : pj) * 64];
       }
       float dj = Hl[pj * 64];
-      // modified Cholesky: a non-positive pivot is reflected instead of failing the pass (see dexr_quad.hpp)
-      if (!(dj > 1e-6f * (2.f * delta + lam))) { ok = false; dj = fmaxf(fabsf(dj), 2.f * delta + lam); }
+      if (!(dj > 1e-30f)) { ok = false; dj = 1.f; }
       const float iv = __frsqrt_rn(dj);
       const float sq = dj * iv;
 #pragma unroll
@@ -611,7 +610,7 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
         const double noise = (double)kp.floor_scale * fabs(F);
         const bool finite = (Fe == Fe) && (smax == smax) && (fabs(Fe) < 1e30);
         const bool below_floor = ok && finite && ((double)pred <= noise) && (smax < 1e-2f);
-        const bool accept = finite && ((Fe <= F) || below_floor);  // (a modified-Cholesky step is judged by the decrease)
+        const bool accept = ok && finite && ((Fe <= F) || below_floor);
         ++my_iters;
         pending = false;
         if (accept) {
@@ -649,7 +648,7 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
           // a step shorter than tol that does not decrease F: the decrease along the (damped) descent direction is below
           // the resolution of F -- converged at the rounding floor (and no livelock between tiny accepted steps that
           // shrink lambda and rounding-level rejections that raise it again)
-          if (finite && smax < kp.tol) {
+          if (ok && finite && smax < kp.tol) {  // (ok: the step came from a valid factorisation)
             done = true;
             status = ST_CONVERGED;
           }
@@ -686,8 +685,7 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
         dd += d[k] * d[k];
       }
     // trust radius: step scaled to at most step_cap per joint; predicted decrease of the damped model along alpha*d
-    // (a step from a modified factorisation -- negative curvature -- is stretched up to 8 x towards the trust radius, see dexr_red.hpp)
-    const float alpha = (kp.step_cap > 0 && (dmax > kp.step_cap || (!okf && dmax > 0.f))) ? fminf(kp.step_cap / dmax, 8.f) : 1.f;
+    const float alpha = (kp.step_cap > 0 && dmax > kp.step_cap) ? kp.step_cap / dmax : 1.f;
     if (stepping) pred = alpha * (1.f - 0.5f * alpha) * gd + 0.5f * alpha * alpha * lam * dd;
 #pragma unroll
     for (int k = 0; k < NMAX; ++k) {

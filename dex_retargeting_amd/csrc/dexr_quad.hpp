@@ -416,10 +416,7 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
         const float dl = Hq[2 * jo * (jo + 1) + j];
         dj = (j & 3) == 0 ? quad_bcast<0>(dl) : (j & 3) == 1 ? quad_bcast<1>(dl) : (j & 3) == 2 ? quad_bcast<2>(dl) : quad_bcast<3>(dl);
       }
-      // modified Cholesky (see LaneSolver::chol_solve): a non-positive pivot -- indefinite Newton model -- is reflected
-      // instead of failing the pass (a failed pass costs a second one here: the model is rebuilt at the old point);
-      // `ok` then only says "unmodified Newton step".  dj is the same in the four lanes of the quad.
-      if (!(dj > 1e-6f * (2.f * delta + lam))) { ok = false; dj = fmaxf(fabsf(dj), 2.f * delta + lam); }
+      if (!(dj > 1e-30f)) { ok = false; dj = 1.f; }
       const float iv = __frsqrt_rn(dj);
       ivs[j] = iv;
       // scale this lane's part of column j (rows r > j) and remember it
@@ -542,7 +539,7 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
         const double noise = (double)kp.floor_scale * fabs(F);
         const bool finite = (Fe == Fe) && (smax == smax) && (fabs(Fe) < 1e30);
         const bool below_floor = ok && finite && ((double)pred <= noise) && (smax < 1e-2f);
-        const bool accept = finite && ((Fe <= F) || below_floor);  // (a modified-Cholesky step is judged by the decrease)
+        const bool accept = ok && finite && ((Fe <= F) || below_floor);
         ++my_iters;
         pending = false;
         if (accept) {
@@ -582,7 +579,7 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
           // a step shorter than tol that does not decrease F: the decrease along the (damped) descent direction is below
           // the resolution of F -- converged at the rounding floor (and no livelock between tiny accepted steps that
           // shrink lambda and rounding-level rejections that raise it again)
-          if (finite && smax < kp.tol) {
+          if (ok && finite && smax < kp.tol) {  // (ok: the step came from a valid factorisation)
             done = true;
             status = ST_CONVERGED;
           }
@@ -618,8 +615,7 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
         dd += d[k] * d[k];
       }
     // trust radius: step scaled to at most step_cap per joint; predicted decrease of the damped model along alpha*d
-    // (a step from a modified factorisation -- negative curvature -- is stretched up to 8 x towards the trust radius, see dexr_red.hpp)
-    const float alpha = (kp.step_cap > 0 && (dmax > kp.step_cap || (!okf && dmax > 0.f))) ? fminf(kp.step_cap / dmax, 8.f) : 1.f;
+    const float alpha = (kp.step_cap > 0 && dmax > kp.step_cap) ? kp.step_cap / dmax : 1.f;
     if (stepping) {
       pred = alpha * (1.f - 0.5f * alpha) * gd + 0.5f * alpha * alpha * lam * dd;
       keff = gd / fmaxf(dd, 1e-30f);
