@@ -97,6 +97,12 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             continue
         if force or _stale(o, [quad_s, QUAD_HEADER, BIG_HEADER] + HEADERS):
             jobs.append((quad_s, o, NO_SLP + [f"-DDEXR_NMAX={n}"]))
+    wide_s = os.path.join(CSRC, "dexr_wide_inst.hip")
+    for n in (16, 24, 32):  # sixteen-lanes-per-frame kernel for dense components
+        o = os.path.join(BUILD, f"dexr_wide_{n}.o")
+        objs.append(o)
+        if force or _stale(o, [wide_s, os.path.join(CSRC, "dexr_wide.hpp"), BIG_HEADER] + HEADERS):
+            jobs.append((wide_s, o, NO_SLP + [f"-DDEXR_NMAX={n}"]))
     red_s = os.path.join(CSRC, "dexr_red_inst.hip")
     for nvb in (8, 16):  # reduced-variable kernel (mimic models): Hessian of the variables in registers
         o = os.path.join(BUILD, f"dexr_red_{nvb}.o")

@@ -32,7 +32,7 @@ class Tuning(C.Structure):
                 ("floor_scale", C.c_float), ("step_cap", C.c_float), ("blind_tol_scale", C.c_float)]
 
 
-KERNEL_AUTO, KERNEL_REGISTER, KERNEL_QUAD, KERNEL_LDS, KERNEL_REDUCED = -1, 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_REGISTER, KERNEL_QUAD, KERNEL_LDS, KERNEL_REDUCED, KERNEL_WIDE = -1, 0, 1, 2, 3, 4
 
 EXPORTS = ["dexr_last_error", "dexr_version", "dexr_device_count", "dexr_default_options", "dexr_model_create",
            "dexr_model_destroy", "dexr_model_info", "dexr_model_get_tuning", "dexr_model_set_tuning", "dexr_model_kernel",

@@ -55,6 +55,10 @@ struct dexr_model {
   bool chain = false;  // every component is a plain serial chain filling its bucket (CHAIN kernel applies)
   bool quad = false;   // dense 9..24-joint components solved four lanes per frame (dexr_quad_kernel)
   bool big = false;    // components of 9+ joints solved by dexr_big_kernel (Hessian in LDS, float64 kinematics)
+  bool wide = false;   // dense 9..32-joint components solved sixteen lanes per frame (dexr_wide_kernel)
+  bool wide_ok = false;  // the model fits that kernel (no mimic joints, <= 16 root-to-leaf chains of <= 16 joints)
+  std::vector<dexr::WideTable> wide_tabs;
+  dexr::WideTable* d_wide = nullptr;
   bool red = false;    // solved in reduced variables by dexr_red_kernel (Hessian of the variables in registers)
   int red_nv = 0;      // its variable bucket (8 or 16), 0 when the model does not fit
   int max_joints = 0, max_vars = 0;
@@ -198,11 +202,92 @@ int launch_quad(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
   return DEXR_OK;
 }
 
+// sixteen lanes per frame: four frames per wave, two waves per SIMD resident; persistent rows fed like the quads
+int launch_wide(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
+  const size_t per_wave = dexr::wide_lds_per_wave(m->bucket);
+  int wpb = 4;
+  while (wpb > 1 && per_wave * wpb > 64 * 1024) wpb >>= 1;
+  const int64_t tiles = (kp.B + 3) / 4;
+  int64_t resident = (int64_t)m->n_cu * 4 * 2;
+  if (m->tune.resident_waves > 0) resident = m->tune.resident_waves;
+  int64_t per_comp = (resident + kp.n_comp - 1) / kp.n_comp;
+  if (per_comp > tiles) per_comp = tiles;
+  const int64_t waves = per_comp * kp.n_comp;
+  const int64_t blocks = (waves + wpb - 1) / wpb;
+  if (blocks > 0x7fffffffLL) return fail(DEXR_ERR_INVALID, "batch too large for one launch");
+  kp.q0 = (uint32_t)(per_comp * 4);
+  const unsigned slot = m->qnext.fetch_add(1u) % dexr_model::QSLOTS;
+  kp.queue = m->d_queue + (size_t)slot * kp.n_comp;
+  hipError_t qe = hipMemsetAsync(kp.queue, 0, (size_t)kp.n_comp * sizeof(unsigned), st);
+  if (qe != hipSuccess) return fail(DEXR_ERR_HIP, "queue reset failed: %s", hipGetErrorString(qe));
+  dexr::wide_launch_fn fn = dexr::find_wide_launcher(m->bucket);
+  if (!fn) return fail(DEXR_ERR_UNSUPPORTED, "no sixteen-lane kernel for bucket %d", m->bucket);
+  hipError_t e = fn(kp, m->d_wide, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, st);
+  if (e != hipSuccess) return fail(DEXR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return DEXR_OK;
+}
+
+// Root-to-leaf chains of every component's kinematic tree (one per lane of a 16-lane row) and the revolute ancestors
+// of every joint, from the depth-first restore / save encoding of the tables (dexr_tables.h).
+bool build_wide_tables(dexr_model* m) {
+  m->wide_tabs.clear();
+  if (m->has_mimic || m->bucket < 16 || m->h.kind == DEXR_KIND_FKONLY) return false;
+  for (const dexr_comp_table& c : m->comps) {
+    dexr::WideTable w;
+    std::memset(&w, 0, sizeof(w));
+    std::memset(w.chain, 0xFF, sizeof(w.chain));
+    const int nj = c.n_joint;
+    if (c.n_term > 16 || c.n_frame > 16) return false;
+    int parent[DEXR_MAXJ], slot_owner[DEXR_NSLOT + 1];
+    bool has_child[DEXR_MAXJ];
+    for (int s = 0; s <= DEXR_NSLOT; ++s) slot_owner[s] = -1;
+    for (int k = 0; k < nj; ++k) {
+      has_child[k] = false;
+      if (c.src_kind[k] != DEXR_SRC_OPT && c.src_kind[k] != DEXR_SRC_FIXED) return false;
+      const int rs = c.restore[k];
+      if (rs == -2) parent[k] = -1;
+      else if (rs >= 0) { if (rs > DEXR_NSLOT) return false; parent[k] = slot_owner[rs]; }
+      else parent[k] = k - 1;
+      if (c.save[k] >= 0) { if (c.save[k] > DEXR_NSLOT) return false; slot_owner[c.save[k]] = k; }
+    }
+    for (int k = 0; k < nj; ++k)
+      if (parent[k] >= 0) has_child[parent[k]] = true;
+    bool published[DEXR_MAXJ];
+    for (int k = 0; k < nj; ++k) {
+      published[k] = false;
+      uint32_t anc = 0;
+      for (int j = k; j >= 0; j = parent[j])
+        if (c.jtype[j] == DEXR_JOINT_REVOLUTE) anc |= 1u << j;
+      w.anc_rev[k] = anc;
+    }
+    int n_chain = 0, depth = 0;
+    for (int k = 0; k < nj; ++k) {
+      if (has_child[k]) continue;
+      if (n_chain == 16) return false;
+      int path[DEXR_MAXJ], len = 0;
+      for (int j = k; j >= 0; j = parent[j]) path[len++] = j;
+      if (len > 16) return false;
+      for (int s = 0; s < len; ++s) {
+        const int j = path[len - 1 - s];
+        w.chain[n_chain][s] = (uint8_t)(j | (published[j] ? 0 : 0x80));
+        published[j] = true;
+      }
+      if (len > depth) depth = len;
+      ++n_chain;
+    }
+    w.n_chain = n_chain;
+    w.depth = depth;
+    m->wide_tabs.push_back(w);
+  }
+  return true;
+}
+
 int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStream_t st) {
   if (kp.B <= 0) return DEXR_OK;
   // fleet buckets / frame sequences / padded rows need the kernels with extended addressing (KernelParams)
   const bool ext = kp.perm != nullptr || kp.bucket != nullptr || kp.T > 0 || kp.ld != kp.n_opt;
   if (mode == dexr::MODE_SOLVE && !f64 && m->red) return launch_red(m, kp, st);
+  if (mode == dexr::MODE_SOLVE && !f64 && m->wide) return launch_wide(m, kp, st);
   if (mode == dexr::MODE_SOLVE && !f64 && m->quad) {
     return launch_quad(m, kp, st);
   }
@@ -299,8 +384,10 @@ void select_kernels(dexr_model* m) {
   const bool red_ok = m->red_nv > 0 && h.kind != DEXR_KIND_FKONLY && m->max_slot < 2 && red_lds <= 160 * 1024 && m->max_joints > 0;
   const bool red_wins = m->has_mimic && m->bucket >= 16;
   m->red = red_ok && (want == DEXR_KERNEL_REDUCED || (want == DEXR_KERNEL_AUTO && red_wins));
-  m->quad = !m->red && quad_ok && (want == DEXR_KERNEL_QUAD || (want == DEXR_KERNEL_AUTO && quad_wins));
-  m->big = !m->red && !m->quad && big_ok && (want == DEXR_KERNEL_LDS || (want == DEXR_KERNEL_AUTO && big_wins));
+  m->wide = m->wide_ok && want == DEXR_KERNEL_WIDE;
+  m->red = m->red && !m->wide;
+  m->quad = !m->wide && !m->red && quad_ok && (want == DEXR_KERNEL_QUAD || (want == DEXR_KERNEL_AUTO && quad_wins));
+  m->big = !m->wide && !m->red && !m->quad && big_ok && (want == DEXR_KERNEL_LDS || (want == DEXR_KERNEL_AUTO && big_wins));
   // the quad kernel scales its damping jump by the curvature along the failed step (not by mean diag H)
   // serial-chain specialisation (LocalTab keeps LF frames / LT terms in registers): every component must be an
   // unbranched chain of exactly `bucket` revolute optimised joints with at most LF frames and LT terms
@@ -338,7 +425,7 @@ bool polish_wanted(const dexr_model* m, const dexr_solve_options* opt) {
   if (polish == 0 || m->bucket == 32) return false;
   const int strict = opt ? opt->strict : 0;
   if (m->red && strict <= 0) return false;  // reduced-variable kernel: float64 kinematics and value, see dexr_red.hpp
-  if ((m->big || m->quad) && !(strict > 0 || (strict == 0 && m->has_mimic))) return false;
+  if ((m->big || m->quad || m->wide) && !(strict > 0 || (strict == 0 && m->has_mimic))) return false;
   return true;
 }
 
@@ -476,14 +563,19 @@ int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out) {
       m->has_mimic = m->has_mimic || c.src_kind[k] == DEXR_SRC_MIMIC;
     }
   default_tuning(m);
+  m->wide_ok = build_wide_tables(m);
   select_kernels(m);
-  if (m->quad) m->tune.lam_jump = 1.0f;  // the quad kernel scales the jump by the curvature along the failed step
+  if (m->quad || m->wide) m->tune.lam_jump = 1.0f;  // the quad kernel scales the jump by the curvature along the failed step
   if (m->bucket < 0) {
     delete m;
     return fail(DEXR_ERR_UNSUPPORTED, "component with %d joints exceeds the largest kernel bucket", maxj);
   }
   hipError_t e = hipMalloc((void**)&m->d_comps, m->comps.size() * sizeof(dexr_comp_table));
   if (e == hipSuccess) e = hipMemcpy(m->d_comps, m->comps.data(), m->comps.size() * sizeof(dexr_comp_table), hipMemcpyHostToDevice);
+  if (e == hipSuccess && m->wide_ok) {
+    e = hipMalloc((void**)&m->d_wide, m->wide_tabs.size() * sizeof(dexr::WideTable));
+    if (e == hipSuccess) e = hipMemcpy(m->d_wide, m->wide_tabs.data(), m->wide_tabs.size() * sizeof(dexr::WideTable), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess) e = hipMalloc((void**)&m->d_queue, (size_t)dexr_model::QSLOTS * h.n_comp * sizeof(unsigned));
   if (e == hipSuccess) {
     int dev = 0, cus = 0;
@@ -494,6 +586,7 @@ int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out) {
   if (e != hipSuccess) {
     if (m->d_queue) (void)hipFree(m->d_queue);
     if (m->d_comps) (void)hipFree(m->d_comps);
+    if (m->d_wide) (void)hipFree(m->d_wide);
     delete m;
     return fail(DEXR_ERR_HIP, "uploading tables failed: %s", hipGetErrorString(e));
   }
@@ -505,6 +598,7 @@ void dexr_model_destroy(dexr_model* m) {
   if (!m) return;
   if (m->d_comps) (void)hipFree(m->d_comps);
   if (m->d_queue) (void)hipFree(m->d_queue);
+  if (m->d_wide) (void)hipFree(m->d_wide);
   delete m;
 }
 
@@ -531,7 +625,7 @@ int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning) {
   dexr_tuning t = m->tune;  // fields beyond the caller's (older, shorter) struct keep their values
   std::memcpy(&t, tuning, tuning->struct_size);
   t.struct_size = (uint32_t)sizeof(dexr_tuning);
-  if (t.kernel < DEXR_KERNEL_AUTO || t.kernel > DEXR_KERNEL_REDUCED) return fail(DEXR_ERR_INVALID, "unknown kernel family %d", t.kernel);
+  if (t.kernel < DEXR_KERNEL_AUTO || t.kernel > DEXR_KERNEL_WIDE) return fail(DEXR_ERR_INVALID, "unknown kernel family %d", t.kernel);
   if (t.persist_from < 0 || t.qchunk < 0 || t.persist_occ < 0 || t.resident_waves < 0 || t.max_blind < 0)
     return fail(DEXR_ERR_INVALID, "negative launch parameter");
   if (!(t.step_cap >= 0) || !(t.lam_jump >= 0) || !(t.lam_fastdec >= 0) || !(t.floor_scale >= 0) || !(t.blind_tol_scale >= 0))
@@ -543,7 +637,7 @@ int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning) {
 
 int dexr_model_kernel(const dexr_model* m, int32_t* family, int32_t* bucket, int32_t* chain) {
   if (!m) return fail(DEXR_ERR_INVALID, "null argument");
-  if (family) *family = m->red ? DEXR_KERNEL_REDUCED : m->quad ? DEXR_KERNEL_QUAD : m->big ? DEXR_KERNEL_LDS : DEXR_KERNEL_REGISTER;
+  if (family) *family = m->wide ? DEXR_KERNEL_WIDE : m->red ? DEXR_KERNEL_REDUCED : m->quad ? DEXR_KERNEL_QUAD : m->big ? DEXR_KERNEL_LDS : DEXR_KERNEL_REGISTER;
   if (bucket) *bucket = m->bucket;
   if (chain) *chain = m->chain ? 1 : 0;
   return DEXR_OK;

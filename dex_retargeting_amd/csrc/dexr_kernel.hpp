@@ -85,6 +85,15 @@ struct KernelParams {
   float clip_eps;
 };
 
+// Per-component side table of the sixteen-lanes-per-frame kernel (dexr_wide.hpp), derived from the component's table by
+// the host when a model is created (dexr_api.hip: build_wide_tables): the kinematic tree cut into root-to-leaf chains,
+// one per lane of a 16-lane row, and the revolute ancestors of every joint.
+struct WideTable {
+  int32_t n_chain, depth;       // root-to-leaf chains (<= 16) and the longest one (<= 16 joints)
+  uint8_t chain[16][16];        // [lane][step]: local joint | 0x80 when this lane publishes it; 0xFF = none
+  uint32_t anc_rev[DEXR_MAXJ];  // bit c set <=> joint c is a REVOLUTE ancestor-or-self of joint r
+};
+
 enum { MODE_SOLVE = 0, MODE_EVAL = 1, MODE_FK = 2 };
 enum { ST_CONVERGED = 0, ST_MAXITER = 1, ST_FALLBACK = 2 };  // == DEXR_STATUS_* in dexr.h
 

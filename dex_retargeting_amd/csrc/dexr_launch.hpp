@@ -48,6 +48,21 @@ static inline launch_fn find_quad_launcher(int bucket) {
   return bucket == 16 ? launch_quad_16 : bucket == 24 ? launch_quad_24 : nullptr;
 }
 
+// sixteen-lanes-per-frame kernel for dense 9..32-joint components without mimic joints (dexr_wide.hpp)
+typedef hipError_t (*wide_launch_fn)(const KernelParams& kp, const WideTable* wt, dim3 grid, dim3 block, size_t lds, hipStream_t st);
+hipError_t launch_wide_16(const KernelParams&, const WideTable*, dim3, dim3, size_t, hipStream_t);
+hipError_t launch_wide_24(const KernelParams&, const WideTable*, dim3, dim3, size_t, hipStream_t);
+hipError_t launch_wide_32(const KernelParams&, const WideTable*, dim3, dim3, size_t, hipStream_t);
+size_t wide_lds_per_wave_16();
+size_t wide_lds_per_wave_24();
+size_t wide_lds_per_wave_32();
+static inline wide_launch_fn find_wide_launcher(int bucket) {
+  return bucket == 16 ? launch_wide_16 : bucket == 24 ? launch_wide_24 : bucket == 32 ? launch_wide_32 : nullptr;
+}
+static inline size_t wide_lds_per_wave(int bucket) {
+  return bucket == 16 ? wide_lds_per_wave_16() : bucket == 24 ? wide_lds_per_wave_24() : bucket == 32 ? wide_lds_per_wave_32() : 0;
+}
+
 // reduced-variable kernel (dexr_red.hpp): Hessian of the n_var <= NV optimised variables in registers, kinematics in LDS
 hipError_t launch_red_8(const KernelParams&, dim3, dim3, size_t, hipStream_t);
 hipError_t launch_red_16(const KernelParams&, dim3, dim3, size_t, hipStream_t);

@@ -1,0 +1,852 @@
+// dexr_wide.hpp -- solve kernel for LARGE DENSE components (9..32 joints, no mimic joints): SIXTEEN LANES PER FRAME.
+//
+// Why: a launch of the four-lanes-per-frame kernel (dexr_quad.hpp) over 65 536 Shadow-DexPilot frames is bound by its
+// SLOWEST frame, not by its throughput -- a frame that needs 44 iterations is a serial chain of ~56 wave passes of
+// ~37 000 instructions each (0.12 ms per pass, 6.5 ms per launch, while the mean frame needs 5 iterations; see
+// DESIGN.md "tail").  A pass therefore has to become short.  Here a frame is spread over a 16-lane DPP row, a wave
+// holds four frames, and every stage of a pass is parallel over the 16 lanes:
+//   * forward kinematics (float64): lane l walks root-to-leaf chain l of the kinematic tree (one finger each; the
+//     shared wrist / free-base prefix is recomputed by every lane), 5-13 joints deep instead of all 24-30 in sequence;
+//   * residuals, Huber weights, DexPilot targets: lane t evaluates term t (<= 16 terms per component);
+//   * Jacobian: lane l forms the columns of joints l and l + 16 for the term in flight, accumulates their gradient
+//     entries and second-order vectors, and publishes the four rows (three coordinates + the Huber rank-one row) of
+//     the term's Jacobian in LDS;
+//   * Hessian: 2-D cyclic over a 4 x 4 lane grid -- lane (a, b) owns H[r][c], r = a (mod 4), c = b (mod 4), 21 floats
+//     at n = 24 -- accumulated as weighted outer products of the published rows; the second-order (Newton) term is
+//     a_c . CF_r for every revolute ancestor c of r, added once per pass from per-joint sums CF_r;
+//   * Cholesky on that grid: the pivot travels by ds_bpermute, the pivot column by one DPP quad broadcast (row side)
+//     and one ds_bpermute (column side) per local row; triangular solves with quad / stride-4 DPP reductions.
+// The accepted point's Hessian and gradient stay in registers, so a REJECTED step costs no extra pass (the quad kernel
+// re-assembles): every pass evaluates a new trial point.
+// ~128 VGPRs, 15 KB of LDS per wave: two waves per SIMD.  Damping / termination rules are those of dexr_quad.hpp.
+#pragma once
+
+#include "dexr_big.hpp"  // sincos_f64
+
+namespace dexr {
+
+template <int CTRL>
+static __device__ __forceinline__ float wdpp(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+static __device__ __forceinline__ double wdpp64(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// all-reduce over a 16-lane row; every stage adds partners symmetrically, so the 16 lanes end with identical bits
+static __device__ __forceinline__ float row_sum(float v) {
+  v += wdpp<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += wdpp<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += wdpp<0x141>(v);  // row_half_mirror: quad 0 <-> 1, 2 <-> 3
+  v += wdpp<0x140>(v);  // row_mirror: half 0 <-> 1
+  return v;
+}
+static __device__ __forceinline__ float row_max(float v) {
+  v = fmaxf(v, wdpp<0xB1>(v));
+  v = fmaxf(v, wdpp<0x4E>(v));
+  v = fmaxf(v, wdpp<0x141>(v));
+  v = fmaxf(v, wdpp<0x140>(v));
+  return v;
+}
+static __device__ __forceinline__ double row_sum64(double v) {
+  v += wdpp64<0xB1>(v);
+  v += wdpp64<0x4E>(v);
+  v += wdpp64<0x141>(v);
+  v += wdpp64<0x140>(v);
+  return v;
+}
+static __device__ __forceinline__ float wquad_sum(float v) {
+  v += wdpp<0xB1>(v);
+  v += wdpp<0x4E>(v);
+  return v;
+}
+// sum over the four lanes {b, b+4, b+8, b+12} of a row (same column class)
+static __device__ __forceinline__ float stride4_sum(float v) {
+  v += wdpp<0x128>(v);  // row_ror:8
+  v += wdpp<0x124>(v);  // row_ror:4
+  return v;
+}
+template <int Q>
+static __device__ __forceinline__ float wquad_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), Q * 0x55, 0xF, 0xF, true));
+}
+
+#ifndef DEXR_WIDE_MINW
+#define DEXR_WIDE_MINW 2
+#endif
+
+// blockDim.x = 256 (4 waves x 4 frames); dynamic LDS per wave = wide_lds_bytes(NMAX)
+template <int NMAX>
+struct WideLds {
+  static constexpr int NR = NMAX / 4;
+  static constexpr int NRP = 8;                        // class chunk of a Jacobian row, padded for 16-byte reads
+  static constexpr int XT = 0;                         // NMAX x 16 floats: X[12], fbeg, fend, pad, pad
+  static constexpr int FO = XT + NMAX * 64;            // 16 frames x 4 floats
+  static constexpr int CH = FO + 256;                  // 16 x 16 chain bytes
+  static constexpr int SLOT0 = CH + 256;
+  // per frame slot
+  static constexpr int P = 0;                          // 16 frames x 3 doubles
+  static constexpr int AX = P + 384;                   // NMAX x 4 floats
+  static constexpr int OG = AX + NMAX * 16;            // NMAX x 4 floats
+  static constexpr int XV = OG + NMAX * 16;            // NMAX floats: joint values of the trial point
+  static constexpr int GV = XV + NMAX * 4;             // NMAX floats: gradient
+  static constexpr int CF = GV + NMAX * 4;             // NMAX x 4 floats: second-order vectors
+  static constexpr int TB = CF + NMAX * 16;            // 16 terms x 16 floats
+  static constexpr int JR = TB + 1024;                 // 4 rows x 4 classes x NRP floats
+  static constexpr int SLOT = JR + 4 * 4 * NRP * 4;
+  static constexpr int WAVE = SLOT0 + 4 * SLOT;
+};
+
+template <int NMAX>
+__global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const KernelParams kp, const dexr_comp_table* __restrict__ comps,
+                                                                         const WideTable* __restrict__ wtabs) {
+  static_assert(NMAX == 16 || NMAX == 24 || NMAX == 32, "bucket");
+  using L = WideLds<NMAX>;
+  constexpr int NR = NMAX / 4;
+  constexpr int NRP = L::NRP;
+  constexpr int NJ2 = NMAX > 16 ? 2 : 1;  // joints owned per lane (l and l + 16)
+
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  const int lane = threadIdx.x & 63;
+  const int l = lane & 15;        // lane within the frame's row
+  const int slot = lane >> 4;     // frame slot of the wave
+  const int a = l >> 2, b = l & 3;  // row / column class of the Hessian grid
+  const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int waves_per_block = blockDim.x >> 6;
+  const int64_t wave_global = (int64_t)blockIdx.x * waves_per_block + wave_in_block;
+  const int comp = (int)(wave_global % kp.n_comp);
+  const int64_t tile = wave_global / kp.n_comp;
+  const int rowbase4 = (lane & 48) << 2;  // ds_bpermute byte address of lane 0 of this row
+
+  unsigned char* wbase = lds_raw + (size_t)wave_in_block * L::WAVE;
+  float* XT = reinterpret_cast<float*>(wbase + L::XT);
+  float* FO = reinterpret_cast<float*>(wbase + L::FO);
+  unsigned char* CH = wbase + L::CH;
+  unsigned char* sbase = wbase + L::SLOT0 + (size_t)slot * L::SLOT;
+  double* Pl = reinterpret_cast<double*>(sbase + L::P);
+  float* AXl = reinterpret_cast<float*>(sbase + L::AX);
+  float* OGl = reinterpret_cast<float*>(sbase + L::OG);
+  float* XVl = reinterpret_cast<float*>(sbase + L::XV);
+  float* GVl = reinterpret_cast<float*>(sbase + L::GV);
+  float* CFl = reinterpret_cast<float*>(sbase + L::CF);
+  float* TBl = reinterpret_cast<float*>(sbase + L::TB);
+  float* JRl = reinterpret_cast<float*>(sbase + L::JR);
+
+  const dexr_comp_table& tb = comps[comp];
+  const WideTable& wt = wtabs[comp];
+  const int nj = tb.n_joint, nt = tb.n_term;
+  const int depth = wt.depth;
+  const float delta = kp.norm_delta;
+  const int64_t nB = kp.bucket ? (int64_t)kp.bucket[1] : kp.B;
+  const int64_t pbase = kp.bucket ? (int64_t)kp.bucket[0] : 0;
+  auto row_of = [&](int64_t it) -> int64_t { return kp.perm ? (int64_t)kp.perm[pbase + it] : it; };
+  const int ld = kp.ld;
+  const bool seq = kp.T > 0;
+
+  // ---- wave-constant tables into LDS (lane-varying joint indices read them in the kinematics) ----------------------
+  for (int k = lane; k < NMAX; k += 64) {
+    const bool in = k < nj;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) XT[k * 16 + i] = in ? tb.X[k][i] : 0.f;
+    XT[k * 16 + 12] = __int_as_float(in ? tb.fbeg[k] : 0);
+    XT[k * 16 + 13] = __int_as_float(in ? tb.fend[k] : 0);
+    XT[k * 16 + 14] = 0.f;
+    XT[k * 16 + 15] = 0.f;
+  }
+  for (int f = lane; f < 16; f += 64) {
+    const bool in = f < tb.n_frame;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) FO[f * 4 + i] = in ? tb.frame_off[f][i] : 0.f;
+    FO[f * 4 + 3] = 0.f;
+  }
+  for (int i = lane; i < 256; i += 64) CH[i] = wt.chain[i >> 4][i & 15];
+
+  uint32_t optmask = 0, revmask = 0;
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k) {
+    if (k < nj && tb.src_kind[k] == DEXR_SRC_OPT) optmask |= 1u << k;
+    if (k < nj && tb.jtype[k] == DEXR_JOINT_REVOLUTE) revmask |= 1u << k;
+  }
+
+  // ---- per-lane constants: the joints this lane owns (l, l + 16) and the ancestor masks of its Hessian rows ---------
+  int jo_[NJ2];
+  bool jin[NJ2], jopt[NJ2], jrev[NJ2], jfix[NJ2];
+  float jlo[NJ2], jhi[NJ2], jmul[NJ2], joff[NJ2];
+  int japi[NJ2], jsrc[NJ2];
+#pragma unroll
+  for (int s = 0; s < NJ2; ++s) {
+    const int k = l + 16 * s;
+    jo_[s] = k;
+    jin[s] = k < nj;
+    const int kk = jin[s] ? k : 0;
+    jopt[s] = jin[s] && tb.src_kind[kk] == DEXR_SRC_OPT;
+    jfix[s] = jin[s] && tb.src_kind[kk] == DEXR_SRC_FIXED;
+    jrev[s] = jin[s] && tb.jtype[kk] == DEXR_JOINT_REVOLUTE;
+    jlo[s] = tb.lo[kk];
+    jhi[s] = tb.hi[kk];
+    jmul[s] = tb.mult[kk];
+    joff[s] = tb.off[kk];
+    japi[s] = jopt[s] ? tb.api[kk] : 0;
+    jsrc[s] = jfix[s] ? tb.src_idx[kk] : 0;
+  }
+  uint32_t ancr[NR];  // revolute ancestors-or-self of row 4 i + a
+#pragma unroll
+  for (int i = 0; i < NR; ++i) ancr[i] = (4 * i + a < nj) ? wt.anc_rev[4 * i + a] : 0u;
+
+  const bool per_coord = kp.kind == DEXR_KIND_POSITION;
+  const double beta = (double)kp.huber_delta, ibeta = 1.0 / beta;
+  const bool newton = kp.newton != 0;
+  const bool dexpilot = kp.kind == DEXR_KIND_DEXPILOT;
+  const int F_ = kp.num_fingers, n_pair = F_ * (F_ - 1) / 2, len_s1 = F_ - 1;
+
+  // ---- per-frame state (replicated in the 16 lanes of the row unless noted) ------------------------------------------
+  int64_t item = 0, lrow = 0, irow = 0;
+  int t_seq = 0;
+  const float* lastp = kp.last;
+  bool active = false;
+  uint32_t nst = 0;
+  float xj[NJ2], xacc[NJ2], xlast[NJ2];  // own joints: trial value, accepted value, regularisation target
+  float gacc[NJ2];                       // own joints: gradient at the accepted point (incl. regulariser)
+  float Ha[NR][NR];                      // Hessian grid entries (4 i + a, 4 j + b), j <= i, at the accepted point
+#pragma unroll
+  for (int s = 0; s < NJ2; ++s) { xj[s] = 0; xacc[s] = 0; xlast[s] = 0; gacc[s] = 0; }
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j) Ha[i][j] = 0;
+
+  auto ref_row = [&](int row, float (&rv)[3]) {
+    if (kp.kpts) {
+      const float* pa = kp.kpts + (irow * kp.n_kp + kp.h_task[row]) * 3;
+      const int o = kp.h_origin[row];
+      if (o >= 0) {
+        const float* pb = kp.kpts + (irow * kp.n_kp + o) * 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rv[i] = pa[i] - pb[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rv[i] = pa[i];
+      }
+    } else {
+      const float* r = kp.ref + (irow * kp.n_ref + row) * 3;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) rv[i] = r[i];
+    }
+  };
+  auto xl = [&](int s) -> float {  // regularisation target of own joint s (see dexr_quad.hpp)
+    float v;
+    if (seq && t_seq > 0)
+      v = __hip_atomic_load(const_cast<float*>(lastp) + japi[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+      v = lastp[japi[s]];
+    return seq ? fminf(fmaxf(v, jlo[s] + kp.clip_eps), jhi[s] - kp.clip_eps) : v;
+  };
+  auto load_frame = [&](int64_t it, int t) {
+    item = it;
+    t_seq = t;
+    lrow = row_of(it);
+    irow = seq ? (int64_t)t * kp.seq_stride + lrow : lrow;
+    lastp = (seq && t > 0) ? kp.qout + (irow - kp.seq_stride) * ld : kp.last + lrow * ld;
+#pragma unroll
+    for (int s = 0; s < NJ2; ++s) {
+      xj[s] = 0;
+      xlast[s] = 0;
+      if (jopt[s]) {
+        xlast[s] = xl(s);
+        const float v = (kp.x0 && !(seq && t_seq > 0)) ? kp.x0[lrow * ld + japi[s]] : xlast[s];
+        xj[s] = fminf(fmaxf(v, jlo[s]), jhi[s]);
+      } else if (jfix[s]) {
+        xj[s] = jmul[s] * kp.fixed[irow * kp.n_fixed + jsrc[s]] + joff[s];
+      }
+      xacc[s] = xj[s];
+    }
+    if (dexpilot) {  // projection bits (optimizer.py:466-476)
+      const uint32_t st = (seq && t_seq > 0) ? nst : (kp.state ? kp.state[lrow] : 0u);
+      nst = 0;
+      for (int i = 0; i < len_s1; ++i) {
+        float rv[3];
+        ref_row(i, rv);
+        const float dist = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+        bool bb = (st >> i) & 1u;
+        if (dist < kp.project_dist) bb = true;
+        if (dist > kp.escape_dist) bb = false;
+        nst |= (bb ? 1u : 0u) << i;
+      }
+      int idx = len_s1;
+      for (int aa = 0; aa < F_ - 2; ++aa)
+        for (int b2 = aa + 1; b2 < F_ - 1; ++b2) {
+          float rv[3];
+          ref_row(idx, rv);
+          const float dist = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+          const bool bb = ((nst >> b2) & 1u) && ((nst >> aa) & 1u) && (dist <= 0.03f);
+          nst |= (bb ? 1u : 0u) << idx;
+          ++idx;
+        }
+    }
+  };
+  // target vector and weight of one term (optimizer.py:246, 479-507)
+  auto term_target = [&](int row, float (&tv)[3], float& wgt) {
+    float rv[3];
+    ref_row(row, rv);
+    wgt = 1.f;
+    if (dexpilot) {
+      if (row < n_pair) {
+        if ((nst >> row) & 1u) {
+          const float dist = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+          const float eta = row < len_s1 ? kp.eta1 : kp.eta2;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) tv[i] = (rv[i] / (dist + 1e-6f)) * eta;
+          wgt = row < len_s1 ? 200.f : 400.f;
+          return;
+        }
+      } else {
+        wgt = (float)(n_pair + F_);
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) tv[i] = rv[i] * kp.scaling;
+    } else {
+      const float sc = (kp.kind == DEXR_KIND_VECTOR) ? kp.scaling : 1.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) tv[i] = rv[i] * sc;
+    }
+  };
+
+  // frames on the fixed base never move
+  if (l < tb.n_base_frame) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Pl[l * 3 + i] = (double)tb.frame_off[l][i];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- float64 forward kinematics, one root-to-leaf chain per lane --------------------------------------------------
+  auto fk = [&]() {
+#pragma unroll
+    for (int s = 0; s < NJ2; ++s)
+      if (jin[s]) XVl[jo_[s]] = xj[s];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pp[3] = {0, 0, 0};
+#pragma clang loop unroll(disable) vectorize(disable)
+    for (int s = 0; s < depth; ++s) {
+      const unsigned cb = CH[l * 16 + s];
+      if (cb != 0xFFu) {
+        const int k = (int)(cb & 0x7Fu);
+        const float4 x0 = *reinterpret_cast<const float4*>(XT + k * 16);
+        const float4 x1 = *reinterpret_cast<const float4*>(XT + k * 16 + 4);
+        const float4 x2 = *reinterpret_cast<const float4*>(XT + k * 16 + 8);
+        const float4 x3 = *reinterpret_cast<const float4*>(XT + k * 16 + 12);
+        const double Xk[12] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pp[i] += R[3 * i] * Xk[9] + R[3 * i + 1] * Xk[10] + R[3 * i + 2] * Xk[11];
+        double Rn[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) Rn[3 * i + j] = R[3 * i] * Xk[j] + R[3 * i + 1] * Xk[3 + j] + R[3 * i + 2] * Xk[6 + j];
+        const double q = (double)XVl[k];
+        if ((revmask >> k) & 1u) {
+          double sn, cs;
+          sincos_f64(q, &sn, &cs);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const double c0 = Rn[3 * i], c1 = Rn[3 * i + 1];
+            R[3 * i] = cs * c0 + sn * c1;
+            R[3 * i + 1] = cs * c1 - sn * c0;
+            R[3 * i + 2] = Rn[3 * i + 2];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) pp[i] += q * Rn[3 * i + 2];
+        }
+        if (cb & 0x80u) {  // this lane publishes the joint
+          *reinterpret_cast<float4*>(AXl + k * 4) = make_float4((float)R[2], (float)R[5], (float)R[8], 0.f);
+          *reinterpret_cast<float4*>(OGl + k * 4) = make_float4((float)pp[0], (float)pp[1], (float)pp[2], 0.f);
+          const int fb = __float_as_int(x3.x), fe = __float_as_int(x3.y);
+          for (int f = fb; f < fe; ++f) {
+            const float4 fo = *reinterpret_cast<const float4*>(FO + f * 4);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+              Pl[f * 3 + i] = pp[i] + R[3 * i] * (double)fo.x + R[3 * i + 1] * (double)fo.y + R[3 * i + 2] * (double)fo.z;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  // ---- value / gradient (own joints) / Hessian grid at the kinematic state in LDS ------------------------------------
+  float gnew[NJ2];
+  float Hn[NR][NR];
+  auto assemble = [&]() -> double {
+    // (1) lane t evaluates term t
+    double Fv = 0;
+    if (l < nt) {
+      const int ft = tb.term_task[l], fo = tb.term_origin[l];
+      double rd[3];
+      float tv[3], wgt;
+      term_target(tb.term_ref[l], tv, wgt);
+      float ptf[3], pof[3] = {0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double pt = Pl[ft * 3 + i];
+        const double po = fo >= 0 ? Pl[fo * 3 + i] : 0.0;
+        rd[i] = pt - po - (double)tv[i];
+        ptf[i] = (float)pt;
+        pof[i] = (float)po;
+      }
+      const double w = (double)kp.inv_norm * (double)wgt;
+      float fvec[3], hw[3], kap = 0;
+      if (per_coord) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const double ee = rd[i], ae = fabs(ee);
+          const bool quad = ae < beta;
+          Fv += w * (quad ? 0.5 * ee * ee * ibeta : ae - 0.5 * beta);
+          fvec[i] = (float)(w * (quad ? ee * ibeta : (ee > 0 ? 1.0 : -1.0)));
+          hw[i] = (float)(w * (quad ? ibeta : (newton ? 0.0 : 1.0 / ae)));
+        }
+      } else {
+        const double d2 = rd[0] * rd[0] + rd[1] * rd[1] + rd[2] * rd[2];
+        const double dd = sqrt(d2);
+        const bool quad = dd < beta;
+        Fv += w * (quad ? 0.5 * d2 * ibeta : dd - 0.5 * beta);
+        const double id = quad ? ibeta : 1.0 / dd;
+        const double psi = w * id;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          fvec[i] = (float)(psi * rd[i]);
+          hw[i] = (float)psi;
+        }
+        kap = quad ? 0.f : (float)(psi * id * id);
+      }
+      float* T = TBl + l * 16;
+      *reinterpret_cast<float4*>(T) = make_float4((float)rd[0], (float)rd[1], (float)rd[2], kap);
+      *reinterpret_cast<float4*>(T + 4) = make_float4(fvec[0], fvec[1], fvec[2], hw[0]);
+      *reinterpret_cast<float4*>(T + 8) = make_float4(ptf[0], ptf[1], ptf[2], hw[1]);
+      *reinterpret_cast<float4*>(T + 12) = make_float4(pof[0], pof[1], pof[2], hw[2]);
+    }
+    // regulariser of the own joints
+#pragma unroll
+    for (int s = 0; s < NJ2; ++s)
+      if (jopt[s]) {
+        const double dx = (double)xj[s] - (double)xlast[s];
+        Fv += (double)delta * dx * dx;
+      }
+    Fv = row_sum64(Fv);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // (2) own joints' axes / origins
+    float jax[NJ2][3], jog[NJ2][3], jcf[NJ2][3];
+#pragma unroll
+    for (int s = 0; s < NJ2; ++s) {
+      const float4 av = *reinterpret_cast<const float4*>(AXl + (jin[s] ? jo_[s] : 0) * 4);
+      const float4 ov = *reinterpret_cast<const float4*>(OGl + (jin[s] ? jo_[s] : 0) * 4);
+      jax[s][0] = av.x; jax[s][1] = av.y; jax[s][2] = av.z;
+      jog[s][0] = ov.x; jog[s][1] = ov.y; jog[s][2] = ov.z;
+      jcf[s][0] = 0; jcf[s][1] = 0; jcf[s][2] = 0;
+      gnew[s] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j) Hn[i][j] = 0;
+
+    // (3) terms in sequence: Jacobian rows through LDS, outer products into the grid
+#pragma clang loop unroll(disable) vectorize(disable)
+    for (int t = 0; t < nt; ++t) {
+      const float* T = TBl + t * 16;
+      const float4 t0 = *reinterpret_cast<const float4*>(T);
+      const float4 t1 = *reinterpret_cast<const float4*>(T + 4);
+      const float4 t2 = *reinterpret_cast<const float4*>(T + 8);
+      const float4 t3 = *reinterpret_cast<const float4*>(T + 12);
+      const int ft = tb.term_task[t], fo = tb.term_origin[t];
+      const uint32_t mt = tb.frame_anc[ft];
+      const uint32_t mo = (fo >= 0) ? tb.frame_anc[fo] : 0u;
+#pragma unroll
+      for (int s = 0; s < NJ2; ++s) {
+        const int k = jo_[s];
+        const bool in_t = (mt >> k) & 1u, in_o = (mo >> k) & 1u;
+        float c0 = 0, c1 = 0, c2 = 0;
+        if (jopt[s] && (in_t || in_o)) {
+          if (jrev[s]) {
+            float v0 = 0, v1 = 0, v2 = 0;
+            if (in_t) { v0 += t2.x - jog[s][0]; v1 += t2.y - jog[s][1]; v2 += t2.z - jog[s][2]; }
+            if (in_o) { v0 -= t3.x - jog[s][0]; v1 -= t3.y - jog[s][1]; v2 -= t3.z - jog[s][2]; }
+            c0 = jax[s][1] * v2 - jax[s][2] * v1;
+            c1 = jax[s][2] * v0 - jax[s][0] * v2;
+            c2 = jax[s][0] * v1 - jax[s][1] * v0;
+          } else {
+            const float sg = (in_t ? 1.f : 0.f) - (in_o ? 1.f : 0.f);
+            c0 = sg * jax[s][0]; c1 = sg * jax[s][1]; c2 = sg * jax[s][2];
+          }
+          gnew[s] += c0 * t1.x + c1 * t1.y + c2 * t1.z;
+          jcf[s][0] += c1 * t1.z - c2 * t1.y;
+          jcf[s][1] += c2 * t1.x - c0 * t1.z;
+          jcf[s][2] += c0 * t1.y - c1 * t1.x;
+        }
+        const float u = c0 * t0.x + c1 * t0.y + c2 * t0.z;
+        // row k of the term's Jacobian^T: position (k mod 4) * NRP + k / 4 of each of the four rows
+        const int pos = (k & 3) * NRP + (k >> 2);
+        JRl[0 * 4 * NRP + pos] = c0;
+        JRl[1 * 4 * NRP + pos] = c1;
+        JRl[2 * 4 * NRP + pos] = c2;
+        JRl[3 * 4 * NRP + pos] = u;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const float wk[4] = {t1.w, t2.w, t3.w, -t0.w};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        float jr[NRP], jc[NRP];
+#pragma unroll
+        for (int i = 0; i < NRP; i += 4) {
+          if (i < NR) {
+            const float4 rv = *reinterpret_cast<const float4*>(JRl + kk * 4 * NRP + a * NRP + i);
+            const float4 cv = *reinterpret_cast<const float4*>(JRl + kk * 4 * NRP + b * NRP + i);
+            jr[i] = rv.x * wk[kk]; jr[i + 1] = rv.y * wk[kk]; jr[i + 2] = rv.z * wk[kk]; jr[i + 3] = rv.w * wk[kk];
+            jc[i] = cv.x; jc[i + 1] = cv.y; jc[i + 2] = cv.z; jc[i + 3] = cv.w;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j) Hn[i][j] += jr[i] * jc[j];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    // (4) second-order kinematic term: H[r][c] += a_c . CF_r for every revolute ancestor-or-self c of r
+    if (newton) {
+#pragma unroll
+      for (int s = 0; s < NJ2; ++s)
+        if (jin[s]) *reinterpret_cast<float4*>(CFl + jo_[s] * 4) = make_float4(jcf[s][0], jcf[s][1], jcf[s][2], 0.f);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float4 axc[NR];
+#pragma unroll
+      for (int j = 0; j < NR; ++j) axc[j] = *reinterpret_cast<const float4*>(AXl + (4 * j + b) * 4);
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const float4 cf = *reinterpret_cast<const float4*>(CFl + (4 * i + a) * 4);
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+          const float v = axc[j].x * cf.x + axc[j].y * cf.y + axc[j].z * cf.z;
+          Hn[i][j] += ((ancr[i] >> (4 * j + b)) & 1u) ? v : 0.f;
+        }
+      }
+    }
+    return Fv;
+  };
+
+  // ---- distributed Cholesky + triangular solves of (H_acc restricted to the free set + damping) d = -g -------------
+  float dstep[NJ2];  // own joints' entries of the step
+  auto factor_and_solve = [&](uint32_t freemask, float lam) -> bool {
+    bool ok = true;
+    float Hw[NR][NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int r = 4 * i + a;
+      const bool fr = (freemask >> r) & 1u;
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        const int c = 4 * j + b;
+        const bool fc = (freemask >> c) & 1u;
+        float v = (fr && fc) ? Ha[i][j] : 0.f;
+        if (i == j && a == b) v = fr ? v + 2.f * delta + lam : 1.f;
+        Hw[i][j] = v;
+      }
+    }
+    float ivs[NMAX];
+#pragma unroll
+    for (int jc = 0; jc < NMAX; ++jc) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int ja = jc & 3, jo = jc >> 2;
+      float dj = __int_as_float(__builtin_amdgcn_ds_bpermute(rowbase4 + 20 * ja, __float_as_int(Hw[jo][jo])));  // lane (ja, ja)
+      if (!(dj > 1e-30f)) { ok = false; dj = 1.f; }
+      const float iv = __frsqrt_rn(dj);
+      ivs[jc] = iv;
+      // scale column jc (lanes of column class ja), rows below the pivot
+#pragma unroll
+      for (int i = jo; i < NR; ++i) {
+        const bool below = (i > jo) || (a > ja);
+        const float v = Hw[i][jo] * iv;
+        Hw[i][jo] = (b == ja && below) ? v : Hw[i][jo];
+      }
+      // pivot column to the grid: row side from lane (a, ja) (own quad), column side from lane (b, ja)
+      float Lr[NR], Lc[NR];
+#pragma unroll
+      for (int i = jo; i < NR; ++i) {
+        const float own = Hw[i][jo];
+        float vr = ja == 0 ? wquad_bcast<0>(own) : ja == 1 ? wquad_bcast<1>(own) : ja == 2 ? wquad_bcast<2>(own) : wquad_bcast<3>(own);
+        float vc = __int_as_float(__builtin_amdgcn_ds_bpermute(rowbase4 + 16 * b + 4 * ja, __float_as_int(own)));
+        if (i == jo) {
+          vr = (a > ja) ? vr : 0.f;
+          vc = (b > ja) ? vc : 0.f;
+        }
+        Lr[i] = vr;
+        Lc[i] = vc;
+      }
+#pragma unroll
+      for (int i = jo; i < NR; ++i)
+#pragma unroll
+        for (int j = jo; j <= i; ++j) {
+          const bool col_jc = (j == jo) && (b == ja);  // the scaled pivot column itself stays
+          Hw[i][j] -= col_jc ? 0.f : Lr[i] * Lc[j];
+        }
+    }
+    // forward: L y = rhs; yb[j] = y[4 j + b]
+    float yb[NR], da[NR], ga[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      yb[i] = 0;
+      da[i] = 0;
+      const int r = 4 * i + a;
+      ga[i] = ((freemask >> r) & 1u) ? -GVl[r] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < NMAX; ++r) {
+      const int ra = r & 3, ro = r >> 2;
+      float part = 0;
+#pragma unroll
+      for (int j = 0; j <= ro; ++j) part += Hw[ro][j] * yb[j];  // entries at or right of the diagonal meet yb = 0
+      const float sum = wquad_sum(part);
+      const float yr_local = (ga[ro] - sum) * ivs[r];  // valid on quad ra
+      const float yr = __int_as_float(__builtin_amdgcn_ds_bpermute(rowbase4 + 16 * ra, __float_as_int(yr_local)));
+      yb[ro] = (b == ra) ? yr : yb[ro];
+    }
+    // backward: L^T d = y; da[i] = d[4 i + a]
+#pragma unroll
+    for (int s = 0; s < NJ2; ++s) dstep[s] = 0;
+#pragma unroll
+    for (int r = NMAX - 1; r >= 0; --r) {
+      const int rb = r & 3, ro = r >> 2;
+      float part = 0;
+#pragma unroll
+      for (int i = ro; i < NR; ++i) part += Hw[i][ro] * da[i];  // rows at or above r meet da = 0
+      const float sum = stride4_sum(part);                      // valid on lanes of column class rb
+      const float dr_local = (yb[ro] - sum) * ivs[r];
+      const float dr = __int_as_float(__builtin_amdgcn_ds_bpermute(rowbase4 + 4 * rb, __float_as_int(dr_local)));
+      da[ro] = (a == rb) ? dr : da[ro];
+#pragma unroll
+      for (int s = 0; s < NJ2; ++s) dstep[s] = (jo_[s] == r) ? dr : dstep[s];
+    }
+    return ok;
+  };
+
+  // ---- projected Levenberg-Marquardt / Newton ------------------------------------------------------------------------
+  float lam = kp.lam0, nu = 2.f, sprev = 1e30f, keff = 0.f;
+  bool done = true, pending = false;
+  int status = ST_MAXITER, my_iters = 0, blind = 0;
+  double F = 0;
+  float smax = 0, pred = 0;
+  bool ok = true;
+  unsigned pool_next = (unsigned)((tile * 4 < (int64_t)kp.q0 && tile * 4 < nB) ? tile * 4 : 0);
+  unsigned pool_end = (unsigned)((tile * 4 < (int64_t)kp.q0 && tile * 4 < nB) ? ((tile * 4 + 4 < nB) ? tile * 4 + 4 : nB) : 0);
+  bool dry = false;
+  unsigned* queue = kp.queue + comp;
+  auto reset_state = [&]() {
+    done = false;
+    pending = false;
+    lam = kp.lam0;
+    nu = 2.f;
+    sprev = 1e30f;
+    keff = 0.f;
+    status = ST_MAXITER;
+    my_iters = 0;
+    blind = 0;
+    F = 0;
+    smax = 0;
+    pred = 0;
+    ok = true;
+  };
+  for (;;) {
+    // (0) hand frames to idle rows
+    const unsigned long long want = __ballot(!active);
+    if (want != 0ull) {
+      if (pool_next >= pool_end && !dry) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(queue, 4u);
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + kp.q0;
+        if ((int64_t)base >= nB) {
+          dry = true;
+        } else {
+          pool_next = base;
+          pool_end = (unsigned)(((int64_t)base + 4 < nB) ? base + 4 : nB);
+        }
+      }
+      if (pool_next < pool_end) {
+        const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
+        const unsigned cand = pool_next + ((below - (unsigned)l) >> 4);
+        const bool got = !active && cand < pool_end;
+        pool_next += (unsigned)__popcll(__ballot(got)) >> 4;
+        if (got) {
+          load_frame((int64_t)cand, 0);
+          active = true;
+          reset_state();
+        }
+      }
+    }
+    if (!__any(active)) {
+      if (dry && pool_next >= pool_end) break;
+      continue;
+    }
+    fk();
+    const double Fe = assemble();
+    if (!done) {
+      bool take = false;
+      if (!pending) {
+        F = Fe;
+        take = true;
+      } else {
+        const double noise = (double)kp.floor_scale * fabs(F);
+        const bool finite = (Fe == Fe) && (smax == smax) && (fabs(Fe) < 1e30);
+        const bool below_floor = ok && finite && ((double)pred <= noise) && (smax < 1e-2f);
+        const bool accept = ok && finite && ((Fe <= F) || below_floor);
+        ++my_iters;
+        pending = false;
+        if (accept) {
+          const float rho = (float)((F - Fe) / fmax((double)pred, 1e-30));
+          const float tt = 2.f * rho - 1.f;
+          float shrink = below_floor ? (1.f / 3.f) : fmaxf(1.f / 3.f, 1.f - tt * tt * tt);
+          if (kp.lam_fastdec > 0 && rho > 0.9f) shrink = kp.lam_fastdec;
+          lam = fmaxf(lam * shrink, 1e-9f);
+          nu = 2.f;
+          F = Fe;
+          take = true;
+          const bool stalled = below_floor && blind >= kp.stall_from && smax > kp.stall_ratio * sprev && smax < kp.stall_cap * kp.tol;
+          blind = below_floor ? blind + 1 : 0;
+          sprev = smax;
+          const float lam_ok = fmaxf(2.f * delta, 10.f * kp.lam0);  // see dexr_quad.hpp
+          if ((smax < kp.tol && lam <= lam_ok) || stalled || blind >= kp.max_blind) {
+            done = true;
+            status = ST_CONVERGED;
+          } else if (smax < kp.tol) {
+            lam = fmaxf(0.1f * lam, 0.5f * lam_ok);
+          }
+        } else {
+          lam = fmaxf(lam, 1e-6f) * nu;
+          if (kp.lam_jump > 0) lam = fmaxf(lam, kp.lam_jump * keff);
+          nu *= 2.f;
+#pragma unroll
+          for (int s = 0; s < NJ2; ++s) xj[s] = xacc[s];
+          if (lam > 1e10f) {
+            done = true;
+            status = finite ? ST_CONVERGED : ST_FALLBACK;
+          }
+          if (ok && finite && smax < kp.tol) {
+            done = true;
+            status = ST_CONVERGED;
+          }
+        }
+        if (!done && my_iters >= kp.max_iter) done = true;
+      }
+      if (take) {  // the evaluated point becomes the accepted point: keep its gradient and Hessian
+#pragma unroll
+        for (int s = 0; s < NJ2; ++s) {
+          xacc[s] = xj[s];
+          gacc[s] = jopt[s] ? gnew[s] + 2.f * delta * (xj[s] - xlast[s]) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j) Ha[i][j] = Hn[i][j];
+      }
+    }
+    // active set of the accepted point, gathered from the 16 lanes of the row
+    uint32_t freemask = 0;
+    {
+      bool fr[NJ2];
+#pragma unroll
+      for (int s = 0; s < NJ2; ++s) {
+        const bool act = (xacc[s] <= jlo[s] && gacc[s] > 0) || (xacc[s] >= jhi[s] && gacc[s] < 0);
+        fr[s] = jopt[s] && !act;
+        if (jin[s]) GVl[jo_[s]] = gacc[s];
+      }
+      const unsigned long long b0 = __ballot(fr[0]);
+      freemask = (uint32_t)((b0 >> (16 * slot)) & 0xFFFFull);
+      if (NJ2 > 1) {
+        const unsigned long long b1 = __ballot(fr[NJ2 - 1]);
+        freemask |= (uint32_t)((b1 >> (16 * slot)) & 0xFFFFull) << 16;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool okf = factor_and_solve(freemask, lam);
+    const bool stepping = !done;
+    if (stepping) {
+      ok = okf;
+      float dmaxl = 0.f, gdl = 0.f, ddl = 0.f;
+#pragma unroll
+      for (int s = 0; s < NJ2; ++s)
+        if (jin[s] && ((freemask >> jo_[s]) & 1u)) {
+          dmaxl = fmaxf(dmaxl, fabsf(dstep[s]));
+          gdl -= gacc[s] * dstep[s];
+          ddl += dstep[s] * dstep[s];
+        }
+      const float dmax = row_max(dmaxl), gd = row_sum(gdl), dd = row_sum(ddl);
+      const float alpha = (kp.step_cap > 0 && dmax > kp.step_cap) ? kp.step_cap / dmax : 1.f;
+      pred = alpha * (1.f - 0.5f * alpha) * gd + 0.5f * alpha * alpha * lam * dd;
+      keff = gd / fmaxf(dd, 1e-30f);
+      float sl = 0.f;
+#pragma unroll
+      for (int s = 0; s < NJ2; ++s)
+        if (jin[s] && ((freemask >> jo_[s]) & 1u)) {
+          const float xt = fminf(fmaxf(xacc[s] + alpha * dstep[s], jlo[s]), jhi[s]);
+          sl = fmaxf(sl, fabsf(xt - xacc[s]));
+          xj[s] = xt;
+        }
+      smax = row_max(sl);
+      pending = true;
+      if (okf && smax < kp.blind_tol && lam <= kp.lam0) {  // see dexr_quad.hpp: verified undamped model, tiny Newton step
+        ++my_iters;
+        pending = false;
+        done = true;
+        status = ST_CONVERGED;
+#pragma unroll
+        for (int s = 0; s < NJ2; ++s) xacc[s] = xj[s];
+      }
+    }
+
+    // (last) retire finished frames
+    if (active && done) {
+      bool badl = false;
+#pragma unroll
+      for (int s = 0; s < NJ2; ++s)
+        if (jopt[s]) badl = badl || !(xacc[s] == xacc[s]);
+      const bool bad = row_max(badl ? 1.f : 0.f) > 0.f;
+      if (bad) status = ST_FALLBACK;
+#pragma unroll
+      for (int s = 0; s < NJ2; ++s)
+        if (jopt[s]) {
+          const float v = bad ? xlast[s] : xacc[s];
+          kp.qout[irow * ld + japi[s]] = v;
+          if (kp.qout64) kp.qout64[irow * ld + japi[s]] = (double)v;
+        }
+      if (l == 0) {
+        if (kp.status) atomicMax(&kp.status[irow], status);
+        if (kp.iters) atomicMax(&kp.iters[irow], my_iters);
+        if (kp.fval) atomicAdd(&kp.fval[irow], (float)F);
+      }
+      if (seq && t_seq + 1 < kp.T) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the next frame's start point is the row just written
+        load_frame(item, t_seq + 1);
+        reset_state();
+      } else {
+        if (l == 0 && dexpilot && kp.state && comp == 0) kp.state[lrow] = nst;
+        active = false;
+        done = true;
+      }
+    }
+  }
+}
+
+}  // namespace dexr

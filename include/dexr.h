@@ -65,6 +65,8 @@ typedef struct dexr_solve_options {
 #define DEXR_KERNEL_LDS 2      /* one lane per frame, Hessian in LDS (dexr_big.hpp)                                   */
 #define DEXR_KERNEL_REDUCED 3  /* one lane per frame, Hessian of the optimised VARIABLES (mimic joints folded while the
                                   Jacobian is formed) in registers, kinematics in LDS (dexr_red.hpp)                   */
+#define DEXR_KERNEL_WIDE 4     /* sixteen lanes per frame: chain-parallel kinematics, 4 x 4 lane grid for the Hessian and
+                                  its Cholesky factor, no re-assembly after a rejected step (dexr_wide.hpp)             */
 typedef struct dexr_tuning {
   uint32_t struct_size; /* sizeof(dexr_tuning) of the caller's header: lets the struct grow compatibly          */
   int32_t kernel;       /* DEXR_KERNEL_*: float32 solve kernel family (AUTO: measured policy, dexr_api.hip)      */

@@ -39,7 +39,7 @@ for path in sorted(glob.glob(os.path.join(cases.CONFIG_DIR, "*", "*.yml"))):
     if KERNEL != "auto":
         from dex_retargeting_amd import _lib
         model.tune(kernel={"register": _lib.KERNEL_REGISTER, "quad": _lib.KERNEL_QUAD, "lds": _lib.KERNEL_LDS,
-                           "reduced": _lib.KERNEL_REDUCED}[KERNEL])
+                           "reduced": _lib.KERNEL_REDUCED, "wide": _lib.KERNEL_WIDE}[KERNEL])
     dex = prob.kind == "dexpilot"
     mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
     st = (lambda: np.zeros(B, np.uint32)) if dex else (lambda: None)

@@ -42,7 +42,7 @@ class CompModel:
             self.vars[t, : len(idx)] = idx
             self.vmask[t, : len(idx)] = True
         self.T, self.m, self.B = T, m, B
-        self.lo, self.hi = (b[self.vars] for b in prob.bounds)
+        self.lo, self.hi = (b.astype(np.float32).astype(np.float64)[self.vars] for b in prob.bounds)  # the kernels' f32 box
 
     def full(self, xc):
         x = self.last.copy()
@@ -90,7 +90,7 @@ class WholeModel:
         self.B, self.T, self.m = ref.shape[0], 1, prob.n_opt
         self.vars = np.arange(prob.n_opt)[None]
         self.vmask = np.ones((1, prob.n_opt), bool)
-        self.lo, self.hi = (b[None] for b in prob.bounds)
+        self.lo, self.hi = (b.astype(np.float32).astype(np.float64)[None] for b in prob.bounds)  # the kernels' f32 box
 
     def full(self, xc):
         return xc[:, 0]
@@ -103,7 +103,8 @@ class WholeModel:
 
 def kernel_lm(cm, *, lam0=1e-4, tol=2e-6, max_iter=64, step_cap=0.3, lam_jump=1.0, lam_fastdec=0.1, blind_tol_scale=10.0,
               max_blind=8, stall_from=2, stall_ratio=0.9, stall_cap=20.0, newton=True, eps=5.96e-8, gn_when=None,
-              cap_mode="inf", lam_floor=1e-9, trace=None, inner_retry=0, cap_grow=0.0, cap_max=1.2, gersh_at=99, retry_mult=None, pivot_rule=None, pivot_floor=1e-3, blind_contract=0.0, neg_boost=0.0):
+              cap_mode="inf", lam_floor=1e-9, trace=None, inner_retry=0, cap_grow=0.0, cap_max=1.2, gersh_at=99, retry_mult=None, pivot_rule=None, pivot_floor=1e-3, blind_contract=0.0, neg_boost=0.0, jump_mode="hd", noise_scale=None,
+              dec_rule=None, accel=0.0, accel_rho=0.9, gn_mode=None, gn_exit=0.05, gn_lam=None):
     """Returns (x (B,T,m), iters (B,T)).  `eps`: rounding unit of the kernel's arithmetic (float32) for the
     below-the-floor logic.  gn_when: optional callable(F, lam, it) -> bool mask selecting Gauss-Newton models."""
     B, T, m = cm.B, cm.T, cm.m
@@ -111,6 +112,9 @@ def kernel_lm(cm, *, lam0=1e-4, tol=2e-6, max_iter=64, step_cap=0.3, lam_jump=1.
     bi = np.arange(B)[:, None, None]
     x = np.clip(cm.last[bi, cm.vars[None]], cm.lo[None], cm.hi[None])
     F, gs, Hs = cm(x, newton)
+    if gn_mode:  # per-frame model switch: Gauss-Newton (PSD) Hessian after an indefinite Newton model, Newton again near the end
+        Hn, Hg = Hs, cm(x, False)[2]
+        gn = np.zeros((B, T), bool)
     lam = np.full((B, T), lam0)
     nu = np.full((B, T), 2.0)
     sprev = np.full((B, T), 1e30)
@@ -122,6 +126,8 @@ def kernel_lm(cm, *, lam0=1e-4, tol=2e-6, max_iter=64, step_cap=0.3, lam_jump=1.
     for _ in range(max_iter + 2):
         if done.all():
             break
+        if gn_mode:
+            Hs = np.where(gn[..., None, None], Hg, Hn)
         act = ((x <= cm.lo[None]) & (gs > 0)) | ((x >= cm.hi[None]) & (gs < 0))
         free = vm & ~act
         ff = free[..., :, None] & free[..., None, :]
@@ -191,7 +197,7 @@ def kernel_lm(cm, *, lam0=1e-4, tol=2e-6, max_iter=64, step_cap=0.3, lam_jump=1.
         if blind_contract > 0:  # only when the previous step shows the fast (quadratic) contraction of a clean Newton tail
             last_step = last_step & ((smax < 10 * tol) | (smax < blind_contract * sprev))
         Ft, gt, Ht = cm(np.where(done[..., None], x, xt), newton)
-        noise = 16 * eps * np.abs(F)
+        noise = 16 * eps * np.abs(F) if noise_scale is None else noise_scale * np.abs(F)
         finite = np.isfinite(Ft)
         below = ok & finite & (pred <= noise) & (smax < 1e-2)
         accept = ok & finite & ((Ft <= F) | below)
@@ -207,6 +213,14 @@ def kernel_lm(cm, *, lam0=1e-4, tol=2e-6, max_iter=64, step_cap=0.3, lam_jump=1.
         shrink = np.where(below, 1 / 3, np.maximum(1 / 3, 1 - tt ** 3))
         if lam_fastdec > 0:
             shrink = np.where(rho > 0.9, lam_fastdec, shrink)
+        if dec_rule is not None:
+            shrink = dec_rule(rho, shrink, below)
+        if accel > 0:  # consecutive accurate steps: the shrink factor itself shrinks geometrically
+            if _ == 0:
+                streak = np.zeros((B, T), int)
+            good = accept & (np.abs(rho - 1) < 1 - accel_rho)
+            streak_new = np.where(good, streak + 1, 0)
+            shrink = np.where(good, np.maximum((1 / 3) ** streak_new, accel), shrink)
         stalled = below & (blind >= stall_from) & (smax > stall_ratio * sprev) & (smax < stall_cap * tol)
         newblind = np.where(below, blind + 1, 0)
         lam_ok = max(2 * delta, 10 * lam0)
@@ -215,8 +229,11 @@ def kernel_lm(cm, *, lam0=1e-4, tol=2e-6, max_iter=64, step_cap=0.3, lam_jump=1.
         rej = live & ~accept & ~take_last
         lam_rej = np.maximum(lam, 1e-6) * nu
         if lam_jump > 0:
-            hd = np.where(vm, np.einsum("btii->bti", Hs), 0.0).sum(-1) / vm.sum(-1)
-            lam_rej = np.maximum(lam_rej, lam_jump * hd)
+            if jump_mode == "keff":  # quad kernel: curvature of the damped model along the failed step
+                lam_rej = np.maximum(lam_rej, lam_jump * gd / np.maximum(dd, 1e-30))
+            else:
+                hd = np.where(vm, np.einsum("btii->bti", Hs), 0.0).sum(-1) / vm.sum(-1)
+                lam_rej = np.maximum(lam_rej, lam_jump * hd)
         if cap_grow > 0:
             capped = alpha < 1.0
             cap = np.where(acc & capped & (rho > 0.5), np.minimum(cap * cap_grow, cap_max), np.where(rej, np.maximum(cap * 0.5, 0.1), cap))
@@ -226,6 +243,15 @@ def kernel_lm(cm, *, lam0=1e-4, tol=2e-6, max_iter=64, step_cap=0.3, lam_jump=1.
                   f"pred={pred[b_, t_]:.3e} F={F[b_, t_]:.4e} Ft={Ft[b_, t_]:.4e} rho={rho[b_, t_]:.2f} acc={bool(acc[b_, t_])} "
                   f"minEig={np.linalg.eigvalsh(np.where(ff, Hs, 0.0)[b_, t_]).min():.2e} done={bool(done[b_, t_])}")
         upd = acc | take_last
+        if gn_mode:
+            Hgt = cm(np.where(done[..., None], x, xt), False)[2]
+            Hn = np.where(upd[..., None, None], Ht, Hn)
+            Hg = np.where(upd[..., None, None], Hgt, Hg)
+            enter = live & ~ok & ~gn
+            leave = acc & gn & (smax < gn_exit)
+            if gn_lam is not None:  # the PSD model needs far less damping than the jump that followed the failure
+                lam_rej = np.where(enter, np.maximum(lam, gn_lam), lam_rej)
+            gn = (gn | enter) & ~leave
         x = np.where(upd[..., None], xt, x)
         F = np.where(upd, Ft, F)
         gs = np.where(upd[..., None], gt, gs)
@@ -234,6 +260,8 @@ def kernel_lm(cm, *, lam0=1e-4, tol=2e-6, max_iter=64, step_cap=0.3, lam_jump=1.
         lam = np.where(overdamped, np.maximum(0.1 * lam, 0.5 * lam_ok), lam)
         nu = np.where(acc, 2.0, np.where(rej, nu * 2, nu))
         blind = np.where(acc, newblind, blind)
+        if accel > 0:
+            streak = np.where(acc, streak_new, np.where(rej, 0, streak))
         sprev = np.where(acc, smax, sprev)
         done = done | take_last | fin_acc | (rej & (lam > 1e10)) | (rej & finite & (smax < tol)) | (live & (iters >= max_iter))
     return x, iters

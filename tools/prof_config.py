@@ -26,7 +26,7 @@ seq = RetargetingConfig.load_from_file(os.path.join(bench_data.CONFIG_DIR, rel))
 model = seq.optimizer.device_model()
 if kernel != "auto":
     model.tune(kernel={"register": _lib.KERNEL_REGISTER, "quad": _lib.KERNEL_QUAD, "lds": _lib.KERNEL_LDS,
-                       "reduced": _lib.KERNEL_REDUCED}[kernel])
+                       "reduced": _lib.KERNEL_REDUCED, "wide": _lib.KERNEL_WIDE}[kernel])
 dex = seq.optimizer.retargeting_type == "DEXPILOT"
 kp = bench_data.human_keypoints(B + 1)
 mid = np.repeat(seq.joint_limits.mean(1)[None], B, 0).astype(np.float32)
@@ -55,5 +55,9 @@ if len(slow) and len(sys.argv) > 5:  # dump the slowest frames for off-line anal
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
     np.savez(os.path.join(REPO, "gpurun_out", sys.argv[5]), idx=slow, kp=kp[1:][slow], last=last[slow], iters=it[slow],
              state=(st[slow] if dex else np.zeros(len(slow), np.uint32)), q=t_q.cpu().numpy()[slow])
+if len(sys.argv) > 6:  # the first N frames with their inputs and iteration counts (tools/lm_lab.py replays them)
+    nh = int(sys.argv[6])
+    np.savez(os.path.join(REPO, "gpurun_out", "head_" + sys.argv[5]), kp=kp[1:][:nh], last=last[:nh], iters=it[:nh],
+             state=(t_st0.cpu().numpy()[:nh].astype(np.uint32) if dex else np.zeros(nh, np.uint32)), q=t_q.cpu().numpy()[:nh])
 print(f"{rel} kernel={model.kernel()} B={B}: ms {np.median([a.elapsed_time(b) for a, b in ev]):.3f}; iters mean {it.mean():.2f} "
       f"p99 {np.percentile(it, 99):.0f} max {it.max()}; hist {np.bincount(it).tolist()}")
