@@ -384,7 +384,10 @@ void select_kernels(dexr_model* m) {
   const bool red_ok = m->red_nv > 0 && h.kind != DEXR_KIND_FKONLY && m->max_slot < 2 && red_lds <= 160 * 1024 && m->max_joints > 0;
   const bool red_wins = m->has_mimic && m->bucket >= 16;
   m->red = red_ok && (want == DEXR_KERNEL_REDUCED || (want == DEXR_KERNEL_AUTO && red_wins));
-  m->wide = m->wide_ok && want == DEXR_KERNEL_WIDE;
+  // sixteen lanes per frame: measured ahead of every other family on every model it supports (Shadow DexPilot 1.9 vs
+  // 6.4 ms quad, LEAP position 2.1 vs 5.0 ms quad, Shadow vector 1.2 vs 1.9-3.0 ms register, Shadow + free joints 9.8 vs
+  // 23-29 ms LDS; 65 536 frames)
+  m->wide = m->wide_ok && (want == DEXR_KERNEL_WIDE || want == DEXR_KERNEL_AUTO);
   m->red = m->red && !m->wide;
   m->quad = !m->wide && !m->red && quad_ok && (want == DEXR_KERNEL_QUAD || (want == DEXR_KERNEL_AUTO && quad_wins));
   m->big = !m->wide && !m->red && !m->quad && big_ok && (want == DEXR_KERNEL_LDS || (want == DEXR_KERNEL_AUTO && big_wins));
