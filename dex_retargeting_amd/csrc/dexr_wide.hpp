@@ -73,6 +73,8 @@ static __device__ __forceinline__ float wquad_bcast(float v) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), Q * 0x55, 0xF, 0xF, true));
 }
 
+typedef float wv2 __attribute__((ext_vector_type(2)));  // register pair: v_pk_fma_f32 / v_pk_mul_f32 operands
+
 #ifndef DEXR_WIDE_MINW
 #define DEXR_WIDE_MINW 2
 #endif
@@ -209,13 +211,15 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   uint32_t nst = 0;
   float xj[NJ2], xacc[NJ2], xlast[NJ2];  // own joints: trial value, accepted value, regularisation target
   float gacc[NJ2];                       // own joints: gradient at the accepted point (incl. regulariser)
-  float Ha[NR][NR];                      // Hessian grid entries (4 i + a, 4 j + b), j <= i, at the accepted point
+  constexpr int NP = NR / 2;             // column pairs of the local Hessian block
+  wv2 Ha[NR][NP];                        // Hessian grid entries (4 i + a, 4 j + b), j <= i, at the accepted point;
+                                         // pair jj holds local columns 2 jj, 2 jj + 1 (packed FMAs)
 #pragma unroll
   for (int s = 0; s < NJ2; ++s) { xj[s] = 0; xacc[s] = 0; xlast[s] = 0; gacc[s] = 0; }
 #pragma unroll
   for (int i = 0; i < NR; ++i)
 #pragma unroll
-    for (int j = 0; j < NR; ++j) Ha[i][j] = 0;
+    for (int j = 0; j < NP; ++j) Ha[i][j] = wv2{0.f, 0.f};
 
   auto ref_row = [&](int row, float (&rv)[3]) {
     if (kp.kpts) {
@@ -382,7 +386,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 
   // ---- value / gradient (own joints) / Hessian grid at the kinematic state in LDS ------------------------------------
   float gnew[NJ2];
-  float Hn[NR][NR];
+  wv2 Hn[NR][NP];
   auto assemble = [&]() -> double {
     // (1) lane t evaluates term t
     double Fv = 0;
@@ -426,10 +430,12 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         kap = quad ? 0.f : (float)(psi * id * id);
       }
       float* T = TBl + l * 16;
-      *reinterpret_cast<float4*>(T) = make_float4((float)rd[0], (float)rd[1], (float)rd[2], kap);
-      *reinterpret_cast<float4*>(T + 4) = make_float4(fvec[0], fvec[1], fvec[2], hw[0]);
-      *reinterpret_cast<float4*>(T + 8) = make_float4(ptf[0], ptf[1], ptf[2], hw[1]);
-      *reinterpret_cast<float4*>(T + 12) = make_float4(pof[0], pof[1], pof[2], hw[2]);
+      // the Hessian is accumulated as sum_k s_k (sqrt(w_k) J_k) (sqrt(w_k) J_k)^T: the square roots of the row weights
+      // travel with the term, the sign of the Huber rank-one row (-kappa) is applied by the outer product
+      *reinterpret_cast<float4*>(T) = make_float4((float)rd[0], (float)rd[1], (float)rd[2], __fsqrt_rn(kap));
+      *reinterpret_cast<float4*>(T + 4) = make_float4(fvec[0], fvec[1], fvec[2], __fsqrt_rn(hw[0]));
+      *reinterpret_cast<float4*>(T + 8) = make_float4(ptf[0], ptf[1], ptf[2], __fsqrt_rn(hw[1]));
+      *reinterpret_cast<float4*>(T + 12) = make_float4(pof[0], pof[1], pof[2], __fsqrt_rn(hw[2]));
     }
     // regulariser of the own joints
 #pragma unroll
@@ -442,7 +448,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // (2) own joints' axes / origins
+    // (2) own joints' axes / origins; accumulators of the pass: data-term gradient and second-order vector
     float jax[NJ2][3], jog[NJ2][3], jcf[NJ2][3];
 #pragma unroll
     for (int s = 0; s < NJ2; ++s) {
@@ -456,9 +462,15 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 #pragma unroll
     for (int i = 0; i < NR; ++i)
 #pragma unroll
-      for (int j = 0; j < NR; ++j) Hn[i][j] = 0;
+      for (int j = 0; j < NP; ++j) Hn[i][j] = wv2{0.f, 0.f};
 
-    // (3) terms in sequence: Jacobian rows through LDS, outer products into the grid
+    // (3) terms in sequence: lane l forms the Jacobian columns of its joints (l, l + 16), accumulates their gradient
+    // entries and second-order vectors and publishes the term's four weighted Jacobian rows; then every lane adds the
+    // rows' outer products to its Hessian entries.
+    // (Measured alternative: one lane per joint ON THE TERM'S CHAINS from a host-built list -- 11-12 of a Shadow hand's
+    // 24 joints move a DexPilot pair -- with the owner lanes collecting gradient / second-order entries through LDS:
+    // 37 % fewer VALU instructions in this loop, the same 1.9 ms for Shadow DexPilot and 10 % slower for the 16-joint
+    // hands; the pass is bound by LDS round trips, not by VALU issue.)
 #pragma clang loop unroll(disable) vectorize(disable)
     for (int t = 0; t < nt; ++t) {
       const float* T = TBl + t * 16;
@@ -491,33 +503,39 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
           jcf[s][1] += c2 * t1.x - c0 * t1.z;
           jcf[s][2] += c0 * t1.y - c1 * t1.x;
         }
-        const float u = c0 * t0.x + c1 * t0.y + c2 * t0.z;
         // row k of the term's Jacobian^T: position (k mod 4) * NRP + k / 4 of each of the four rows
         const int pos = (k & 3) * NRP + (k >> 2);
-        JRl[0 * 4 * NRP + pos] = c0;
-        JRl[1 * 4 * NRP + pos] = c1;
-        JRl[2 * 4 * NRP + pos] = c2;
-        JRl[3 * 4 * NRP + pos] = u;
+        JRl[0 * 4 * NRP + pos] = c0 * t1.w;
+        JRl[1 * 4 * NRP + pos] = c1 * t2.w;
+        JRl[2 * 4 * NRP + pos] = c2 * t3.w;
+        if (!per_coord) JRl[3 * 4 * NRP + pos] = (c0 * t0.x + c1 * t0.y + c2 * t0.z) * t0.w;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      const float wk[4] = {t1.w, t2.w, t3.w, -t0.w};
+      const int nrow = per_coord ? 3 : 4;  // SmoothL1 per coordinate has no rank-one row
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        float jr[NRP], jc[NRP];
+        if (kk < nrow) {
+          float jr[NRP];
+          wv2 jc[NRP / 2];
 #pragma unroll
-        for (int i = 0; i < NRP; i += 4) {
-          if (i < NR) {
-            const float4 rv = *reinterpret_cast<const float4*>(JRl + kk * 4 * NRP + a * NRP + i);
-            const float4 cv = *reinterpret_cast<const float4*>(JRl + kk * 4 * NRP + b * NRP + i);
-            jr[i] = rv.x * wk[kk]; jr[i + 1] = rv.y * wk[kk]; jr[i + 2] = rv.z * wk[kk]; jr[i + 3] = rv.w * wk[kk];
-            jc[i] = cv.x; jc[i + 1] = cv.y; jc[i + 2] = cv.z; jc[i + 3] = cv.w;
+          for (int i = 0; i < NRP; i += 4) {
+            if (i < NR) {
+              const float4 rv = *reinterpret_cast<const float4*>(JRl + kk * 4 * NRP + a * NRP + i);
+              const float4 cv = *reinterpret_cast<const float4*>(JRl + kk * 4 * NRP + b * NRP + i);
+              jr[i] = rv.x; jr[i + 1] = rv.y; jr[i + 2] = rv.z; jr[i + 3] = rv.w;
+              jc[i / 2] = wv2{cv.x, cv.y};
+              jc[i / 2 + 1] = wv2{cv.z, cv.w};
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < NR; ++i) {
+            const float ri = kk == 3 ? -jr[i] : jr[i];
+            const wv2 rr = wv2{ri, ri};
+#pragma unroll
+            for (int jj = 0; jj <= i / 2; ++jj) Hn[i][jj] = __builtin_elementwise_fma(rr, jc[jj], Hn[i][jj]);
           }
         }
-#pragma unroll
-        for (int i = 0; i < NR; ++i)
-#pragma unroll
-          for (int j = 0; j <= i; ++j) Hn[i][j] += jr[i] * jc[j];
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -539,7 +557,8 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 #pragma unroll
         for (int j = 0; j <= i; ++j) {
           const float v = axc[j].x * cf.x + axc[j].y * cf.y + axc[j].z * cf.z;
-          Hn[i][j] += ((ancr[i] >> (4 * j + b)) & 1u) ? v : 0.f;
+          const float add = ((ancr[i] >> (4 * j + b)) & 1u) ? v : 0.f;
+          if (j & 1) Hn[i][j / 2].y += add; else Hn[i][j / 2].x += add;
         }
       }
     }
@@ -550,42 +569,49 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   float dstep[NJ2];  // own joints' entries of the step
   auto factor_and_solve = [&](uint32_t freemask, float lam) -> bool {
     bool ok = true;
-    float Hw[NR][NR];
+    wv2 Hw[NR][NP];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       const int r = 4 * i + a;
       const bool fr = (freemask >> r) & 1u;
 #pragma unroll
-      for (int j = 0; j <= i; ++j) {
+      for (int j = 0; j <= (i | 1); ++j) {
         const int c = 4 * j + b;
         const bool fc = (freemask >> c) & 1u;
-        float v = (fr && fc) ? Ha[i][j] : 0.f;
+        float v = (fr && fc && j <= i) ? ((j & 1) ? Ha[i][j / 2].y : Ha[i][j / 2].x) : 0.f;
         if (i == j && a == b) v = fr ? v + 2.f * delta + lam : 1.f;
-        Hw[i][j] = v;
+        if (j & 1) Hw[i][j / 2].y = v; else Hw[i][j / 2].x = v;
       }
     }
-    float ivs[NMAX];
+    auto hw_get = [&](int i, int j) -> float { return (j & 1) ? Hw[i][j / 2].y : Hw[i][j / 2].x; };
+    float ivr[NR], ivc[NR];  // 1 / L[r][r] of row 4 i + a and of column 4 j + b
+#pragma unroll
+    for (int i = 0; i < NR; ++i) { ivr[i] = 0.f; ivc[i] = 0.f; }
 #pragma unroll
     for (int jc = 0; jc < NMAX; ++jc) {
       constexpr int dummy = 0;
       (void)dummy;
       const int ja = jc & 3, jo = jc >> 2;
-      float dj = __int_as_float(__builtin_amdgcn_ds_bpermute(rowbase4 + 20 * ja, __float_as_int(Hw[jo][jo])));  // lane (ja, ja)
+      // pivot: lane (ja, ja) -> its quad (DPP) -> the row (mask + stride-4 sum)
+      const float own_d = hw_get(jo, jo);
+      const float qd = ja == 0 ? wquad_bcast<0>(own_d) : ja == 1 ? wquad_bcast<1>(own_d) : ja == 2 ? wquad_bcast<2>(own_d) : wquad_bcast<3>(own_d);
+      float dj = stride4_sum(a == ja ? qd : 0.f);
       if (!(dj > 1e-30f)) { ok = false; dj = 1.f; }
       const float iv = __frsqrt_rn(dj);
-      ivs[jc] = iv;
-      // scale column jc (lanes of column class ja), rows below the pivot
+      ivr[jo] = (a == ja) ? iv : ivr[jo];
+      ivc[jo] = (b == ja) ? iv : ivc[jo];
+      // scale column jc (lanes of column class ja), rows below the pivot; then send it to the grid: row side from
+      // lane (a, ja) (own quad, DPP), column side from lane (b, ja) (ds_bpermute)
+      float Lr[NR];
+      wv2 Lc[NP];
+#pragma unroll
+      for (int jj = 0; jj < NP; ++jj) Lc[jj] = wv2{0.f, 0.f};
 #pragma unroll
       for (int i = jo; i < NR; ++i) {
         const bool below = (i > jo) || (a > ja);
-        const float v = Hw[i][jo] * iv;
-        Hw[i][jo] = (b == ja && below) ? v : Hw[i][jo];
-      }
-      // pivot column to the grid: row side from lane (a, ja) (own quad), column side from lane (b, ja)
-      float Lr[NR], Lc[NR];
-#pragma unroll
-      for (int i = jo; i < NR; ++i) {
-        const float own = Hw[i][jo];
+        const float cur = hw_get(i, jo);
+        const float own = (b == ja && below) ? cur * iv : cur;
+        if (jo & 1) Hw[i][jo / 2].y = own; else Hw[i][jo / 2].x = own;
         float vr = ja == 0 ? wquad_bcast<0>(own) : ja == 1 ? wquad_bcast<1>(own) : ja == 2 ? wquad_bcast<2>(own) : wquad_bcast<3>(own);
         float vc = __int_as_float(__builtin_amdgcn_ds_bpermute(rowbase4 + 16 * b + 4 * ja, __float_as_int(own)));
         if (i == jo) {
@@ -593,15 +619,15 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
           vc = (b > ja) ? vc : 0.f;
         }
         Lr[i] = vr;
-        Lc[i] = vc;
+        if (i & 1) Lc[i / 2].y = vc; else Lc[i / 2].x = vc;
       }
+      // the pivot column itself (local column jo on lanes with b == ja) sees Lc[jo] = 0 there: it stays as scaled
 #pragma unroll
-      for (int i = jo; i < NR; ++i)
+      for (int i = jo; i < NR; ++i) {
+        const wv2 rr = wv2{-Lr[i], -Lr[i]};
 #pragma unroll
-        for (int j = jo; j <= i; ++j) {
-          const bool col_jc = (j == jo) && (b == ja);  // the scaled pivot column itself stays
-          Hw[i][j] -= col_jc ? 0.f : Lr[i] * Lc[j];
-        }
+        for (int jj = jo / 2; jj <= i / 2; ++jj) Hw[i][jj] = __builtin_elementwise_fma(rr, Lc[jj], Hw[i][jj]);
+      }
     }
     // forward: L y = rhs; yb[j] = y[4 j + b]
     float yb[NR], da[NR], ga[NR];
@@ -617,10 +643,10 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       const int ra = r & 3, ro = r >> 2;
       float part = 0;
 #pragma unroll
-      for (int j = 0; j <= ro; ++j) part += Hw[ro][j] * yb[j];  // entries at or right of the diagonal meet yb = 0
+      for (int j = 0; j <= ro; ++j) part += hw_get(ro, j) * yb[j];  // entries at or right of the diagonal meet yb = 0
       const float sum = wquad_sum(part);
-      const float yr_local = (ga[ro] - sum) * ivs[r];  // valid on quad ra
-      const float yr = __int_as_float(__builtin_amdgcn_ds_bpermute(rowbase4 + 16 * ra, __float_as_int(yr_local)));
+      const float yr_local = (ga[ro] - sum) * ivr[ro];  // valid on quad ra
+      const float yr = stride4_sum(a == ra ? yr_local : 0.f);  // quad ra -> every quad
       yb[ro] = (b == ra) ? yr : yb[ro];
     }
     // backward: L^T d = y; da[i] = d[4 i + a]
@@ -631,10 +657,11 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       const int rb = r & 3, ro = r >> 2;
       float part = 0;
 #pragma unroll
-      for (int i = ro; i < NR; ++i) part += Hw[i][ro] * da[i];  // rows at or above r meet da = 0
+      for (int i = ro; i < NR; ++i) part += hw_get(i, ro) * da[i];  // rows at or above r meet da = 0
       const float sum = stride4_sum(part);                      // valid on lanes of column class rb
-      const float dr_local = (yb[ro] - sum) * ivs[r];
-      const float dr = __int_as_float(__builtin_amdgcn_ds_bpermute(rowbase4 + 4 * rb, __float_as_int(dr_local)));
+      const float dr_local = (yb[ro] - sum) * ivc[ro];
+      const float dr = rb == 0 ? wquad_bcast<0>(dr_local) : rb == 1 ? wquad_bcast<1>(dr_local)
+                     : rb == 2 ? wquad_bcast<2>(dr_local) : wquad_bcast<3>(dr_local);  // lane b = rb of every quad
       da[ro] = (a == rb) ? dr : da[ro];
 #pragma unroll
       for (int s = 0; s < NJ2; ++s) dstep[s] = (jo_[s] == r) ? dr : dstep[s];
@@ -758,7 +785,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 #pragma unroll
         for (int i = 0; i < NR; ++i)
 #pragma unroll
-          for (int j = 0; j <= i; ++j) Ha[i][j] = Hn[i][j];
+          for (int j = 0; j <= i / 2; ++j) Ha[i][j] = Hn[i][j];
       }
     }
     // active set of the accepted point, gathered from the 16 lanes of the row
