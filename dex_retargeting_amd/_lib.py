@@ -36,6 +36,7 @@ KERNEL_AUTO, KERNEL_REGISTER, KERNEL_QUAD, KERNEL_LDS, KERNEL_REDUCED, KERNEL_WI
 
 EXPORTS = ["dexr_last_error", "dexr_version", "dexr_device_count", "dexr_default_options", "dexr_model_create",
            "dexr_model_destroy", "dexr_model_info", "dexr_model_get_tuning", "dexr_model_set_tuning", "dexr_model_kernel",
+           "dexr_model_lane_plan",
            "dexr_retarget_dev", "dexr_retarget_seq_dev", "dexr_seq_compose_dev", "dexr_fleet_workspace_bytes",
            "dexr_retarget_multi_dev", "dexr_retarget", "dexr_retarget_f64",
            "dexr_retarget_kp_dev", "dexr_retarget_kp", "dexr_eval", "dexr_fk", "dexr_mano_keypoints_dev",
@@ -73,6 +74,7 @@ def load() -> C.CDLL:
     lib.dexr_model_get_tuning.argtypes = [vp, C.POINTER(Tuning)]
     lib.dexr_model_set_tuning.argtypes = [vp, C.POINTER(Tuning)]
     lib.dexr_model_kernel.argtypes = [vp, i32p, i32p, i32p]
+    lib.dexr_model_lane_plan.argtypes = [vp, C.c_int32, i32p, i32p, vp, vp]
     lib.dexr_retarget_dev.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, optp, vp]
     lib.dexr_retarget_seq_dev.argtypes = [vp, i64, C.c_int32, vp, C.c_int32, vp, vp, vp, vp, vp, C.c_float, optp, vp]
     lib.dexr_seq_compose_dev.argtypes = [i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, f64p, f64p, vp, vp,
@@ -154,6 +156,15 @@ class Model:
         f, b, c = C.c_int32(), C.c_int32(), C.c_int32()
         check(load().dexr_model_kernel(self._h, C.byref(f), C.byref(b), C.byref(c)))
         return int(f.value), int(b.value), bool(c.value)
+
+    def lane_plan(self, comp: int = 0):
+        """(n_chain, depth, chain (16,16) uint8, anc_rev (32,) uint32) of the sixteen-lane kernel for one component."""
+        n, d = C.c_int32(), C.c_int32()
+        chain = np.zeros((16, 16), np.uint8)
+        anc = np.zeros(32, np.uint32)
+        check(load().dexr_model_lane_plan(self._h, comp, C.byref(n), C.byref(d), chain.ctypes.data_as(C.c_void_p),
+                                          anc.ctypes.data_as(C.c_void_p)))
+        return int(n.value), int(d.value), chain, anc
 
     # host-pointer entry points -------------------------------------------------------------------
     def retarget(self, ref, fixed, last, state=None, opts: Optional[SolveOptions] = None, want_info=False,

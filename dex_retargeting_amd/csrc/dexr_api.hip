@@ -646,6 +646,19 @@ int dexr_model_kernel(const dexr_model* m, int32_t* family, int32_t* bucket, int
   return DEXR_OK;
 }
 
+int dexr_model_lane_plan(const dexr_model* m, int32_t comp, int32_t* n_chain, int32_t* depth, uint8_t* chain_out,
+                         uint32_t* anc_rev_out) {
+  if (!m) return fail(DEXR_ERR_INVALID, "null argument");
+  if (!m->wide_ok) return fail(DEXR_ERR_UNSUPPORTED, "model does not fit the sixteen-lane kernel");
+  if (comp < 0 || comp >= (int32_t)m->wide_tabs.size()) return fail(DEXR_ERR_INVALID, "component %d out of range", comp);
+  const dexr::WideTable& w = m->wide_tabs[comp];
+  if (n_chain) *n_chain = w.n_chain;
+  if (depth) *depth = w.depth;
+  if (chain_out) std::memcpy(chain_out, w.chain, sizeof(w.chain));
+  if (anc_rev_out) std::memcpy(anc_rev_out, w.anc_rev, sizeof(w.anc_rev));
+  return DEXR_OK;
+}
+
 static int retarget_dev_impl(const dexr_model* m, int64_t B, const float* ref, bool ref_is_keypoints, const float* fixed,
                              const float* last, uint32_t* state, float* qpos_out, int32_t* status_out,
                              int32_t* iters_out, float* fval_out, const dexr_solve_options* opt, void* stream) {

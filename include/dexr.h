@@ -101,6 +101,11 @@ int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning);  /* re-runs
 /* Which float32 solve kernel the handle launches: DEXR_KERNEL_* in *family, joint bucket in *bucket, 1 in *chain
  * when the serial-chain specialisation is active (diagnostics for tools/ and tests). */
 int dexr_model_kernel(const dexr_model* m, int32_t* family, int32_t* bucket, int32_t* chain);
+/* Diagnostics: the lane plan of component `comp` for the sixteen-lane kernel -- chain_out[16][16]: lane l, step s ->
+ * local joint (bit 7 set when that lane publishes the joint's frame, 0xFF: none); anc_rev_out[DEXR_MAXJ]: revolute
+ * ancestors-or-self of each joint.  DEXR_ERR_UNSUPPORTED when the model does not fit that kernel. */
+int dexr_model_lane_plan(const dexr_model* m, int32_t comp, int32_t* n_chain, int32_t* depth, uint8_t* chain_out,
+                         uint32_t* anc_rev_out);
 
 /* == Optimizer.retarget x B  (optimizer.py:77-102).
  *   ref      B x n_ref x 3 float32  (vector/dexpilot: task-origin vectors; position: target positions)

@@ -846,3 +846,87 @@ def test_native_fleet_entry_point_handles_edge_cases():
         assert np.abs(out[sel][:, : prob.n_opt] - want).max() < 2e-6
         assert np.all(out[sel][:, prob.n_opt:] == -7.0)
         assert np.all(status[sel] <= 1)
+
+
+# ---- sixteen-lanes-per-frame kernel (dexr_wide.hpp) ---------------------------------------------------------------------
+WIDE_CONFIGS = ["teleop/shadow_hand_right_dexpilot.yml", "offline/leap_hand_left.yml", "teleop/allegro_hand_right_dexpilot.yml",
+                "offline/shadow_hand_right.yml", "teleop/shadow_hand_right.yml"]
+
+
+@pytest.mark.parametrize("rel", WIDE_CONFIGS)
+def test_lane_plan_covers_the_kinematic_tree(rel):
+    """The host-built lane plan of the sixteen-lane kernel: every joint is published by exactly one lane, every lane's
+    chain is a root-to-leaf path of the tree the tables encode (restore / save slots), and the ancestor masks list the
+    revolute joints on the path from the root."""
+    seq, prob = build(rel)
+    model = seq.optimizer.device_model()
+    assert model.kernel()[0] == _lib.KERNEL_WIDE
+    comps = seq.optimizer.compiled_model().comps
+    for ci, comp in enumerate(comps):
+        n_chain, depth, chain, anc = model.lane_plan(ci)
+        nj = int(comp["n_joint"])
+        parent, owner = {}, {}
+        for k in range(nj):
+            rs = int(comp["restore"][k])
+            parent[k] = -1 if rs == -2 else (owner[rs] if rs >= 0 else k - 1)
+            if int(comp["save"][k]) >= 0:
+                owner[int(comp["save"][k])] = k
+        leaves = [k for k in range(nj) if k not in parent.values()]
+        assert n_chain == len(leaves) <= 16 and 1 <= depth <= 16
+        published = []
+        for lane in range(16):
+            joints = [int(c & 0x7F) for c in chain[lane] if c != 0xFF]
+            published += [int(c & 0x7F) for c in chain[lane] if c != 0xFF and c & 0x80]
+            if lane >= n_chain:
+                assert not joints
+                continue
+            assert list(chain[lane][len(joints):]) == [0xFF] * (16 - len(joints))
+            assert parent[joints[0]] == -1 and joints[-1] in leaves
+            assert all(parent[b] == a for a, b in zip(joints[:-1], joints[1:]))
+            assert max(len(joints), 1) <= depth
+        assert sorted(published) == list(range(nj))
+        for k in range(nj):
+            want, j = 0, k
+            while j >= 0:
+                if int(comp["jtype"][j]) == 0:
+                    want |= 1 << j
+                j = parent[j]
+            assert int(anc[k]) == want
+
+
+@pytest.mark.parametrize("rel", ["teleop/shadow_hand_right_dexpilot.yml", "offline/leap_hand_left.yml",
+                                 "teleop/allegro_hand_right_dexpilot.yml"])
+def test_sixteen_lane_and_four_lane_kernels_agree(rel):
+    """Same damping rules, different work distribution and summation order: the two kernel families return the same
+    minimiser (to float32 solve accuracy) on all but the few frames where rounding sends them to different basins, and
+    the sixteen-lane kernel is deterministic run to run."""
+    seq, prob = build(rel)
+    model = seq.optimizer.device_model()
+    B = 4096
+    kp = np.ascontiguousarray(cases.human_keypoints(B + 1, seed=cases.SEED))
+    mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
+    dex = prob.kind == "dexpilot"
+
+    def run(kernel, kpts, start):
+        model.tune(kernel=kernel)
+        st = np.zeros(B, np.uint32) if dex else None
+        q, info = model.retarget(kpts, None, start, state=st, keypoints=True, want_info=True)
+        return q, info
+
+    last, _ = run(_lib.KERNEL_WIDE, kp[:-1], mid)
+    qw, iw = run(_lib.KERNEL_WIDE, kp[1:], last)
+    assert model.kernel()[0] == _lib.KERNEL_WIDE
+    qw2, _ = run(_lib.KERNEL_WIDE, kp[1:], last)
+    assert np.array_equal(qw, qw2)
+    qq, iq = run(_lib.KERNEL_QUAD, kp[1:], last)
+    assert model.kernel()[0] == _lib.KERNEL_QUAD
+    model.tune(kernel=_lib.KERNEL_AUTO)
+    assert (iw["status"] == 0).all() and (iq["status"] == 0).all()
+    dq = np.abs(qw.astype(np.float64) - qq).max(1)
+    assert (dq > 1e-4).mean() < 0.01, (dq > 1e-4).sum()
+    assert np.percentile(dq, 95) < 2e-5, np.percentile(dq, [50, 95, 99])
+
+
+def test_mimic_models_keep_the_reduced_variable_kernel():
+    seq, _ = build("teleop/schunk_svh_hand_right_dexpilot.yml")
+    assert seq.optimizer.device_model().kernel()[0] == _lib.KERNEL_REDUCED
