@@ -53,7 +53,8 @@ WORKLOADS = {
 }
 KERNEL_NAMES = {0: "dexr_kernel (one lane per frame and component, Hessian in registers)",
                 1: "dexr_quad_kernel (four lanes per frame)", 2: "dexr_big_kernel (Hessian in LDS)",
-                3: "dexr_red_kernel (reduced variables: Hessian in registers, kinematics in LDS)"}
+                3: "dexr_red_kernel (reduced variables: Hessian in registers, kinematics in LDS)",
+                4: "dexr_wide_kernel (sixteen lanes per frame: chain-parallel FK, 4 x 4 lane grid Hessian / Cholesky)"}
 
 
 def algorithmic_bytes_per_frame(n_opt: int, dexpilot: bool, n_rows: int, keypoints: bool) -> int:
