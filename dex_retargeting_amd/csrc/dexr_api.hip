@@ -56,7 +56,10 @@ struct dexr_model {
   bool quad = false;   // dense 9..24-joint components solved four lanes per frame (dexr_quad_kernel)
   bool big = false;    // components of 9+ joints solved by dexr_big_kernel (Hessian in LDS, float64 kinematics)
   bool wide = false;   // dense 9..32-joint components solved sixteen lanes per frame (dexr_wide_kernel)
-  bool wide_ok = false;  // the model fits that kernel (no mimic joints, <= 16 root-to-leaf chains of <= 16 joints)
+  bool wide_ok = false;  // the model fits that kernel (<= 16 root-to-leaf chains of <= 16 joints; with mimic joints:
+                         // <= 16 variables moving <= 3 joints each)
+  bool wide_mimic = false;  // ... through its variable-grid instantiation (mimic joints folded)
+  bool wide_modchol = false;  // ... with modified Cholesky and the damping rules that go with it (tune.pivot_rule)
   std::vector<dexr::WideTable> wide_tabs;
   dexr::WideTable* d_wide = nullptr;
   bool red = false;    // solved in reduced variables by dexr_red_kernel (Hessian of the variables in registers)
@@ -93,6 +96,7 @@ void fill_params(const dexr_model* m, dexr::KernelParams& kp, int64_t B) {
   // curvature instead of creeping up by x2, x4, ...; small components also drop it by 10x (not 3x) after a step the
   // model predicted well.  Allegro vector, 65 536 frames: 0.143 -> 0.119 ms; Shadow DexPilot: 19.4 -> 15.4 ms.
   kp.lam_jump = m->tune.lam_jump;
+  kp.modchol = m->wide_modchol ? 1 : 0;
   kp.lam_fastdec = m->tune.lam_fastdec;
   kp.floor_scale = m->tune.floor_scale;
   kp.step_cap = m->tune.step_cap;
@@ -204,9 +208,9 @@ int launch_quad(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
 
 // sixteen lanes per frame: four frames per wave, two waves per SIMD resident; persistent rows fed like the quads
 int launch_wide(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
-  const size_t per_wave = dexr::wide_lds_per_wave(m->bucket);
+  const size_t per_wave = m->wide_mimic ? dexr::wide_lds_per_wave_m_16() : dexr::wide_lds_per_wave(m->bucket);
   int wpb = 4;
-  while (wpb > 1 && per_wave * wpb > 64 * 1024) wpb >>= 1;
+  while (wpb > 1 && per_wave * wpb > 80 * 1024) wpb >>= 1;
   const int64_t tiles = (kp.B + 3) / 4;
   int64_t resident = (int64_t)m->n_cu * 4 * 2;
   if (m->tune.resident_waves > 0) resident = m->tune.resident_waves;
@@ -220,7 +224,7 @@ int launch_wide(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
   kp.queue = m->d_queue + (size_t)slot * kp.n_comp;
   hipError_t qe = hipMemsetAsync(kp.queue, 0, (size_t)kp.n_comp * sizeof(unsigned), st);
   if (qe != hipSuccess) return fail(DEXR_ERR_HIP, "queue reset failed: %s", hipGetErrorString(qe));
-  dexr::wide_launch_fn fn = dexr::find_wide_launcher(m->bucket);
+  dexr::wide_launch_fn fn = m->wide_mimic ? dexr::launch_wide_m_16 : dexr::find_wide_launcher(m->bucket);
   if (!fn) return fail(DEXR_ERR_UNSUPPORTED, "no sixteen-lane kernel for bucket %d", m->bucket);
   hipError_t e = fn(kp, m->d_wide, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, st);
   if (e != hipSuccess) return fail(DEXR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -231,7 +235,9 @@ int launch_wide(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
 // of every joint, from the depth-first restore / save encoding of the tables (dexr_tables.h).
 bool build_wide_tables(dexr_model* m) {
   m->wide_tabs.clear();
-  if (m->has_mimic || m->bucket < 16 || m->h.kind == DEXR_KIND_FKONLY) return false;
+  m->wide_mimic = m->has_mimic;
+  if (m->bucket < 16 || m->h.kind == DEXR_KIND_FKONLY) return false;
+  if (m->has_mimic && (m->max_vars > 16 || m->max_joints > 32)) return false;
   for (const dexr_comp_table& c : m->comps) {
     dexr::WideTable w;
     std::memset(&w, 0, sizeof(w));
@@ -243,7 +249,7 @@ bool build_wide_tables(dexr_model* m) {
     for (int s = 0; s <= DEXR_NSLOT; ++s) slot_owner[s] = -1;
     for (int k = 0; k < nj; ++k) {
       has_child[k] = false;
-      if (c.src_kind[k] != DEXR_SRC_OPT && c.src_kind[k] != DEXR_SRC_FIXED) return false;
+      if (c.src_kind[k] != DEXR_SRC_OPT && c.src_kind[k] != DEXR_SRC_FIXED && c.src_kind[k] != DEXR_SRC_MIMIC) return false;
       const int rs = c.restore[k];
       if (rs == -2) parent[k] = -1;
       else if (rs >= 0) { if (rs > DEXR_NSLOT) return false; parent[k] = slot_owner[rs]; }
@@ -277,6 +283,44 @@ bool build_wide_tables(dexr_model* m) {
     }
     w.n_chain = n_chain;
     w.depth = depth;
+    std::memset(w.fam, 0xFF, sizeof(w.fam));
+    if (m->has_mimic) {
+      // joint families of the variables, the variable's own joint first
+      int fam_n[16] = {0};
+      for (int v = 0; v < c.n_var; ++v) w.fam[v][fam_n[v]++] = (uint8_t)c.var_joint[v];
+      for (int k = 0; k < nj; ++k) {
+        const int v = c.var[k];
+        if (v < 0 || c.var_joint[v] == k) continue;
+        if (fam_n[v] == 3) return false;
+        w.fam[v][fam_n[v]++] = (uint8_t)k;
+      }
+      for (int v = 0; v < c.n_var; ++v) w.fam_max = fam_n[v] > w.fam_max ? fam_n[v] : w.fam_max;
+      // second-order pairs (k, revolute ancestor-or-self j), bucketed by the lane (vhi mod 4, vlo mod 4) that owns
+      // the target entry (vhi, vlo) of the variable grid
+      struct PairRec { int lane; uint32_t word; };
+      std::vector<PairRec> recs;
+      for (int k = 0; k < nj; ++k) {
+        if (c.var[k] < 0) continue;
+        for (int j = k; j >= 0; j = parent[j]) {
+          if (c.jtype[j] != DEXR_JOINT_REVOLUTE || c.var[j] < 0) continue;
+          const int vk = c.var[k], vj = c.var[j];
+          const int vhi = vk > vj ? vk : vj, vlo = vk > vj ? vj : vk;
+          const int i = vhi >> 2, jj = vlo >> 2;
+          const uint32_t dbl = (j != k && vk == vj) ? 1u : 0u;
+          recs.push_back({(vhi & 3) * 4 + (vlo & 3), (uint32_t)k | ((uint32_t)j << 5) | ((uint32_t)(i * (i + 1) / 2 + jj) << 10) | (dbl << 14)});
+        }
+      }
+      if (recs.size() > 128) return false;
+      int n = 0;
+      for (int ln = 0; ln < 16; ++ln) {
+        w.pair_off[ln] = (uint8_t)n;
+        for (const PairRec& r : recs)
+          if (r.lane == ln) w.pair[n++] = r.word;
+        const int cnt = n - w.pair_off[ln];
+        if (cnt > w.pair_max) w.pair_max = cnt;
+      }
+      w.pair_off[16] = (uint8_t)n;
+    }
     m->wide_tabs.push_back(w);
   }
   return true;
@@ -358,6 +402,7 @@ void default_tuning(dexr_model* m) {
   // small components: a verified, undamped Newton step below 100 tol (2e-4 rad) leaves an error of ~C s^2 < 1e-6 rad
   // (tools/lm_lab.py: max 8.6e-7 over 1 863 frames) and saves the confirming pass: mean 4.3 -> 3.9 passes per frame
   t.blind_tol_scale = m->bucket <= 8 ? 100.f : 10.f;
+  t.pivot_rule = -1;
 }
 
 // Which float32 solve kernel serves the model.  Measured on MI355X (65 536 frames, tools/all_configs.py,
@@ -388,6 +433,9 @@ void select_kernels(dexr_model* m) {
   // 6.4 ms quad, LEAP position 2.1 vs 5.0 ms quad, Shadow vector 1.2 vs 1.9-3.0 ms register, Shadow + free joints 9.8 vs
   // 23-29 ms LDS; 65 536 frames)
   m->wide = m->wide_ok && (want == DEXR_KERNEL_WIDE || want == DEXR_KERNEL_AUTO);
+  // mimic vector models (SVH: two small components) stay on the reduced-variable kernel: 0.7-0.8 vs 0.9-1.1 ms
+  if (m->wide && m->has_mimic && want == DEXR_KERNEL_AUTO && h.kind == DEXR_KIND_VECTOR && red_ok) m->wide = false;
+  m->wide_modchol = m->wide && (m->tune.pivot_rule > 0 || (m->tune.pivot_rule < 0 && m->wide_mimic && h.kind == DEXR_KIND_DEXPILOT));
   m->red = m->red && !m->wide;
   m->quad = !m->wide && !m->red && quad_ok && (want == DEXR_KERNEL_QUAD || (want == DEXR_KERNEL_AUTO && quad_wins));
   m->big = !m->wide && !m->red && !m->quad && big_ok && (want == DEXR_KERNEL_LDS || (want == DEXR_KERNEL_AUTO && big_wins));
@@ -427,7 +475,8 @@ bool polish_wanted(const dexr_model* m, const dexr_solve_options* opt) {
   if (polish < 0) polish = (m->h.kind == DEXR_KIND_POSITION || m->h.kind == DEXR_KIND_DEXPILOT) ? 24 : 0;
   if (polish == 0 || m->bucket == 32) return false;
   const int strict = opt ? opt->strict : 0;
-  if (m->red && strict <= 0) return false;  // reduced-variable kernel: float64 kinematics and value, see dexr_red.hpp
+  if ((m->red || (m->wide && m->wide_mimic)) && strict <= 0) return false;  // variable-space kernels: float64 kinematics
+                                                                            // (incl. the mimic joint values) and value
   if ((m->big || m->quad || m->wide) && !(strict > 0 || (strict == 0 && m->has_mimic))) return false;
   return true;
 }
@@ -568,7 +617,7 @@ int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out) {
   default_tuning(m);
   m->wide_ok = build_wide_tables(m);
   select_kernels(m);
-  if (m->quad || m->wide) m->tune.lam_jump = 1.0f;  // the quad kernel scales the jump by the curvature along the failed step
+  if (m->quad || (m->wide && !m->wide_modchol)) m->tune.lam_jump = 1.0f;  // the quad kernel scales the jump by the curvature along the failed step
   if (m->bucket < 0) {
     delete m;
     return fail(DEXR_ERR_UNSUPPORTED, "component with %d joints exceeds the largest kernel bucket", maxj);
@@ -629,6 +678,7 @@ int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning) {
   std::memcpy(&t, tuning, tuning->struct_size);
   t.struct_size = (uint32_t)sizeof(dexr_tuning);
   if (t.kernel < DEXR_KERNEL_AUTO || t.kernel > DEXR_KERNEL_WIDE) return fail(DEXR_ERR_INVALID, "unknown kernel family %d", t.kernel);
+  if (t.pivot_rule < -1 || t.pivot_rule > 1) return fail(DEXR_ERR_INVALID, "unknown pivot rule %d", t.pivot_rule);
   if (t.persist_from < 0 || t.qchunk < 0 || t.persist_occ < 0 || t.resident_waves < 0 || t.max_blind < 0)
     return fail(DEXR_ERR_INVALID, "negative launch parameter");
   if (!(t.step_cap >= 0) || !(t.lam_jump >= 0) || !(t.lam_fastdec >= 0) || !(t.floor_scale >= 0) || !(t.blind_tol_scale >= 0))

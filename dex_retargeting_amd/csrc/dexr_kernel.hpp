@@ -62,6 +62,7 @@ struct KernelParams {
   int32_t stall_from;             // termination at the float rounding floor (see "stalled" in the kernels): from this
   float stall_ratio;              // many unverifiable ("blind") steps on, a step that is not < stall_ratio x the
   float stall_cap;                // previous one and is < stall_cap x tol ends the solve
+  int32_t modchol;                // dexr_wide_kernel: modified Cholesky + its damping rules (dexr_tuning.pivot_rule)
   uint32_t q0;                    // queue mode: frames [0, q0) are handed out statically (wave w starts with tile w),
                                   // the queue counter numbers the frames from q0 on
   uint32_t qchunk;                // frames a wave takes from its component's queue per atomicAdd; 0 = tile mode
@@ -92,6 +93,12 @@ struct WideTable {
   int32_t n_chain, depth;       // root-to-leaf chains (<= 16) and the longest one (<= 16 joints)
   uint8_t chain[16][16];        // [lane][step]: local joint | 0x80 when this lane publishes it; 0xFF = none
   uint32_t anc_rev[DEXR_MAXJ];  // bit c set <=> joint c is a REVOLUTE ancestor-or-self of joint r
+  // models with mimic joints (grid of the <= 16 optimised variables):
+  uint8_t fam[16][4];           // joints that move with variable v (its own joint first), 0xFF-padded
+  int32_t fam_max;              // largest family
+  uint32_t pair[128];           // second-order joint pairs: k | j << 5 | local lower entry << 10 | doubled << 14,
+  uint8_t pair_off[20];         // sorted by the lane that owns the target entry: lane l has [pair_off[l], pair_off[l+1])
+  int32_t pair_max;             // longest per-lane list
 };
 
 enum { MODE_SOLVE = 0, MODE_EVAL = 1, MODE_FK = 2 };

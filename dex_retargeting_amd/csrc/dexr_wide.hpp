@@ -80,35 +80,50 @@ typedef float wv2 __attribute__((ext_vector_type(2)));  // register pair: v_pk_f
 #endif
 
 // blockDim.x = 256 (4 waves x 4 frames); dynamic LDS per wave = wide_lds_bytes(NMAX)
-template <int NMAX>
+// NMAX: size of the Hessian grid (joints; with MIMIC: optimised VARIABLES, mimic joints folded into their source's
+// column).  NJ: joints the kinematics can hold.
+template <int NMAX, bool MIMIC>
 struct WideLds {
+  static constexpr int NJ = MIMIC ? 32 : NMAX;
   static constexpr int NR = NMAX / 4;
-  static constexpr int NRP = 8;                        // class chunk of a Jacobian row, padded for 16-byte reads
-  static constexpr int XT = 0;                         // NMAX x 16 floats: X[12], fbeg, fend, pad, pad
-  static constexpr int FO = XT + NMAX * 64;            // 16 frames x 4 floats
+  static constexpr int NRP = NR <= 4 ? 4 : 8;          // class chunk of a Jacobian row, padded for 16-byte reads
+  static constexpr int XT = 0;                         // NJ x 16 floats: X[12], fbeg | fend << 8, var + 1, vmul, off
+  static constexpr int FO = XT + NJ * 64;              // 16 frames x 4 floats
   static constexpr int CH = FO + 256;                  // 16 x 16 chain bytes
-  static constexpr int SLOT0 = CH + 256;
+  static constexpr int PL = CH + 256;                  // MIMIC: second-order pair list, 128 words + 17 lane offsets
+  static constexpr int SLOT0 = PL + (MIMIC ? 512 + 32 : 0);
   // per frame slot
   static constexpr int P = 0;                          // 16 frames x 3 doubles
-  static constexpr int AX = P + 384;                   // NMAX x 4 floats
-  static constexpr int OG = AX + NMAX * 16;            // NMAX x 4 floats
-  static constexpr int XV = OG + NMAX * 16;            // NMAX floats: joint values of the trial point
-  static constexpr int GV = XV + NMAX * 4;             // NMAX floats: gradient
-  static constexpr int CF = GV + NMAX * 4;             // NMAX x 4 floats: second-order vectors
-  static constexpr int TB = CF + NMAX * 16;            // 16 terms x 16 floats
+  static constexpr int AX = P + 384;                   // NJ x 4 floats
+  static constexpr int OG = AX + NJ * 16;              // NJ x 4 floats
+  static constexpr int XV = OG + NJ * 16;              // NJ floats: joint values of the trial point (MIMIC: variables)
+  static constexpr int QJ = XV + NJ * 4;               // MIMIC: NJ floats, values of the fixed joints of the frame
+  static constexpr int GV = QJ + (MIMIC ? NJ * 4 : 0); // NMAX floats: gradient
+  static constexpr int CF = GV + NMAX * 4;             // NJ x 4 floats: second-order vectors
+  static constexpr int TB = CF + NJ * 16;              // 16 terms x 16 floats (MIMIC: reused for the second-order sums)
   static constexpr int JR = TB + 1024;                 // 4 rows x 4 classes x NRP floats
   static constexpr int SLOT = JR + 4 * 4 * NRP * 4;
   static constexpr int WAVE = SLOT0 + 4 * SLOT;
 };
 
-template <int NMAX>
+template <int NMAX, bool MIMIC>
 __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const KernelParams kp, const dexr_comp_table* __restrict__ comps,
                                                                          const WideTable* __restrict__ wtabs) {
   static_assert(NMAX == 16 || NMAX == 24 || NMAX == 32, "bucket");
-  using L = WideLds<NMAX>;
+  static_assert(!MIMIC || NMAX == 16, "the variable grid of the mimic kernel has 16 rows");
+  using L = WideLds<NMAX, MIMIC>;
+  constexpr int NJ = L::NJ;
   constexpr int NR = NMAX / 4;
   constexpr int NRP = L::NRP;
-  constexpr int NJ2 = NMAX > 16 ? 2 : 1;  // joints owned per lane (l and l + 16)
+  constexpr int NJ2 = NMAX > 16 ? 2 : 1;  // grid indices owned per lane (l and l + 16): joints, with MIMIC variables
+  constexpr int NFS = 2;                  // MIMIC: joint slots per lane (l, l + 16) for the fixed joints' values
+  constexpr int FAM = 3;                  // MIMIC: joints per variable (the variable's own joint + its mimic followers)
+  // Optional damping dynamics of dexr_red.hpp: a non-positive pivot is reflected instead of failing the pass, such a
+  // step is judged by the decrease alone and stretched towards the trust radius, and a rejection raises lambda to
+  // lam_jump x mean diag(H).  Measured (65 536 frames): shorter iteration tails for DexPilot models with mimic joints
+  // (Inspire 1.35-1.48 -> 0.86-0.99 ms), longer ones for position models (Inspire 1.24-1.36 -> 1.66-1.78 ms) and for the
+  // joint-space models (Shadow DexPilot, round 2) -- hence a launch parameter (dexr_tuning.pivot_rule).
+  const bool MODCHOL = kp.modchol != 0;  // (wave-uniform)
 
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63;
@@ -126,11 +141,14 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   float* XT = reinterpret_cast<float*>(wbase + L::XT);
   float* FO = reinterpret_cast<float*>(wbase + L::FO);
   unsigned char* CH = wbase + L::CH;
+  uint32_t* PLw = reinterpret_cast<uint32_t*>(wbase + L::PL);
+  unsigned char* POFF = wbase + L::PL + 512;
   unsigned char* sbase = wbase + L::SLOT0 + (size_t)slot * L::SLOT;
   double* Pl = reinterpret_cast<double*>(sbase + L::P);
   float* AXl = reinterpret_cast<float*>(sbase + L::AX);
   float* OGl = reinterpret_cast<float*>(sbase + L::OG);
   float* XVl = reinterpret_cast<float*>(sbase + L::XV);
+  float* QJl = reinterpret_cast<float*>(sbase + L::QJ);
   float* GVl = reinterpret_cast<float*>(sbase + L::GV);
   float* CFl = reinterpret_cast<float*>(sbase + L::CF);
   float* TBl = reinterpret_cast<float*>(sbase + L::TB);
@@ -139,6 +157,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   const dexr_comp_table& tb = comps[comp];
   const WideTable& wt = wtabs[comp];
   const int nj = tb.n_joint, nt = tb.n_term;
+  const int ng = MIMIC ? tb.n_var : nj;  // rows of the Hessian grid in use
   const int depth = wt.depth;
   const float delta = kp.norm_delta;
   const int64_t nB = kp.bucket ? (int64_t)kp.bucket[1] : kp.B;
@@ -148,14 +167,18 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   const bool seq = kp.T > 0;
 
   // ---- wave-constant tables into LDS (lane-varying joint indices read them in the kinematics) ----------------------
-  for (int k = lane; k < NMAX; k += 64) {
+  for (int k = lane; k < NJ; k += 64) {
     const bool in = k < nj;
 #pragma unroll
     for (int i = 0; i < 12; ++i) XT[k * 16 + i] = in ? tb.X[k][i] : 0.f;
-    XT[k * 16 + 12] = __int_as_float(in ? tb.fbeg[k] : 0);
-    XT[k * 16 + 13] = __int_as_float(in ? tb.fend[k] : 0);
-    XT[k * 16 + 14] = 0.f;
-    XT[k * 16 + 15] = 0.f;
+    XT[k * 16 + 12] = __int_as_float(in ? (tb.fbeg[k] | (tb.fend[k] << 8)) : 0);
+    XT[k * 16 + 13] = __int_as_float((in && MIMIC) ? tb.var[k] + 1 : 0);  // 0: not driven by a variable (fixed joint)
+    XT[k * 16 + 14] = (in && MIMIC) ? tb.vmul[k] : 0.f;
+    XT[k * 16 + 15] = (in && MIMIC) ? tb.off[k] : 0.f;
+  }
+  if (MIMIC) {
+    for (int i = lane; i < 128; i += 64) PLw[i] = wt.pair[i];
+    for (int i = lane; i < 32; i += 64) POFF[i] = i < 17 ? wt.pair_off[i] : 0;
   }
   for (int f = lane; f < 16; f += 64) {
     const bool in = f < tb.n_frame;
@@ -167,7 +190,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 
   uint32_t optmask = 0, revmask = 0;
 #pragma unroll
-  for (int k = 0; k < NMAX; ++k) {
+  for (int k = 0; k < NJ; ++k) {
     if (k < nj && tb.src_kind[k] == DEXR_SRC_OPT) optmask |= 1u << k;
     if (k < nj && tb.jtype[k] == DEXR_JOINT_REVOLUTE) revmask |= 1u << k;
   }
@@ -179,12 +202,12 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   int japi[NJ2], jsrc[NJ2];
 #pragma unroll
   for (int s = 0; s < NJ2; ++s) {
-    const int k = l + 16 * s;
+    const int k = l + 16 * s;  // grid index: joint, with MIMIC variable
     jo_[s] = k;
-    jin[s] = k < nj;
-    const int kk = jin[s] ? k : 0;
+    jin[s] = k < ng;
+    const int kk = jin[s] ? (MIMIC ? tb.var_joint[k] : k) : 0;  // the joint whose box / api index apply
     jopt[s] = jin[s] && tb.src_kind[kk] == DEXR_SRC_OPT;
-    jfix[s] = jin[s] && tb.src_kind[kk] == DEXR_SRC_FIXED;
+    jfix[s] = !MIMIC && jin[s] && tb.src_kind[kk] == DEXR_SRC_FIXED;
     jrev[s] = jin[s] && tb.jtype[kk] == DEXR_JOINT_REVOLUTE;
     jlo[s] = tb.lo[kk];
     jhi[s] = tb.hi[kk];
@@ -195,7 +218,33 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   }
   uint32_t ancr[NR];  // revolute ancestors-or-self of row 4 i + a
 #pragma unroll
-  for (int i = 0; i < NR; ++i) ancr[i] = (4 * i + a < nj) ? wt.anc_rev[4 * i + a] : 0u;
+  for (int i = 0; i < NR; ++i) ancr[i] = (!MIMIC && 4 * i + a < nj) ? wt.anc_rev[4 * i + a] : 0u;
+  // MIMIC: the joints that move with this lane's variable (its own joint first) and their dq/dx; the fixed joints in
+  // this lane's joint slots (their values go to LDS once per frame)
+  int famk[FAM];
+  float famm[FAM];
+  bool fsfix[NFS];
+  float fsmul[NFS], fsoff[NFS];
+  int fssrc[NFS];
+  int fam_max = 0;  // wave-uniform: the largest family of the component
+  if (MIMIC) {
+#pragma unroll
+    for (int e = 0; e < FAM; ++e) {
+      const unsigned kb = wt.fam[l][e];
+      famk[e] = kb == 0xFFu ? -1 : (int)kb;
+      famm[e] = kb == 0xFFu ? 0.f : tb.vmul[kb];
+    }
+    fam_max = wt.fam_max;
+#pragma unroll
+    for (int s = 0; s < NFS; ++s) {
+      const int k = l + 16 * s;
+      fsfix[s] = k < nj && tb.src_kind[k < nj ? k : 0] == DEXR_SRC_FIXED;
+      const int kk = fsfix[s] ? k : 0;
+      fsmul[s] = tb.mult[kk];
+      fsoff[s] = tb.off[kk];
+      fssrc[s] = fsfix[s] ? tb.src_idx[kk] : 0;
+    }
+  }
 
   const bool per_coord = kp.kind == DEXR_KIND_POSITION;
   const double beta = (double)kp.huber_delta, ibeta = 1.0 / beta;
@@ -265,6 +314,11 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         xj[s] = jmul[s] * kp.fixed[irow * kp.n_fixed + jsrc[s]] + joff[s];
       }
       xacc[s] = xj[s];
+    }
+    if (MIMIC) {
+#pragma unroll
+      for (int s = 0; s < NFS; ++s)
+        if (fsfix[s]) QJl[l + 16 * s] = fsmul[s] * kp.fixed[irow * kp.n_fixed + fssrc[s]] + fsoff[s];
     }
     if (dexpilot) {  // projection bits (optimizer.py:466-476)
       const uint32_t st = (seq && t_seq > 0) ? nst : (kp.state ? kp.state[lrow] : 0u);
@@ -350,7 +404,13 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         for (int i = 0; i < 3; ++i)
 #pragma unroll
           for (int j = 0; j < 3; ++j) Rn[3 * i + j] = R[3 * i] * Xk[j] + R[3 * i + 1] * Xk[3 + j] + R[3 * i + 2] * Xk[6 + j];
-        const double q = (double)XVl[k];
+        double q;
+        if (MIMIC) {  // q = vmul * x[var] + off in float64 (a float32 product makes F a step function of x)
+          const int vc = __float_as_int(x3.y);
+          q = vc > 0 ? fma((double)x3.z, (double)XVl[vc > 0 ? vc - 1 : 0], (double)x3.w) : (double)QJl[k];
+        } else {
+          q = (double)XVl[k];
+        }
         if ((revmask >> k) & 1u) {
           double sn, cs;
           sincos_f64(q, &sn, &cs);
@@ -370,7 +430,8 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         if (cb & 0x80u) {  // this lane publishes the joint
           *reinterpret_cast<float4*>(AXl + k * 4) = make_float4((float)R[2], (float)R[5], (float)R[8], 0.f);
           *reinterpret_cast<float4*>(OGl + k * 4) = make_float4((float)pp[0], (float)pp[1], (float)pp[2], 0.f);
-          const int fb = __float_as_int(x3.x), fe = __float_as_int(x3.y);
+          const int fbe = __float_as_int(x3.x);
+          const int fb = fbe & 0xFF, fe = fbe >> 8;
           for (int f = fb; f < fe; ++f) {
             const float4 fo = *reinterpret_cast<const float4*>(FO + f * 4);
 #pragma unroll
@@ -449,16 +510,19 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     __builtin_amdgcn_wave_barrier();
 
     // (2) own joints' axes / origins; accumulators of the pass: data-term gradient and second-order vector
-    float jax[NJ2][3], jog[NJ2][3], jcf[NJ2][3];
+    constexpr int NCOL = MIMIC ? FAM : NJ2;  // joints whose columns this lane forms
+    float jax[NCOL][3], jog[NCOL][3], jcf[NCOL][3];
 #pragma unroll
-    for (int s = 0; s < NJ2; ++s) {
-      const float4 av = *reinterpret_cast<const float4*>(AXl + (jin[s] ? jo_[s] : 0) * 4);
-      const float4 ov = *reinterpret_cast<const float4*>(OGl + (jin[s] ? jo_[s] : 0) * 4);
+    for (int s = 0; s < NCOL; ++s) {
+      const int kj = MIMIC ? (famk[s] >= 0 ? famk[s] : 0) : (jin[s] ? jo_[s] : 0);
+      const float4 av = *reinterpret_cast<const float4*>(AXl + kj * 4);
+      const float4 ov = *reinterpret_cast<const float4*>(OGl + kj * 4);
       jax[s][0] = av.x; jax[s][1] = av.y; jax[s][2] = av.z;
       jog[s][0] = ov.x; jog[s][1] = ov.y; jog[s][2] = ov.z;
       jcf[s][0] = 0; jcf[s][1] = 0; jcf[s][2] = 0;
-      gnew[s] = 0;
     }
+#pragma unroll
+    for (int s = 0; s < NJ2; ++s) gnew[s] = 0;
 #pragma unroll
     for (int i = 0; i < NR; ++i)
 #pragma unroll
@@ -481,6 +545,42 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       const int ft = tb.term_task[t], fo = tb.term_origin[t];
       const uint32_t mt = tb.frame_anc[ft];
       const uint32_t mo = (fo >= 0) ? tb.frame_anc[fo] : 0u;
+      if (MIMIC) {
+        // the variable's column is the vmul-weighted sum over its joint family (kinematics_adaptor.py:102-113)
+        float c0 = 0, c1 = 0, c2 = 0;
+#pragma unroll
+        for (int e = 0; e < FAM; ++e) {
+          if (e < fam_max) {
+            const int k = famk[e] >= 0 ? famk[e] : 0;
+            const bool on = famk[e] >= 0;
+            const bool in_t = on && ((mt >> k) & 1u), in_o = on && ((mo >> k) & 1u);
+            float d0 = 0, d1 = 0, d2 = 0;
+            if (in_t || in_o) {
+              if ((revmask >> k) & 1u) {
+                float v0 = 0, v1 = 0, v2 = 0;
+                if (in_t) { v0 += t2.x - jog[e][0]; v1 += t2.y - jog[e][1]; v2 += t2.z - jog[e][2]; }
+                if (in_o) { v0 -= t3.x - jog[e][0]; v1 -= t3.y - jog[e][1]; v2 -= t3.z - jog[e][2]; }
+                d0 = jax[e][1] * v2 - jax[e][2] * v1;
+                d1 = jax[e][2] * v0 - jax[e][0] * v2;
+                d2 = jax[e][0] * v1 - jax[e][1] * v0;
+              } else {
+                const float sg = (in_t ? 1.f : 0.f) - (in_o ? 1.f : 0.f);
+                d0 = sg * jax[e][0]; d1 = sg * jax[e][1]; d2 = sg * jax[e][2];
+              }
+              jcf[e][0] += d1 * t1.z - d2 * t1.y;
+              jcf[e][1] += d2 * t1.x - d0 * t1.z;
+              jcf[e][2] += d0 * t1.y - d1 * t1.x;
+            }
+            c0 += famm[e] * d0; c1 += famm[e] * d1; c2 += famm[e] * d2;
+          }
+        }
+        gnew[0] += c0 * t1.x + c1 * t1.y + c2 * t1.z;
+        const int pos = (l & 3) * NRP + (l >> 2);
+        JRl[0 * 4 * NRP + pos] = c0 * t1.w;
+        JRl[1 * 4 * NRP + pos] = c1 * t2.w;
+        JRl[2 * 4 * NRP + pos] = c2 * t3.w;
+        if (!per_coord) JRl[3 * 4 * NRP + pos] = (c0 * t0.x + c1 * t0.y + c2 * t0.z) * t0.w;
+      } else {
 #pragma unroll
       for (int s = 0; s < NJ2; ++s) {
         const int k = jo_[s];
@@ -509,6 +609,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         JRl[1 * 4 * NRP + pos] = c1 * t2.w;
         JRl[2 * 4 * NRP + pos] = c2 * t3.w;
         if (!per_coord) JRl[3 * 4 * NRP + pos] = (c0 * t0.x + c1 * t0.y + c2 * t0.z) * t0.w;
+      }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -542,7 +643,46 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     }
 
     // (4) second-order kinematic term: H[r][c] += a_c . CF_r for every revolute ancestor-or-self c of r
-    if (newton) {
+    if (newton && MIMIC) {
+      // H[v][w] += sum over joint pairs (k in family v, j a revolute ancestor-or-self of k in family w) of
+      // m_k m_j a_j . CF_k (twice when both are followers of one variable): the host lists the pairs per owner lane of
+      // the target entry (dexr_api.hip: build_wide_tables), so a lane only adds into its own entries -- through private
+      // LDS slots, a register file has no run-time index
+#pragma unroll
+      for (int e = 0; e < FAM; ++e)
+        if (famk[e] >= 0) *reinterpret_cast<float4*>(CFl + famk[e] * 4) = make_float4(jcf[e][0], jcf[e][1], jcf[e][2], 0.f);
+      float* HBl = TBl + l * 12;  // the term block is free now
+      *reinterpret_cast<float4*>(HBl) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(HBl + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(HBl + 8) = make_float4(0.f, 0.f, 0.f, 0.f);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int p0 = POFF[l], p1 = POFF[l + 1];
+      const int pair_max = wt.pair_max;
+#pragma clang loop unroll(disable) vectorize(disable)
+      for (int it = 0; it < pair_max; ++it) {
+        const int pp = p0 + it;
+        if (pp < p1) {
+          const uint32_t w = PLw[pp];
+          const int k = (int)(w & 31u), j = (int)((w >> 5) & 31u), e = (int)((w >> 10) & 15u);
+          const float4 aj = *reinterpret_cast<const float4*>(AXl + j * 4);
+          const float4 cf = *reinterpret_cast<const float4*>(CFl + k * 4);
+          float val = XT[k * 16 + 14] * XT[j * 16 + 14] * (aj.x * cf.x + aj.y * cf.y + aj.z * cf.z);
+          if ((w >> 14) & 1u) val += val;
+          HBl[e] += val;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+          const float add = HBl[i * (i + 1) / 2 + j];
+          if (j & 1) Hn[i][j / 2].y += add; else Hn[i][j / 2].x += add;
+        }
+    }
+    if (newton && !MIMIC) {
 #pragma unroll
       for (int s = 0; s < NJ2; ++s)
         if (jin[s]) *reinterpret_cast<float4*>(CFl + jo_[s] * 4) = make_float4(jcf[s][0], jcf[s][1], jcf[s][2], 0.f);
@@ -567,8 +707,17 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 
   // ---- distributed Cholesky + triangular solves of (H_acc restricted to the free set + damping) d = -g -------------
   float dstep[NJ2];  // own joints' entries of the step
+  float hdmean = 0.f;  // mean diagonal of the free block of the accepted Hessian (MODCHOL: scale of the damping jump)
   auto factor_and_solve = [&](uint32_t freemask, float lam) -> bool {
     bool ok = true;
+    if (MODCHOL) {
+      float hds = 0.f;
+#pragma unroll
+      for (int i = 0; i < NR; ++i)
+        if (a == b && ((freemask >> (4 * i + a)) & 1u)) hds += (i & 1) ? Ha[i][i / 2].y : Ha[i][i / 2].x;
+      const int nfree = __popc(freemask);
+      hdmean = row_sum(hds) / (float)(nfree > 0 ? nfree : 1);
+    }
     wv2 Hw[NR][NP];
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
@@ -596,7 +745,11 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       const float own_d = hw_get(jo, jo);
       const float qd = ja == 0 ? wquad_bcast<0>(own_d) : ja == 1 ? wquad_bcast<1>(own_d) : ja == 2 ? wquad_bcast<2>(own_d) : wquad_bcast<3>(own_d);
       float dj = stride4_sum(a == ja ? qd : 0.f);
-      if (!(dj > 1e-30f)) { ok = false; dj = 1.f; }
+      if (MODCHOL) {
+        if (!(dj > 1e-6f * (2.f * delta + lam))) { ok = false; dj = fmaxf(fabsf(dj), 2.f * delta + lam); }
+      } else {
+        if (!(dj > 1e-30f)) { ok = false; dj = 1.f; }
+      }
       const float iv = __frsqrt_rn(dj);
       ivr[jo] = (a == ja) ? iv : ivr[jo];
       ivc[jo] = (b == ja) ? iv : ivc[jo];
@@ -737,7 +890,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         const double noise = (double)kp.floor_scale * fabs(F);
         const bool finite = (Fe == Fe) && (smax == smax) && (fabs(Fe) < 1e30);
         const bool below_floor = ok && finite && ((double)pred <= noise) && (smax < 1e-2f);
-        const bool accept = ok && finite && ((Fe <= F) || below_floor);
+        const bool accept = (ok || MODCHOL) && finite && ((Fe <= F) || below_floor);
         ++my_iters;
         pending = false;
         if (accept) {
@@ -761,7 +914,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
           }
         } else {
           lam = fmaxf(lam, 1e-6f) * nu;
-          if (kp.lam_jump > 0) lam = fmaxf(lam, kp.lam_jump * keff);
+          if (kp.lam_jump > 0) lam = fmaxf(lam, kp.lam_jump * (MODCHOL ? hdmean : keff));
           nu *= 2.f;
 #pragma unroll
           for (int s = 0; s < NJ2; ++s) xj[s] = xacc[s];
@@ -769,7 +922,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
             done = true;
             status = finite ? ST_CONVERGED : ST_FALLBACK;
           }
-          if (ok && finite && smax < kp.tol) {
+          if ((ok || MODCHOL) && finite && smax < kp.tol) {
             done = true;
             status = ST_CONVERGED;
           }
@@ -820,7 +973,9 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
           ddl += dstep[s] * dstep[s];
         }
       const float dmax = row_max(dmaxl), gd = row_sum(gdl), dd = row_sum(ddl);
-      const float alpha = (kp.step_cap > 0 && dmax > kp.step_cap) ? kp.step_cap / dmax : 1.f;
+      // (MODCHOL: a step from a modified factorisation is stretched towards the trust radius, at most 8 x)
+      const float alpha = (kp.step_cap > 0 && (dmax > kp.step_cap || (MODCHOL && !okf && dmax > 0.f)))
+                              ? fminf(kp.step_cap / dmax, MODCHOL ? 8.f : 1e30f) : 1.f;
       pred = alpha * (1.f - 0.5f * alpha) * gd + 0.5f * alpha * alpha * lam * dd;
       keff = gd / fmaxf(dd, 1e-30f);
       float sl = 0.f;

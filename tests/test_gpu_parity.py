@@ -557,7 +557,7 @@ def test_strict_option_polishes_mixed_precision_answers():
     ref = np.ascontiguousarray(cases.ref_from_keypoints(prob, kp), dtype=np.float32)
     mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
     model = opt.device_model()
-    assert model.kernel()[0] == _lib.KERNEL_REDUCED
+    assert model.kernel()[0] in (_lib.KERNEL_REDUCED, _lib.KERNEL_WIDE)
     last = model.retarget(ref[:-1], None, mid)
     q64 = model.retarget_f64(ref[1:], None, last)
     dq = {}
@@ -927,6 +927,50 @@ def test_sixteen_lane_and_four_lane_kernels_agree(rel):
     assert np.percentile(dq, 95) < 2e-5, np.percentile(dq, [50, 95, 99])
 
 
-def test_mimic_models_keep_the_reduced_variable_kernel():
+def test_kernel_policy_for_models_with_mimic_joints():
+    """DexPilot / position models with mimic joints run the sixteen-lane kernel on the grid of their optimised variables;
+    the SVH vector model (two small components) keeps the reduced-variable kernel; per-finger vector models the register
+    kernels."""
     seq, _ = build("teleop/schunk_svh_hand_right_dexpilot.yml")
+    assert seq.optimizer.device_model().kernel()[0] == _lib.KERNEL_WIDE
+    seq, _ = build("offline/inspire_hand_left.yml")
+    assert seq.optimizer.device_model().kernel()[0] == _lib.KERNEL_WIDE
+    seq, _ = build("teleop/schunk_svh_hand_right.yml")
     assert seq.optimizer.device_model().kernel()[0] == _lib.KERNEL_REDUCED
+    seq, _ = build("teleop/ability_hand_right.yml")
+    assert seq.optimizer.device_model().kernel()[0] == _lib.KERNEL_REGISTER
+
+
+@pytest.mark.parametrize("rel", ["teleop/schunk_svh_hand_right_dexpilot.yml", "offline/inspire_hand_left.yml",
+                                 "teleop/ability_hand_right_dexpilot.yml"])
+def test_sixteen_lane_variable_grid_agrees_with_the_reduced_variable_kernel(rel):
+    """Mimic joints folded into their source's column (kinematics_adaptor.py:102-113): the sixteen-lane kernel on the
+    variable grid and dexr_red_kernel minimise the same function; both pivot rules of the former reach the same
+    minimiser on all but a few frames."""
+    seq, prob = build(rel)
+    model = seq.optimizer.device_model()
+    B = 4096
+    kp = np.ascontiguousarray(cases.human_keypoints(B + 1, seed=cases.SEED))
+    mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
+    dex = prob.kind == "dexpilot"
+
+    def run(kpts, start, **tune):
+        model.tune(**tune)
+        st = np.zeros(B, np.uint32) if dex else None
+        return model.retarget(kpts, None, start, state=st, keypoints=True, want_info=True)
+
+    last, _ = run(kp[:-1], mid, kernel=_lib.KERNEL_REDUCED)
+    qr, ir = run(kp[1:], last, kernel=_lib.KERNEL_REDUCED)
+    assert model.kernel()[0] == _lib.KERNEL_REDUCED
+    res = {}
+    for rule in (0, 1):
+        q, info = run(kp[1:], last, kernel=_lib.KERNEL_WIDE, pivot_rule=rule)
+        assert model.kernel()[0] == _lib.KERNEL_WIDE
+        assert (info["status"] == 0).all()
+        dq = np.abs(q.astype(np.float64) - qr).max(1)
+        assert (dq > 1e-4).mean() < 0.02, (rule, (dq > 1e-4).sum())
+        assert np.percentile(dq, 95) < 2e-5, (rule, np.percentile(dq, [50, 95, 99]))
+        res[rule] = q
+    q2, _ = run(kp[1:], last, kernel=_lib.KERNEL_WIDE, pivot_rule=1)
+    assert np.array_equal(q2, res[1])
+    model.tune(kernel=_lib.KERNEL_AUTO, pivot_rule=-1)
