@@ -103,10 +103,11 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         objs.append(o)
         if force or _stale(o, [wide_s, os.path.join(CSRC, "dexr_wide.hpp"), BIG_HEADER] + HEADERS):
             jobs.append((wide_s, o, NO_SLP + [f"-DDEXR_NMAX={n}"]))
-    o = os.path.join(BUILD, "dexr_wide_m_16.o")  # the same kernel on the grid of the optimised variables (mimic joints)
-    objs.append(o)
-    if force or _stale(o, [wide_s, os.path.join(CSRC, "dexr_wide.hpp"), BIG_HEADER] + HEADERS):
-        jobs.append((wide_s, o, NO_SLP + ["-DDEXR_NMAX=16", "-DDEXR_MIMIC=1"]))
+    for tag, defs in (("m", []), ("mc", ["-DDEXR_MODCHOL=1"])):  # the same kernel on the grid of the optimised variables
+        o = os.path.join(BUILD, f"dexr_wide_{tag}_16.o")         # (mimic joints), plain / modified Cholesky
+        objs.append(o)
+        if force or _stale(o, [wide_s, os.path.join(CSRC, "dexr_wide.hpp"), BIG_HEADER] + HEADERS):
+            jobs.append((wide_s, o, NO_SLP + ["-DDEXR_NMAX=16", "-DDEXR_MIMIC=1"] + defs))
     red_s = os.path.join(CSRC, "dexr_red_inst.hip")
     for nvb in (8, 16):  # reduced-variable kernel (mimic models): Hessian of the variables in registers
         o = os.path.join(BUILD, f"dexr_red_{nvb}.o")

@@ -96,7 +96,6 @@ void fill_params(const dexr_model* m, dexr::KernelParams& kp, int64_t B) {
   // curvature instead of creeping up by x2, x4, ...; small components also drop it by 10x (not 3x) after a step the
   // model predicted well.  Allegro vector, 65 536 frames: 0.143 -> 0.119 ms; Shadow DexPilot: 19.4 -> 15.4 ms.
   kp.lam_jump = m->tune.lam_jump;
-  kp.modchol = m->wide_modchol ? 1 : 0;
   kp.lam_fastdec = m->tune.lam_fastdec;
   kp.floor_scale = m->tune.floor_scale;
   kp.step_cap = m->tune.step_cap;
@@ -224,7 +223,8 @@ int launch_wide(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
   kp.queue = m->d_queue + (size_t)slot * kp.n_comp;
   hipError_t qe = hipMemsetAsync(kp.queue, 0, (size_t)kp.n_comp * sizeof(unsigned), st);
   if (qe != hipSuccess) return fail(DEXR_ERR_HIP, "queue reset failed: %s", hipGetErrorString(qe));
-  dexr::wide_launch_fn fn = m->wide_mimic ? dexr::launch_wide_m_16 : dexr::find_wide_launcher(m->bucket);
+  dexr::wide_launch_fn fn = m->wide_mimic ? (m->wide_modchol ? dexr::launch_wide_mc_16 : dexr::launch_wide_m_16)
+                                          : dexr::find_wide_launcher(m->bucket);
   if (!fn) return fail(DEXR_ERR_UNSUPPORTED, "no sixteen-lane kernel for bucket %d", m->bucket);
   hipError_t e = fn(kp, m->d_wide, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, st);
   if (e != hipSuccess) return fail(DEXR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
@@ -435,7 +435,8 @@ void select_kernels(dexr_model* m) {
   m->wide = m->wide_ok && (want == DEXR_KERNEL_WIDE || want == DEXR_KERNEL_AUTO);
   // mimic vector models (SVH: two small components) stay on the reduced-variable kernel: 0.7-0.8 vs 0.9-1.1 ms
   if (m->wide && m->has_mimic && want == DEXR_KERNEL_AUTO && h.kind == DEXR_KIND_VECTOR && red_ok) m->wide = false;
-  m->wide_modchol = m->wide && (m->tune.pivot_rule > 0 || (m->tune.pivot_rule < 0 && m->wide_mimic && h.kind == DEXR_KIND_DEXPILOT));
+  // (the modified-Cholesky rules are instantiated for the variable-grid kernel only)
+  m->wide_modchol = m->wide && m->wide_mimic && (m->tune.pivot_rule > 0 || (m->tune.pivot_rule < 0 && h.kind == DEXR_KIND_DEXPILOT));
   m->red = m->red && !m->wide;
   m->quad = !m->wide && !m->red && quad_ok && (want == DEXR_KERNEL_QUAD || (want == DEXR_KERNEL_AUTO && quad_wins));
   m->big = !m->wide && !m->red && !m->quad && big_ok && (want == DEXR_KERNEL_LDS || (want == DEXR_KERNEL_AUTO && big_wins));

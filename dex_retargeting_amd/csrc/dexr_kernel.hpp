@@ -62,7 +62,6 @@ struct KernelParams {
   int32_t stall_from;             // termination at the float rounding floor (see "stalled" in the kernels): from this
   float stall_ratio;              // many unverifiable ("blind") steps on, a step that is not < stall_ratio x the
   float stall_cap;                // previous one and is < stall_cap x tol ends the solve
-  int32_t modchol;                // dexr_wide_kernel: modified Cholesky + its damping rules (dexr_tuning.pivot_rule)
   uint32_t q0;                    // queue mode: frames [0, q0) are handed out statically (wave w starts with tile w),
                                   // the queue counter numbers the frames from q0 on
   uint32_t qchunk;                // frames a wave takes from its component's queue per atomicAdd; 0 = tile mode

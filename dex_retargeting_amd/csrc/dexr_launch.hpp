@@ -54,7 +54,9 @@ hipError_t launch_wide_16(const KernelParams&, const WideTable*, dim3, dim3, siz
 hipError_t launch_wide_24(const KernelParams&, const WideTable*, dim3, dim3, size_t, hipStream_t);
 hipError_t launch_wide_32(const KernelParams&, const WideTable*, dim3, dim3, size_t, hipStream_t);
 hipError_t launch_wide_m_16(const KernelParams&, const WideTable*, dim3, dim3, size_t, hipStream_t);  // mimic joints folded
+hipError_t launch_wide_mc_16(const KernelParams&, const WideTable*, dim3, dim3, size_t, hipStream_t);  // + modified Cholesky
 size_t wide_lds_per_wave_m_16();
+size_t wide_lds_per_wave_mc_16();
 size_t wide_lds_per_wave_16();
 size_t wide_lds_per_wave_24();
 size_t wide_lds_per_wave_32();

@@ -106,7 +106,7 @@ struct WideLds {
   static constexpr int WAVE = SLOT0 + 4 * SLOT;
 };
 
-template <int NMAX, bool MIMIC>
+template <int NMAX, bool MIMIC, bool MODCHOL>
 __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const KernelParams kp, const dexr_comp_table* __restrict__ comps,
                                                                          const WideTable* __restrict__ wtabs) {
   static_assert(NMAX == 16 || NMAX == 24 || NMAX == 32, "bucket");
@@ -122,8 +122,8 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   // step is judged by the decrease alone and stretched towards the trust radius, and a rejection raises lambda to
   // lam_jump x mean diag(H).  Measured (65 536 frames): shorter iteration tails for DexPilot models with mimic joints
   // (Inspire 1.35-1.48 -> 0.86-0.99 ms), longer ones for position models (Inspire 1.24-1.36 -> 1.66-1.78 ms) and for the
-  // joint-space models (Shadow DexPilot, round 2) -- hence a launch parameter (dexr_tuning.pivot_rule).
-  const bool MODCHOL = kp.modchol != 0;  // (wave-uniform)
+  // joint-space models (Shadow DexPilot, round 2) -- hence a choice per model (dexr_tuning.pivot_rule; instantiated for the
+  // variable-grid kernel only: as a run-time flag it cost the joint-space kernels 56 more spilled registers).
 
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63;

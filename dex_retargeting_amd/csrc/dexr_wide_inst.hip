@@ -1,5 +1,6 @@
 // dexr_wide_inst.hip -- instantiation of the sixteen-lanes-per-frame solve kernel (dexr_wide.hpp) for one joint bucket.
-// Compile with -DDEXR_NMAX=<16|24|32> [-DDEXR_MIMIC=1: grid of the optimised variables, mimic joints folded (NMAX 16)].
+// Compile with -DDEXR_NMAX=<16|24|32> [-DDEXR_MIMIC=1: grid of the optimised variables, mimic joints folded (NMAX 16);
+// -DDEXR_MODCHOL=1 with it: modified Cholesky and its damping rules].
 #include "dexr_wide.hpp"
 #include "dexr_launch.hpp"
 
@@ -12,7 +13,12 @@
 #endif
 
 namespace dexr {
-#if DEXR_MIMIC
+#ifndef DEXR_MODCHOL
+#define DEXR_MODCHOL 0
+#endif
+#if DEXR_MIMIC && DEXR_MODCHOL
+#define DEXR_WNAME(base) base##mc_16
+#elif DEXR_MIMIC
 #define DEXR_WNAME(base) base##m_16
 #else
 #define DEXR_WNAME(base) DEXR_WCAT(base, DEXR_NMAX)
@@ -23,12 +29,12 @@ namespace dexr {
 hipError_t DEXR_WNAME(launch_wide_)(const KernelParams& kp, const WideTable* wt, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   static size_t configured = 0;  // dynamic LDS above 64 KB has to be requested once per kernel
   if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dexr_wide_kernel<DEXR_NMAX, (DEXR_MIMIC != 0)>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dexr_wide_kernel<DEXR_NMAX, (DEXR_MIMIC != 0), (DEXR_MODCHOL != 0)>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     configured = lds;
   }
-  hipLaunchKernelGGL((dexr_wide_kernel<DEXR_NMAX, (DEXR_MIMIC != 0)>), grid, block, lds, st, kp, kp.comps, wt);
+  hipLaunchKernelGGL((dexr_wide_kernel<DEXR_NMAX, (DEXR_MIMIC != 0), (DEXR_MODCHOL != 0)>), grid, block, lds, st, kp, kp.comps, wt);
   return hipGetLastError();
 }
 size_t DEXR_WNAME(wide_lds_per_wave_)() { return (size_t)WideLds<DEXR_NMAX, (DEXR_MIMIC != 0)>::WAVE; }

@@ -83,7 +83,7 @@ typedef struct dexr_tuning {
   float floor_scale;    /* mixed-precision kernels: value differences below floor_scale x |F| are unverifiable    */
   float step_cap;       /* trust radius per joint [rad|m] (0: off)                                                */
   float blind_tol_scale; /* a verified undamped Newton step shorter than blind_tol_scale x tol ends the solve (10) */
-  int32_t pivot_rule;   /* sixteen-lane kernel: 0 plain Cholesky (a non-positive pivot fails the pass; lam_jump scales
+  int32_t pivot_rule;   /* sixteen-lane kernel on the variable grid (models with mimic joints): 0 plain Cholesky (a non-positive pivot fails the pass; lam_jump scales
                            the Rayleigh quotient of the failed step), 1 modified Cholesky (the pivot is reflected, the
                            step judged by the decrease and stretched to the trust radius; lam_jump scales mean diag H),
                            -1 measured policy (1 for DexPilot models with mimic joints)                             */

@@ -10,6 +10,7 @@ import numpy as np
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tools"))
 import torch  # noqa: E402
 
 import bench_data  # noqa: E402
@@ -27,6 +28,10 @@ model = seq.optimizer.device_model()
 if kernel != "auto":
     model.tune(kernel={"register": _lib.KERNEL_REGISTER, "quad": _lib.KERNEL_QUAD, "lds": _lib.KERNEL_LDS,
                        "reduced": _lib.KERNEL_REDUCED, "wide": _lib.KERNEL_WIDE}[kernel])
+if os.environ.get("DEXR_TOOL_KNOBS"):  # e.g. DEXR_TOOL_KNOBS="pivot_rule=1,lam_jump=0.3" (tools only; the library reads no environment)
+    import _tune
+
+    _tune.apply(model, dict(kv.split("=") for kv in os.environ["DEXR_TOOL_KNOBS"].split(",")))
 dex = seq.optimizer.retargeting_type == "DEXPILOT"
 kp = bench_data.human_keypoints(B + 1)
 mid = np.repeat(seq.joint_limits.mean(1)[None], B, 0).astype(np.float32)
