@@ -59,6 +59,16 @@ struct dexr_model {
   bool wide_ok = false;  // the model fits that kernel (<= 16 root-to-leaf chains of <= 16 joints; with mimic joints:
                          // <= 16 variables moving <= 3 joints each)
   bool wide_mimic = false;  // ... through its variable-grid instantiation (mimic joints folded)
+  // longest-first ordering (launch_wide): LSLOTS workspaces handed out round-robin; a slot's last use is fenced by an
+  // event, so launches on different streams never share one
+  static constexpr int LSLOTS = 4;
+  struct LptSlot {
+    void* buf = nullptr;
+    size_t bytes = 0;
+    hipEvent_t done = nullptr;
+  };
+  mutable LptSlot lpt[LSLOTS];
+  mutable std::atomic<unsigned> lnext{0};
   bool wide_modchol = false;  // ... with modified Cholesky and the damping rules that go with it (tune.pivot_rule)
   std::vector<dexr::WideTable> wide_tabs;
   dexr::WideTable* d_wide = nullptr;
@@ -205,8 +215,13 @@ int launch_quad(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
   return DEXR_OK;
 }
 
+}  // namespace
+size_t dexr_fleet_ws_ints();
+hipError_t dexr_lpt_order_launch(int64_t B, const float* f0, const float* sum, float ratio, int32_t* key, int32_t* ws, hipStream_t st);
+namespace {
+
 // sixteen lanes per frame: four frames per wave, two waves per SIMD resident; persistent rows fed like the quads
-int launch_wide(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
+int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
   const size_t per_wave = m->wide_mimic ? dexr::wide_lds_per_wave_m_16() : dexr::wide_lds_per_wave(m->bucket);
   int wpb = 4;
   while (wpb > 1 && per_wave * wpb > 80 * 1024) wpb >>= 1;
@@ -229,6 +244,64 @@ int launch_wide(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
   hipError_t e = fn(kp, m->d_wide, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, st);
   if (e != hipSuccess) return fail(DEXR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
   return DEXR_OK;
+}
+
+// LONGEST-FIRST ORDERING.  A launch over many more frames than the GPU holds at once (2 waves x 4 frames per SIMD) is
+// bound by slow frames the queue hands out late: Shadow DexPilot, 65 536 frames = 1.08 ms of throughput + 0.83 ms of
+// tail.  For DexPilot models the objective at the start point predicts the slow frames (top 5 %
+// by F(x0): 91 % of the frames with >= 15 iterations), so: (1) a screening launch of the same kernel evaluates F(x0)
+// (kinematics + terms, ~15 % of one solver pass per frame) and sums it, (2) frames above 1.3 x the batch mean get key 0,
+// the rest key 1, (3) the fleet bucketing kernels turn the keys into an index list, (4) the solve launch walks that
+// list.  Everything is stream-ordered on the caller's stream; the workspace is one of LSLOTS per-model buffers.
+// MEASURED (65 536 frames): with the frames sorted by their true iteration counts (a perfect predictor, tools/
+// prof_config.py DEXR_TOOL_LPT) Shadow DexPilot 1.87 -> 1.35-1.48 ms and LEAP DexPilot 1.21 -> 0.84-0.91 ms; with this
+// predictor the screening + ordering launches cost 0.15-0.25 ms and the frames it misses still run 20-34 passes:
+// Shadow 1.91 -> 2.04 ms, LEAP 1.23 -> 1.53 ms at ratio 2.  Hence opt-in (dexr_tuning.longest_first = 1), off by default;
+// position models have no usable predictor at all (F(x0), |g|, first step, curvature: <= 45 % of the slow frames in the
+// top 20 %).
+int launch_wide(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
+  const int want = m->tune.longest_first;
+  const int64_t in_flight = (int64_t)m->n_cu * 4 * 2 * 4;
+  const bool plain = !kp.perm && !kp.bucket && kp.T == 0 && kp.n_comp == 1;
+  (void)in_flight;
+  const bool on = plain && want > 0;  // measured: not a win by default (see below), opt-in only
+  if (!on) return launch_wide_once(m, kp, st);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+    return launch_wide_once(m, kp, st);  // graph capture: no allocation / cross-stream fencing inside a captured region
+  const size_t B = (size_t)kp.B;
+  const size_t ws_ints = dexr_fleet_ws_ints() + B;
+  const size_t bytes = 256 + B * sizeof(float) + B * sizeof(int32_t) + ws_ints * sizeof(int32_t);
+  dexr_model::LptSlot& sl = m->lpt[m->lnext.fetch_add(1u) % dexr_model::LSLOTS];
+  if (!sl.done) HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  else HIP_TRY(hipStreamWaitEvent(st, sl.done, 0));  // the slot's previous user (possibly another stream) has finished
+  if (sl.bytes < bytes) {
+    if (sl.buf) {
+      HIP_TRY(hipEventSynchronize(sl.done));
+      HIP_TRY(hipFree(sl.buf));
+      sl.buf = nullptr;
+      sl.bytes = 0;
+    }
+    HIP_TRY(hipMalloc(&sl.buf, bytes));
+    sl.bytes = bytes;
+  }
+  unsigned char* base = static_cast<unsigned char*>(sl.buf);
+  float* sum = reinterpret_cast<float*>(base);
+  float* f0 = reinterpret_cast<float*>(base + 256);
+  int32_t* key = reinterpret_cast<int32_t*>(base + 256 + B * sizeof(float));
+  int32_t* ws = key + B;
+  HIP_TRY(hipMemsetAsync(sum, 0, 256, st));
+  dexr::KernelParams ks = kp;
+  ks.screen = f0;
+  ks.screen_sum = sum;
+  int rc = launch_wide_once(m, ks, st);
+  if (rc != DEXR_OK) return rc;
+  hipError_t e = dexr_lpt_order_launch(kp.B, f0, sum, 1.3f, key, ws, st);
+  if (e != hipSuccess) return fail(DEXR_ERR_HIP, "ordering kernels failed: %s", hipGetErrorString(e));
+  kp.perm = ws + dexr_fleet_ws_ints();
+  rc = launch_wide_once(m, kp, st);
+  HIP_TRY(hipEventRecord(sl.done, st));
+  return rc;
 }
 
 // Root-to-leaf chains of every component's kinematic tree (one per lane of a 16-lane row) and the revolute ancestors
@@ -403,6 +476,7 @@ void default_tuning(dexr_model* m) {
   // (tools/lm_lab.py: max 8.6e-7 over 1 863 frames) and saves the confirming pass: mean 4.3 -> 3.9 passes per frame
   t.blind_tol_scale = m->bucket <= 8 ? 100.f : 10.f;
   t.pivot_rule = -1;
+  t.longest_first = -1;
 }
 
 // Which float32 solve kernel serves the model.  Measured on MI355X (65 536 frames, tools/all_configs.py,
@@ -509,6 +583,7 @@ int dexr_prep_launch(int64_t B, const float* kp, const float* op9, float* out, f
 // dexr_aux.hip
 size_t dexr_fleet_ws_ints();
 hipError_t dexr_fleet_bucket_launch(int n_models, int64_t B, const int32_t* model_id, int32_t* ws, hipStream_t st);
+hipError_t dexr_lpt_order_launch(int64_t B, const float* f0, const float* sum, float ratio, int32_t* key, int32_t* ws, hipStream_t st);
 hipError_t dexr_seq_compose_launch(int64_t B, int T, int n_q, int n_opt, int n_fixed, const int32_t* kind,
                                    const int32_t* idx, const double* mult, const double* off, const float* qraw,
                                    const float* fixed, double alpha, int use_filter, int first_frame_initialises,
@@ -652,6 +727,10 @@ void dexr_model_destroy(dexr_model* m) {
   if (m->d_comps) (void)hipFree(m->d_comps);
   if (m->d_queue) (void)hipFree(m->d_queue);
   if (m->d_wide) (void)hipFree(m->d_wide);
+  for (dexr_model::LptSlot& sl : m->lpt) {
+    if (sl.buf) (void)hipFree(sl.buf);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+  }
   delete m;
 }
 
@@ -680,6 +759,7 @@ int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning) {
   t.struct_size = (uint32_t)sizeof(dexr_tuning);
   if (t.kernel < DEXR_KERNEL_AUTO || t.kernel > DEXR_KERNEL_WIDE) return fail(DEXR_ERR_INVALID, "unknown kernel family %d", t.kernel);
   if (t.pivot_rule < -1 || t.pivot_rule > 1) return fail(DEXR_ERR_INVALID, "unknown pivot rule %d", t.pivot_rule);
+  if (t.longest_first < -1 || t.longest_first > 1) return fail(DEXR_ERR_INVALID, "longest_first must be -1, 0 or 1");
   if (t.persist_from < 0 || t.qchunk < 0 || t.persist_occ < 0 || t.resident_waves < 0 || t.max_blind < 0)
     return fail(DEXR_ERR_INVALID, "negative launch parameter");
   if (!(t.step_cap >= 0) || !(t.lam_jump >= 0) || !(t.lam_fastdec >= 0) || !(t.floor_scale >= 0) || !(t.blind_tol_scale >= 0))

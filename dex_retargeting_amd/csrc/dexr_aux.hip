@@ -66,6 +66,15 @@ __global__ void __launch_bounds__(256) fleet_scatter_kernel(const int32_t* __res
   }
 }
 
+// Longest-first ordering of a batch (dexr_api.hip: launch_wide): key 0 = frame whose objective at the start point is
+// above `ratio` x the batch mean (it will need many solver passes), key 1 = everything else.
+__global__ void __launch_bounds__(256) lpt_key_kernel(const float* __restrict__ f0, const float* __restrict__ sum, int64_t B,
+                                                      float ratio, int32_t* __restrict__ key) {
+  const float thr = ratio * (*sum) / (float)B;
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x)
+    key[b] = f0[b] > thr ? 0 : 1;
+}
+
 struct ComposeMap {
   int32_t kind[DEXR_MAX_DOF];  // 0 target joint, 1 fixed joint, 2 mimic joint
   int32_t idx[DEXR_MAX_DOF];   // column of qpos_raw / column of fixed / source dof
@@ -130,6 +139,17 @@ hipError_t dexr_fleet_bucket_launch(int n_models, int64_t B, const int32_t* mode
   hipLaunchKernelGGL(fleet_offsets_kernel, dim3(1), dim3(64), 0, st, n_models, counts, bucket, cursor);
   hipLaunchKernelGGL(fleet_scatter_kernel, dim3(blocks), dim3(256), 0, st, model_id, B, n_models, bucket, cursor, perm);
   return hipGetLastError();
+}
+
+// keys from the screening launch's F(x0) values, then the index list (hard frames first) through the fleet bucketing
+// kernels; ws: the fleet workspace (perm at ws + dexr_fleet_ws_ints())
+hipError_t dexr_lpt_order_launch(int64_t B, const float* f0, const float* sum, float ratio, int32_t* key, int32_t* ws, hipStream_t st) {
+  const int64_t want = (B + 255) / 256;
+  const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  hipLaunchKernelGGL(lpt_key_kernel, dim3(blocks), dim3(256), 0, st, f0, sum, B, ratio, key);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return dexr_fleet_bucket_launch(2, B, key, ws, st);
 }
 
 hipError_t dexr_seq_compose_launch(int64_t B, int T, int n_q, int n_opt, int n_fixed, const int32_t* kind,

@@ -62,6 +62,8 @@ struct KernelParams {
   int32_t stall_from;             // termination at the float rounding floor (see "stalled" in the kernels): from this
   float stall_ratio;              // many unverifiable ("blind") steps on, a step that is not < stall_ratio x the
   float stall_cap;                // previous one and is < stall_cap x tol ends the solve
+  float* screen;                  // dexr_wide_kernel, screening launch: F(x0) per row (NULL: solve launch)
+  float* screen_sum;              //   and its sum over the batch
   uint32_t q0;                    // queue mode: frames [0, q0) are handed out statically (wave w starts with tile w),
                                   // the queue counter numbers the frames from q0 on
   uint32_t qchunk;                // frames a wave takes from its component's queue per atomicAdd; 0 = tile mode

@@ -448,8 +448,8 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   // ---- value / gradient (own joints) / Hessian grid at the kinematic state in LDS ------------------------------------
   float gnew[NJ2];
   wv2 Hn[NR][NP];
-  auto assemble = [&]() -> double {
-    // (1) lane t evaluates term t
+  // (1) lane t evaluates term t; returns F (identical in the 16 lanes of the row)
+  auto terms = [&]() -> double {
     double Fv = 0;
     if (l < nt) {
       const int ft = tb.term_task[l], fo = tb.term_origin[l];
@@ -508,6 +508,10 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     Fv = row_sum64(Fv);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    return Fv;
+  };
+  auto assemble = [&]() -> double {
+    const double Fv = terms();
 
     // (2) own joints' axes / origins; accumulators of the pass: data-term gradient and second-order vector
     constexpr int NCOL = MIMIC ? FAM : NJ2;  // joints whose columns this lane forms
@@ -848,19 +852,23 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     pred = 0;
     ok = true;
   };
+  float screen_acc = 0.f;  // screening launch: sum of F(x0) over the frames of this wave (lane 0 of each row)
   for (;;) {
     // (0) hand frames to idle rows
     const unsigned long long want = __ballot(!active);
     if (want != 0ull) {
       if (pool_next >= pool_end && !dry) {
+        // take exactly as many frames as there are idle rows: a frame parked in this wave's pool while its other rows
+        // are busy would start late (near the end of the queue other waves' rows are idle by then)
+        const unsigned nwant = (unsigned)__popcll(want) >> 4;
         unsigned base = 0;
-        if (lane == 0) base = atomicAdd(queue, 4u);
+        if (lane == 0) base = atomicAdd(queue, nwant);
         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + kp.q0;
         if ((int64_t)base >= nB) {
           dry = true;
         } else {
           pool_next = base;
-          pool_end = (unsigned)(((int64_t)base + 4 < nB) ? base + 4 : nB);
+          pool_end = (unsigned)(((int64_t)base + nwant < nB) ? base + nwant : nB);
         }
       }
       if (pool_next < pool_end) {
@@ -880,6 +888,19 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       continue;
     }
     fk();
+    if (kp.screen) {
+      // SCREENING launch (longest-first ordering, dexr_api.hip: launch_wide): F at the start point is all that is
+      // wanted of a frame -- large values mark the frames that will need many passes (DexPilot models: the top 5 % by
+      // F(x0) hold 91 % of the frames with >= 15 iterations)
+      const double F0 = terms();
+      if (active) {
+        if (l == 0) kp.screen[lrow] = (float)F0;
+        screen_acc += (l == 0) ? (float)F0 : 0.f;
+        active = false;
+        done = true;
+      }
+      continue;
+    }
     const double Fe = assemble();
     if (!done) {
       bool take = false;
@@ -1029,6 +1050,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       }
     }
   }
+  if (kp.screen && l == 0 && screen_acc != 0.f) atomicAdd(kp.screen_sum, screen_acc);
 }
 
 }  // namespace dexr

@@ -87,6 +87,10 @@ typedef struct dexr_tuning {
                            the Rayleigh quotient of the failed step), 1 modified Cholesky (the pivot is reflected, the
                            step judged by the decrease and stretched to the trust radius; lam_jump scales mean diag H),
                            -1 measured policy (1 for DexPilot models with mimic joints)                             */
+  int32_t longest_first; /* sixteen-lane kernel, plain batches: a screening launch evaluates F at the start points, frames
+                           above 1.3 x the batch mean are solved first (a launch is otherwise bound by slow frames the
+                           queue hands out late).  1 on, 0 off, -1 measured policy (currently off: the screening costs
+                           more than the ordering gains with this predictor, see dexr_api.hip launch_wide)            */
 } dexr_tuning;
 
 const char* dexr_last_error(void);

@@ -974,3 +974,24 @@ def test_sixteen_lane_variable_grid_agrees_with_the_reduced_variable_kernel(rel)
     q2, _ = run(kp[1:], last, kernel=_lib.KERNEL_WIDE, pivot_rule=1)
     assert np.array_equal(q2, res[1])
     model.tune(kernel=_lib.KERNEL_AUTO, pivot_rule=-1)
+
+
+def test_longest_first_ordering_changes_the_schedule_not_the_answers():
+    """dexr_tuning.longest_first: screening launch + device-side index list, hard frames first.  Every frame's
+    arithmetic is the same, so the answers are bitwise those of the plain launch."""
+    seq, prob = build("teleop/shadow_hand_right_dexpilot.yml")
+    model = seq.optimizer.device_model()
+    B = 20000
+    kp = np.ascontiguousarray(cases.human_keypoints(B + 1, seed=cases.SEED))
+    mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
+    last = model.retarget(kp[:-1], None, mid, state=np.zeros(B, np.uint32), keypoints=True)
+    out = {}
+    for lf in (0, 1, 1):
+        model.tune(longest_first=lf)
+        st = np.zeros(B, np.uint32)
+        q, info = model.retarget(kp[1:], None, last, state=st, keypoints=True, want_info=True)
+        assert (info["status"] == 0).all()
+        out.setdefault(lf, []).append((q, st.copy(), info["iters"].copy()))
+    model.tune(longest_first=-1)
+    for q, st, it in out[1]:
+        assert np.array_equal(q, out[0][0][0]) and np.array_equal(st, out[0][0][1]) and np.array_equal(it, out[0][0][2])

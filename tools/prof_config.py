@@ -64,5 +64,27 @@ if len(sys.argv) > 6:  # the first N frames with their inputs and iteration coun
     nh = int(sys.argv[6])
     np.savez(os.path.join(REPO, "gpurun_out", "head_" + sys.argv[5]), kp=kp[1:][:nh], last=last[:nh], iters=it[:nh],
              state=(t_st0.cpu().numpy()[:nh].astype(np.uint32) if dex else np.zeros(nh, np.uint32)), q=t_q.cpu().numpy()[:nh])
+if os.environ.get("DEXR_TOOL_LPT"):  # what would longest-first ordering buy?  re-run with the frames sorted by the
+    # iteration counts just measured (a perfect predictor), or with only the top fraction moved to the front
+    frac = float(os.environ["DEXR_TOOL_LPT"])
+    order = np.argsort(-it, kind="stable")
+    nfront = int(frac * B)
+    front = np.sort(order[:nfront])
+    rest = np.setdiff1d(np.arange(B), front)
+    pm = torch.from_numpy(np.concatenate([front, rest])).to(dev)
+    t_kp2, t_last2 = t_kp[pm].contiguous(), t_last[pm].contiguous()
+    t_st2 = t_st0[pm].contiguous() if dex else None
+    ts = []
+    for _ in range(n):
+        if dex:
+            t_st.copy_(t_st2)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(s)
+        model.retarget_dev(B, t_kp2.data_ptr(), 0, t_last2.data_ptr(), t_st.data_ptr() if dex else 0, t_q.data_ptr(),
+                           stream=s.cuda_stream, keypoints=True)
+        b.record(s)
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    print(f"  hardest {frac:.0%} of the frames first: ms {np.median(ts):.3f}")
 print(f"{rel} kernel={model.kernel()} B={B}: ms {np.median([a.elapsed_time(b) for a, b in ev]):.3f}; iters mean {it.mean():.2f} "
       f"p99 {np.percentile(it, 99):.0f} max {it.max()}; hist {np.bincount(it).tolist()}")
