@@ -713,11 +713,11 @@ def test_mixed_fleet_equals_per_model_calls():
 # ---- fused T-frame sequence kernel + compose kernel ----------------------------------------
 @pytest.mark.parametrize("rel", ["teleop/allegro_hand_right.yml",          # serial-chain small kernel
                                  "teleop/ability_hand_right.yml",          # small generic kernel, mimic joints
-                                 "teleop/shadow_hand_right_dexpilot.yml",  # quad kernel, carried projection bits
-                                 "offline/leap_hand_right.yml",            # quad kernel, free joints, alpha = 1
-                                 "teleop/shadow_hand_right.yml",           # large register kernel
-                                 "offline/shadow_hand_right.yml",          # LDS kernel (30 joints)
-                                 "teleop/inspire_hand_right_dexpilot.yml"])  # polish model: float64 sequence kernel
+                                 "teleop/shadow_hand_right_dexpilot.yml",  # sixteen-lane kernel, carried projection bits
+                                 "offline/leap_hand_right.yml",            # sixteen-lane kernel, free joints, alpha = 1
+                                 "teleop/shadow_hand_right.yml",           # sixteen-lane kernel, vector objective
+                                 "offline/shadow_hand_right.yml",          # sixteen-lane kernel, 30 joints (32-row grid)
+                                 "teleop/inspire_hand_right_dexpilot.yml"])  # sixteen-lane kernel on the variable grid (mimic)
 def test_fused_sequence_kernel_equals_frame_by_frame(rel):
     """dexr_retarget_seq_dev + dexr_seq_compose_dev (two launches for T x B frames, every lane looping over its
     sequence's frames inside the kernel) == DeviceSeqRetargeting.retarget called T times (one solve launch + torch
