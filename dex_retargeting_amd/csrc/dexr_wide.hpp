@@ -737,9 +737,20 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       }
     }
     auto hw_get = [&](int i, int j) -> float { return (j & 1) ? Hw[i][j / 2].y : Hw[i][j / 2].x; };
-    float ivr[NR], ivc[NR];  // 1 / L[r][r] of row 4 i + a and of column 4 j + b
+    // The right-hand side rides along as row NMAX of the matrix (held by quad 0, class a = 0): the factorisation's
+    // trailing updates then ARE the forward substitution -- after the last step that row holds y = L^-1 rhs.  Saves a
+    // 24-step dependent chain of quad sums and row broadcasts per pass.
+    wv2 Hy[NP];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) { ivr[i] = 0.f; ivc[i] = 0.f; }
+    for (int j = 0; j < NR; ++j) {
+      const int c = 4 * j + b;
+      const float v = (a == 0 && ((freemask >> c) & 1u)) ? -GVl[c] : 0.f;
+      if (j & 1) Hy[j / 2].y = v; else Hy[j / 2].x = v;
+    }
+    auto hy_get = [&](int j) -> float { return (j & 1) ? Hy[j / 2].y : Hy[j / 2].x; };
+    float ivc[NR];  // 1 / L[c][c] of column 4 j + b
+#pragma unroll
+    for (int i = 0; i < NR; ++i) ivc[i] = 0.f;
 #pragma unroll
     for (int jc = 0; jc < NMAX; ++jc) {
       constexpr int dummy = 0;
@@ -755,7 +766,6 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         if (!(dj > 1e-30f)) { ok = false; dj = 1.f; }
       }
       const float iv = __frsqrt_rn(dj);
-      ivr[jo] = (a == ja) ? iv : ivr[jo];
       ivc[jo] = (b == ja) ? iv : ivc[jo];
       // scale column jc (lanes of column class ja), rows below the pivot; then send it to the grid: row side from
       // lane (a, ja) (own quad, DPP), column side from lane (b, ja) (ds_bpermute)
@@ -785,26 +795,22 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 #pragma unroll
         for (int jj = jo / 2; jj <= i / 2; ++jj) Hw[i][jj] = __builtin_elementwise_fma(rr, Lc[jj], Hw[i][jj]);
       }
+      {  // the right-hand-side row
+        const float cur = hy_get(jo);
+        const float own = (b == ja) ? cur * iv : cur;
+        if (jo & 1) Hy[jo / 2].y = own; else Hy[jo / 2].x = own;
+        const float ly = ja == 0 ? wquad_bcast<0>(own) : ja == 1 ? wquad_bcast<1>(own) : ja == 2 ? wquad_bcast<2>(own) : wquad_bcast<3>(own);
+        const wv2 rr = wv2{-ly, -ly};
+#pragma unroll
+        for (int jj = jo / 2; jj < NP; ++jj) Hy[jj] = __builtin_elementwise_fma(rr, Lc[jj], Hy[jj]);
+      }
     }
-    // forward: L y = rhs; yb[j] = y[4 j + b]
-    float yb[NR], da[NR], ga[NR];
+    // y[4 j + b] from quad 0 to the lanes of column class b of every quad
+    float yb[NR], da[NR];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-      yb[i] = 0;
-      da[i] = 0;
-      const int r = 4 * i + a;
-      ga[i] = ((freemask >> r) & 1u) ? -GVl[r] : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < NMAX; ++r) {
-      const int ra = r & 3, ro = r >> 2;
-      float part = 0;
-#pragma unroll
-      for (int j = 0; j <= ro; ++j) part += hw_get(ro, j) * yb[j];  // entries at or right of the diagonal meet yb = 0
-      const float sum = wquad_sum(part);
-      const float yr_local = (ga[ro] - sum) * ivr[ro];  // valid on quad ra
-      const float yr = stride4_sum(a == ra ? yr_local : 0.f);  // quad ra -> every quad
-      yb[ro] = (b == ra) ? yr : yb[ro];
+    for (int j = 0; j < NR; ++j) {
+      yb[j] = stride4_sum(a == 0 ? hy_get(j) : 0.f);
+      da[j] = 0;
     }
     // backward: L^T d = y; da[i] = d[4 i + a]
 #pragma unroll
