@@ -90,7 +90,8 @@ struct WideLds {
   static constexpr int XT = 0;                         // NJ x 16 floats: X[12], fbeg | fend << 8, var + 1, vmul, off
   static constexpr int FO = XT + NJ * 64;              // 16 frames x 4 floats
   static constexpr int CH = FO + 256;                  // 16 x 16 chain bytes
-  static constexpr int PL = CH + 256;                  // MIMIC: second-order pair list, 128 words + 17 lane offsets
+  static constexpr int ANC = CH + 256;                 // NMAX words: revolute ancestors-or-self of each joint
+  static constexpr int PL = ANC + NMAX * 4;            // MIMIC: second-order pair list, 128 words + 17 lane offsets
   static constexpr int SLOT0 = PL + (MIMIC ? 512 + 32 : 0);
   // per frame slot
   static constexpr int P = 0;                          // 16 frames x 3 doubles
@@ -141,6 +142,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   float* XT = reinterpret_cast<float*>(wbase + L::XT);
   float* FO = reinterpret_cast<float*>(wbase + L::FO);
   unsigned char* CH = wbase + L::CH;
+  uint32_t* ANCw = reinterpret_cast<uint32_t*>(wbase + L::ANC);
   uint32_t* PLw = reinterpret_cast<uint32_t*>(wbase + L::PL);
   unsigned char* POFF = wbase + L::PL + 512;
   unsigned char* sbase = wbase + L::SLOT0 + (size_t)slot * L::SLOT;
@@ -187,6 +189,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     FO[f * 4 + 3] = 0.f;
   }
   for (int i = lane; i < 256; i += 64) CH[i] = wt.chain[i >> 4][i & 15];
+  for (int i = lane; i < NMAX; i += 64) ANCw[i] = (!MIMIC && i < nj) ? wt.anc_rev[i] : 0u;
 
   uint32_t optmask = 0, revmask = 0;
 #pragma unroll
@@ -198,8 +201,9 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   // ---- per-lane constants: the joints this lane owns (l, l + 16) and the ancestor masks of its Hessian rows ---------
   int jo_[NJ2];
   bool jin[NJ2], jopt[NJ2], jrev[NJ2], jfix[NJ2];
-  float jlo[NJ2], jhi[NJ2], jmul[NJ2], joff[NJ2];
-  int japi[NJ2], jsrc[NJ2];
+  float jlo[NJ2], jhi[NJ2];
+  int jsel[NJ2];  // the joint whose box / api index / fixed-value map apply (read from the tables when a frame is
+                  // loaded or retired: registers are the scarce resource of this kernel)
 #pragma unroll
   for (int s = 0; s < NJ2; ++s) {
     const int k = l + 16 * s;  // grid index: joint, with MIMIC variable
@@ -211,21 +215,14 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     jrev[s] = jin[s] && tb.jtype[kk] == DEXR_JOINT_REVOLUTE;
     jlo[s] = tb.lo[kk];
     jhi[s] = tb.hi[kk];
-    jmul[s] = tb.mult[kk];
-    joff[s] = tb.off[kk];
-    japi[s] = jopt[s] ? tb.api[kk] : 0;
-    jsrc[s] = jfix[s] ? tb.src_idx[kk] : 0;
+    jsel[s] = kk;
   }
-  uint32_t ancr[NR];  // revolute ancestors-or-self of row 4 i + a
-#pragma unroll
-  for (int i = 0; i < NR; ++i) ancr[i] = (!MIMIC && 4 * i + a < nj) ? wt.anc_rev[4 * i + a] : 0u;
   // MIMIC: the joints that move with this lane's variable (its own joint first) and their dq/dx; the fixed joints in
   // this lane's joint slots (their values go to LDS once per frame)
   int famk[FAM];
   float famm[FAM];
   bool fsfix[NFS];
-  float fsmul[NFS], fsoff[NFS];
-  int fssrc[NFS];
+
   int fam_max = 0;  // wave-uniform: the largest family of the component
   if (MIMIC) {
 #pragma unroll
@@ -239,10 +236,6 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     for (int s = 0; s < NFS; ++s) {
       const int k = l + 16 * s;
       fsfix[s] = k < nj && tb.src_kind[k < nj ? k : 0] == DEXR_SRC_FIXED;
-      const int kk = fsfix[s] ? k : 0;
-      fsmul[s] = tb.mult[kk];
-      fsoff[s] = tb.off[kk];
-      fssrc[s] = fsfix[s] ? tb.src_idx[kk] : 0;
     }
   }
 
@@ -291,9 +284,9 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   auto xl = [&](int s) -> float {  // regularisation target of own joint s (see dexr_quad.hpp)
     float v;
     if (seq && t_seq > 0)
-      v = __hip_atomic_load(const_cast<float*>(lastp) + japi[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = __hip_atomic_load(const_cast<float*>(lastp) + tb.api[jsel[s]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else
-      v = lastp[japi[s]];
+      v = lastp[tb.api[jsel[s]]];
     return seq ? fminf(fmaxf(v, jlo[s] + kp.clip_eps), jhi[s] - kp.clip_eps) : v;
   };
   auto load_frame = [&](int64_t it, int t) {
@@ -308,17 +301,20 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       xlast[s] = 0;
       if (jopt[s]) {
         xlast[s] = xl(s);
-        const float v = (kp.x0 && !(seq && t_seq > 0)) ? kp.x0[lrow * ld + japi[s]] : xlast[s];
+        const float v = (kp.x0 && !(seq && t_seq > 0)) ? kp.x0[lrow * ld + tb.api[jsel[s]]] : xlast[s];
         xj[s] = fminf(fmaxf(v, jlo[s]), jhi[s]);
       } else if (jfix[s]) {
-        xj[s] = jmul[s] * kp.fixed[irow * kp.n_fixed + jsrc[s]] + joff[s];
+        xj[s] = tb.mult[jsel[s]] * kp.fixed[irow * kp.n_fixed + tb.src_idx[jsel[s]]] + tb.off[jsel[s]];
       }
       xacc[s] = xj[s];
     }
     if (MIMIC) {
 #pragma unroll
       for (int s = 0; s < NFS; ++s)
-        if (fsfix[s]) QJl[l + 16 * s] = fsmul[s] * kp.fixed[irow * kp.n_fixed + fssrc[s]] + fsoff[s];
+        if (fsfix[s]) {
+          const int k = l + 16 * s;
+          QJl[k] = tb.mult[k] * kp.fixed[irow * kp.n_fixed + tb.src_idx[k]] + tb.off[k];
+        }
     }
     if (dexpilot) {  // projection bits (optimizer.py:466-476)
       const uint32_t st = (seq && t_seq > 0) ? nst : (kp.state ? kp.state[lrow] : 0u);
@@ -701,7 +697,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 #pragma unroll
         for (int j = 0; j <= i; ++j) {
           const float v = axc[j].x * cf.x + axc[j].y * cf.y + axc[j].z * cf.z;
-          const float add = ((ancr[i] >> (4 * j + b)) & 1u) ? v : 0.f;
+          const float add = ((ANCw[4 * i + a] >> (4 * j + b)) & 1u) ? v : 0.f;
           if (j & 1) Hn[i][j / 2].y += add; else Hn[i][j / 2].x += add;
         }
       }
@@ -1037,8 +1033,9 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       for (int s = 0; s < NJ2; ++s)
         if (jopt[s]) {
           const float v = bad ? xlast[s] : xacc[s];
-          kp.qout[irow * ld + japi[s]] = v;
-          if (kp.qout64) kp.qout64[irow * ld + japi[s]] = (double)v;
+          const int api = tb.api[jsel[s]];
+          kp.qout[irow * ld + api] = v;
+          if (kp.qout64) kp.qout64[irow * ld + api] = (double)v;
         }
       if (l == 0) {
         if (kp.status) atomicMax(&kp.status[irow], status);
