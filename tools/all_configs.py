@@ -21,13 +21,13 @@ from oracle import cases  # noqa: E402  (input recipes only)
 RetargetingConfig.set_default_urdf_dir(str(DEFAULT_URDF_DIR))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 and sys.argv[2] != "all" else None  # substrings of config paths to run
-KERNEL = sys.argv[3] if len(sys.argv) > 3 else "auto"  # force a kernel family (auto|register|quad|lds|reduced) where it applies
+KERNEL = sys.argv[3] if len(sys.argv) > 3 else "auto"  # force a kernel family (auto|register|quad|lds|reduced|wide) where it applies
 dev = torch.device("cuda:0")
 kp = cases.human_keypoints(B + 1, seed=cases.SEED)
 t_kp = torch.from_numpy(np.ascontiguousarray(kp[1:])).to(dev)
 s = torch.cuda.current_stream()
 print(f"# {B} frames per launch, one MI355X; dq = max_j |q_f32 - q_f64| per frame over all frames")
-print(f"# kernel = {KERNEL}; kernel column: (family 0 register / 1 quad / 2 LDS / 3 reduced, joint bucket, chain)")
+print(f"# kernel = {KERNEL}; kernel column: (family 0 register / 1 quad / 2 LDS / 3 reduced / 4 sixteen-lane, joint bucket, chain)")
 print(f"{'config':44s} {'kernel':>14s} {'n_opt':>5s} {'comps':>5s} {'ms':>8s} {'Mframes/s':>9s} {'it mean':>7s} {'it max':>6s} {'conv':>6s} {'p99.9 dq':>9s} {'>1e-4':>6s} {'it p99':>6s} {'tile max':>8s}")
 for path in sorted(glob.glob(os.path.join(cases.CONFIG_DIR, "*", "*.yml"))):
     rel = os.path.relpath(path, cases.CONFIG_DIR)
