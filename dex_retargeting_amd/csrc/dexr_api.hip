@@ -226,7 +226,10 @@ int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st)
   int wpb = 4;
   while (wpb > 1 && per_wave * wpb > 80 * 1024) wpb >>= 1;
   const int64_t tiles = (kp.B + 3) / 4;
-  int64_t resident = (int64_t)m->n_cu * 4 * 2;
+  // waves per SIMD: 2 (256 VGPRs; 15-17 KB of LDS per wave); the 16-row joint grid is built for 3 (168 VGPRs, 11.8 KB):
+  // LEAP DexPilot 1.24 -> 1.14 ms, Allegro DexPilot 0.84 -> 0.75 ms
+  const int occ = (!m->wide_mimic && m->bucket == 16) ? 3 : 2;
+  int64_t resident = (int64_t)m->n_cu * 4 * occ;
   if (m->tune.resident_waves > 0) resident = m->tune.resident_waves;
   int64_t per_comp = (resident + kp.n_comp - 1) / kp.n_comp;
   if (per_comp > tiles) per_comp = tiles;

@@ -18,7 +18,8 @@
 //     and one ds_bpermute (column side) per local row; triangular solves with quad / stride-4 DPP reductions.
 // The accepted point's Hessian and gradient stay in registers, so a REJECTED step costs no extra pass (the quad kernel
 // re-assembles): every pass evaluates a new trial point.
-// ~128 VGPRs, 15 KB of LDS per wave: two waves per SIMD.  Damping / termination rules are those of dexr_quad.hpp.
+// 256 VGPRs and 15 KB of LDS per wave: two waves per SIMD (the 16-row grid: 168 VGPRs, 12 KB, three waves).  Damping /
+// termination rules are those of dexr_quad.hpp.
 #pragma once
 
 #include "dexr_big.hpp"  // sincos_f64
@@ -191,12 +192,10 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   for (int i = lane; i < 256; i += 64) CH[i] = wt.chain[i >> 4][i & 15];
   for (int i = lane; i < NMAX; i += 64) ANCw[i] = (!MIMIC && i < nj) ? wt.anc_rev[i] : 0u;
 
-  uint32_t optmask = 0, revmask = 0;
+  uint32_t revmask = 0;
 #pragma unroll
-  for (int k = 0; k < NJ; ++k) {
-    if (k < nj && tb.src_kind[k] == DEXR_SRC_OPT) optmask |= 1u << k;
+  for (int k = 0; k < NJ; ++k)
     if (k < nj && tb.jtype[k] == DEXR_JOINT_REVOLUTE) revmask |= 1u << k;
-  }
 
   // ---- per-lane constants: the joints this lane owns (l, l + 16) and the ancestor masks of its Hessian rows ---------
   int jo_[NJ2];
@@ -749,8 +748,6 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     for (int i = 0; i < NR; ++i) ivc[i] = 0.f;
 #pragma unroll
     for (int jc = 0; jc < NMAX; ++jc) {
-      constexpr int dummy = 0;
-      (void)dummy;
       const int ja = jc & 3, jo = jc >> 2;
       // pivot: lane (ja, ja) -> its quad (DPP) -> the row (mask + stride-4 sum)
       const float own_d = hw_get(jo, jo);
