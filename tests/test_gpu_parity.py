@@ -995,3 +995,49 @@ def test_longest_first_ordering_changes_the_schedule_not_the_answers():
     model.tune(longest_first=-1)
     for q, st, it in out[1]:
         assert np.array_equal(q, out[0][0][0]) and np.array_equal(st, out[0][0][1]) and np.array_equal(it, out[0][0][2])
+
+
+@pytest.mark.parametrize("rel", ["teleop/allegro_hand_right.yml", "teleop/shadow_hand_right_dexpilot.yml"])
+def test_launches_on_two_streams_do_not_interfere(rel):
+    """Independent batches issued alternately on two HIP streams through the same model handle (work-queue slots are
+    handed out round-robin per launch): every batch's answer equals the one a lone launch returns, bitwise."""
+    import torch
+
+    seq, prob = build(rel)
+    model = seq.optimizer.device_model()
+    B, n_batches = 20000, 6
+    dex = prob.kind == "dexpilot"
+    dev = torch.device("cuda:0")
+    mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
+    batches = []
+    for j in range(n_batches):
+        kp = np.ascontiguousarray(cases.human_keypoints(B + 1, seed=cases.SEED + j))
+        st = np.zeros(B, np.uint32) if dex else None
+        last = model.retarget(kp[:-1], None, mid, state=st, keypoints=True)
+        st1 = None if st is None else st.copy()
+        want = model.retarget(kp[1:], None, last, state=st1, keypoints=True)
+        batches.append(dict(t_kp=torch.from_numpy(kp[1:]).to(dev), t_last=torch.from_numpy(last).to(dev),
+                            t_st=None if st is None else torch.from_numpy(st.astype(np.int32)).to(dev),
+                            t_out=torch.zeros((B, prob.n_opt), dtype=torch.float32, device=dev), want=want))
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for j, b in enumerate(batches):
+            s = streams[j & 1]
+            st = b["t_st"].clone() if dex else None  # (allocated on the default stream: synchronise before use)
+            torch.cuda.synchronize() if dex else None
+            model.retarget_dev(B, b["t_kp"].data_ptr(), 0, b["t_last"].data_ptr(), st.data_ptr() if dex else 0,
+                               b["t_out"].data_ptr(), stream=s.cuda_stream, keypoints=True)
+            b["st_keep"] = st
+        torch.cuda.synchronize()
+        for b in batches:
+            assert np.array_equal(b["t_out"].cpu().numpy(), b["want"])
+
+
+def test_tuning_rejects_unknown_values():
+    seq, _ = build("teleop/shadow_hand_right_dexpilot.yml")
+    model = seq.optimizer.device_model()
+    for bad in (dict(kernel=7), dict(pivot_rule=3), dict(longest_first=2), dict(lam_jump=-1.0)):
+        with pytest.raises(_lib.DexrError):
+            model.tune(**bad)
+    model.tune(kernel=_lib.KERNEL_AUTO)
