@@ -98,7 +98,9 @@ struct WideLds {
   static constexpr int P = 0;                          // 16 frames x 3 doubles
   static constexpr int AX = P + 384;                   // NJ x 4 floats
   static constexpr int OG = AX + NJ * 16;              // NJ x 4 floats
-  static constexpr int XV = OG + NJ * 16;              // NJ floats: joint values of the trial point (MIMIC: variables)
+  static constexpr int SC = OG + NJ * 16;              // NJ x 2 doubles: (sin q, cos q) of a revolute joint, (q, -) of a
+                                                       // prismatic one, computed by the joint's slot lane
+  static constexpr int XV = SC + NJ * 16;              // NJ floats: joint values of the trial point (MIMIC: variables)
   static constexpr int QJ = XV + NJ * 4;               // MIMIC: NJ floats, values of the fixed joints of the frame
   static constexpr int GV = QJ + (MIMIC ? NJ * 4 : 0); // NMAX floats: gradient
   static constexpr int CF = GV + NMAX * 4;             // NJ x 4 floats: second-order vectors
@@ -150,6 +152,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   double* Pl = reinterpret_cast<double*>(sbase + L::P);
   float* AXl = reinterpret_cast<float*>(sbase + L::AX);
   float* OGl = reinterpret_cast<float*>(sbase + L::OG);
+  double* SCl = reinterpret_cast<double*>(sbase + L::SC);
   float* XVl = reinterpret_cast<float*>(sbase + L::XV);
   float* QJl = reinterpret_cast<float*>(sbase + L::QJ);
   float* GVl = reinterpret_cast<float*>(sbase + L::GV);
@@ -379,18 +382,61 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 #pragma unroll
     for (int s = 0; s < NJ2; ++s)
       if (jin[s]) XVl[jo_[s]] = xj[s];
+    if (MIMIC) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // sines / cosines of all joints first, one or two joints per lane: the chain walk below then has no polynomial in
+    // its dependency chain (a chain is 7-13 joints deep; every lane used to evaluate all of its chain's sincos in turn)
+#pragma unroll
+    for (int s = 0; s < (NJ + 15) / 16; ++s) {
+      const int k = l + 16 * s;
+      if (k < nj) {
+        double q;
+        if (MIMIC) {  // q = vmul * x[var] + off in float64 (a float32 product makes F a step function of x)
+          const float4 x3 = *reinterpret_cast<const float4*>(XT + k * 16 + 12);
+          const int vc = __float_as_int(x3.y);
+          q = vc > 0 ? fma((double)x3.z, (double)XVl[vc > 0 ? vc - 1 : 0], (double)x3.w) : (double)QJl[k];
+        } else {
+          q = (double)xj[s < NJ2 ? s : 0];
+        }
+        double sn = q, cs = 0.0;
+        if ((revmask >> k) & 1u) sincos_f64(q, &sn, &cs);
+        SCl[2 * k] = sn;
+        SCl[2 * k + 1] = cs;
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pp[3] = {0, 0, 0};
+    // the tables of step s + 1 are fetched while step s is computed (two LDS round trips per step off the chain) --
+    // except in the three-waves-per-SIMD build of the 16-row grid, where the 20 extra live registers spill
+    constexpr bool PREFETCH = MIMIC || NMAX > 16;
+    unsigned cb = depth > 0 ? CH[l * 16] : 0xFFu;
+    int kf = cb != 0xFFu ? (int)(cb & 0x7Fu) : 0;
+    float4 x0 = *reinterpret_cast<const float4*>(XT + kf * 16);
+    float4 x1 = *reinterpret_cast<const float4*>(XT + kf * 16 + 4);
+    float4 x2 = *reinterpret_cast<const float4*>(XT + kf * 16 + 8);
+    float4 x3 = *reinterpret_cast<const float4*>(XT + kf * 16 + 12);
+    double scs = SCl[2 * kf], scc = SCl[2 * kf + 1];
 #pragma clang loop unroll(disable) vectorize(disable)
     for (int s = 0; s < depth; ++s) {
-      const unsigned cb = CH[l * 16 + s];
+      unsigned cbn = 0xFFu;
+      float4 y0, y1, y2, y3;
+      double scsn, sccn;
+      auto fetch_next = [&]() {
+        cbn = (s + 1 < depth) ? CH[l * 16 + s + 1] : 0xFFu;
+        const int kn = cbn != 0xFFu ? (int)(cbn & 0x7Fu) : 0;
+        y0 = *reinterpret_cast<const float4*>(XT + kn * 16);
+        y1 = *reinterpret_cast<const float4*>(XT + kn * 16 + 4);
+        y2 = *reinterpret_cast<const float4*>(XT + kn * 16 + 8);
+        y3 = *reinterpret_cast<const float4*>(XT + kn * 16 + 12);
+        scsn = SCl[2 * kn];
+        sccn = SCl[2 * kn + 1];
+      };
+      if (PREFETCH) fetch_next();
       if (cb != 0xFFu) {
         const int k = (int)(cb & 0x7Fu);
-        const float4 x0 = *reinterpret_cast<const float4*>(XT + k * 16);
-        const float4 x1 = *reinterpret_cast<const float4*>(XT + k * 16 + 4);
-        const float4 x2 = *reinterpret_cast<const float4*>(XT + k * 16 + 8);
-        const float4 x3 = *reinterpret_cast<const float4*>(XT + k * 16 + 12);
         const double Xk[12] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w};
 #pragma unroll
         for (int i = 0; i < 3; ++i) pp[i] += R[3 * i] * Xk[9] + R[3 * i + 1] * Xk[10] + R[3 * i + 2] * Xk[11];
@@ -399,16 +445,8 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         for (int i = 0; i < 3; ++i)
 #pragma unroll
           for (int j = 0; j < 3; ++j) Rn[3 * i + j] = R[3 * i] * Xk[j] + R[3 * i + 1] * Xk[3 + j] + R[3 * i + 2] * Xk[6 + j];
-        double q;
-        if (MIMIC) {  // q = vmul * x[var] + off in float64 (a float32 product makes F a step function of x)
-          const int vc = __float_as_int(x3.y);
-          q = vc > 0 ? fma((double)x3.z, (double)XVl[vc > 0 ? vc - 1 : 0], (double)x3.w) : (double)QJl[k];
-        } else {
-          q = (double)XVl[k];
-        }
         if ((revmask >> k) & 1u) {
-          double sn, cs;
-          sincos_f64(q, &sn, &cs);
+          const double sn = scs, cs = scc;
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
             const double c0 = Rn[3 * i], c1 = Rn[3 * i + 1];
@@ -417,6 +455,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
             R[3 * i + 2] = Rn[3 * i + 2];
           }
         } else {
+          const double q = scs;
 #pragma unroll
           for (int i = 0; i < 9; ++i) R[i] = Rn[i];
 #pragma unroll
@@ -435,6 +474,10 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
           }
         }
       }
+      if (!PREFETCH) fetch_next();
+      cb = cbn;
+      x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+      scs = scsn; scc = sccn;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
