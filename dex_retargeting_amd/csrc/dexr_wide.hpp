@@ -92,7 +92,8 @@ struct WideLds {
   static constexpr int FO = XT + NJ * 64;              // 16 frames x 4 floats
   static constexpr int CH = FO + 256;                  // 16 x 16 chain bytes
   static constexpr int ANC = CH + 256;                 // NMAX words: revolute ancestors-or-self of each joint
-  static constexpr int PL = ANC + NMAX * 4;            // MIMIC: second-order pair list, 128 words + 17 lane offsets
+  static constexpr int BOX = ANC + NMAX * 4;           // NMAX x (lo, hi): box of each grid variable
+  static constexpr int PL = BOX + NMAX * 8;            // MIMIC: second-order pair list, 128 words + 17 lane offsets
   static constexpr int SLOT0 = PL + (MIMIC ? 512 + 32 : 0);
   // per frame slot
   static constexpr int P = 0;                          // 16 frames x 3 doubles
@@ -106,7 +107,10 @@ struct WideLds {
   static constexpr int CF = GV + NMAX * 4;             // NJ x 4 floats: second-order vectors
   static constexpr int TB = CF + NJ * 16;              // 16 terms x 16 floats (MIMIC: reused for the second-order sums)
   static constexpr int JR = TB + 1024;                 // 4 rows x 4 classes x NRP floats
-  static constexpr int SLOT = JR + 4 * 4 * NRP * 4;
+  static constexpr int FS = JR + 4 * 4 * NRP * 4;      // 32 bytes: row of the frame's inputs / of its item, item, frame of
+                                                       // the sequence, DexPilot bits (registers are the scarce resource)
+  static constexpr int XL = FS + 32;                   // NMAX floats: regularisation target (the frame's start row)
+  static constexpr int SLOT = XL + NMAX * 4;
   static constexpr int WAVE = SLOT0 + 4 * SLOT;
 };
 
@@ -146,6 +150,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   float* FO = reinterpret_cast<float*>(wbase + L::FO);
   unsigned char* CH = wbase + L::CH;
   uint32_t* ANCw = reinterpret_cast<uint32_t*>(wbase + L::ANC);
+  float* BOXw = reinterpret_cast<float*>(wbase + L::BOX);
   uint32_t* PLw = reinterpret_cast<uint32_t*>(wbase + L::PL);
   unsigned char* POFF = wbase + L::PL + 512;
   unsigned char* sbase = wbase + L::SLOT0 + (size_t)slot * L::SLOT;
@@ -159,6 +164,9 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   float* CFl = reinterpret_cast<float*>(sbase + L::CF);
   float* TBl = reinterpret_cast<float*>(sbase + L::TB);
   float* JRl = reinterpret_cast<float*>(sbase + L::JR);
+  int64_t* FS64 = reinterpret_cast<int64_t*>(sbase + L::FS);     // [0] irow, [1] lrow, [2] item
+  int32_t* FS32 = reinterpret_cast<int32_t*>(sbase + L::FS) + 6;  // [0] frame of the sequence, [1] DexPilot bits
+  float* XLl = reinterpret_cast<float*>(sbase + L::XL);
 
   const dexr_comp_table& tb = comps[comp];
   const WideTable& wt = wtabs[comp];
@@ -203,9 +211,9 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   // ---- per-lane constants: the joints this lane owns (l, l + 16) and the ancestor masks of its Hessian rows ---------
   int jo_[NJ2];
   bool jin[NJ2], jopt[NJ2], jrev[NJ2], jfix[NJ2];
-  float jlo[NJ2], jhi[NJ2];
-  int jsel[NJ2];  // the joint whose box / api index / fixed-value map apply (read from the tables when a frame is
-                  // loaded or retired: registers are the scarce resource of this kernel)
+  // (the joint whose box / api index / fixed-value map apply is looked up in the tables when a frame is loaded or
+  // retired: registers are the scarce resource of this kernel)
+  auto jsel = [&](int s) -> int { return jin[s] ? (MIMIC ? tb.var_joint[jo_[s]] : jo_[s]) : 0; };
 #pragma unroll
   for (int s = 0; s < NJ2; ++s) {
     const int k = l + 16 * s;  // grid index: joint, with MIMIC variable
@@ -215,9 +223,10 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     jopt[s] = jin[s] && tb.src_kind[kk] == DEXR_SRC_OPT;
     jfix[s] = !MIMIC && jin[s] && tb.src_kind[kk] == DEXR_SRC_FIXED;
     jrev[s] = jin[s] && tb.jtype[kk] == DEXR_JOINT_REVOLUTE;
-    jlo[s] = tb.lo[kk];
-    jhi[s] = tb.hi[kk];
-    jsel[s] = kk;
+    if (jin[s]) {  // (every row's lane l writes the same two values: benign)
+      BOXw[2 * k] = tb.lo[kk];
+      BOXw[2 * k + 1] = tb.hi[kk];
+    }
   }
   // MIMIC: the joints that move with this lane's variable (its own joint first) and their dq/dx; the fixed joints in
   // this lane's joint slots (their values go to LDS once per frame)
@@ -248,24 +257,25 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   const int F_ = kp.num_fingers, n_pair = F_ * (F_ - 1) / 2, len_s1 = F_ - 1;
 
   // ---- per-frame state (replicated in the 16 lanes of the row unless noted) ------------------------------------------
-  int64_t item = 0, lrow = 0, irow = 0;
-  int t_seq = 0;
-  const float* lastp = kp.last;
+  // per-frame bookkeeping lives in LDS (FS64 / FS32), read where it is needed
+  auto f_irow = [&]() -> int64_t { return FS64[0]; };
+  auto f_lrow = [&]() -> int64_t { return FS64[1]; };
+  auto f_nst = [&]() -> uint32_t { return (uint32_t)FS32[1]; };
   bool active = false;
-  uint32_t nst = 0;
-  float xj[NJ2], xacc[NJ2], xlast[NJ2];  // own joints: trial value, accepted value, regularisation target
+  float xj[NJ2], xacc[NJ2];  // own joints: trial value, accepted value (the regularisation target is in LDS: XLl)
   float gacc[NJ2];                       // own joints: gradient at the accepted point (incl. regulariser)
   constexpr int NP = NR / 2;             // column pairs of the local Hessian block
   wv2 Ha[NR][NP];                        // Hessian grid entries (4 i + a, 4 j + b), j <= i, at the accepted point;
                                          // pair jj holds local columns 2 jj, 2 jj + 1 (packed FMAs)
 #pragma unroll
-  for (int s = 0; s < NJ2; ++s) { xj[s] = 0; xacc[s] = 0; xlast[s] = 0; gacc[s] = 0; }
+  for (int s = 0; s < NJ2; ++s) { xj[s] = 0; xacc[s] = 0; gacc[s] = 0; }
 #pragma unroll
   for (int i = 0; i < NR; ++i)
 #pragma unroll
     for (int j = 0; j < NP; ++j) Ha[i][j] = wv2{0.f, 0.f};
 
   auto ref_row = [&](int row, float (&rv)[3]) {
+    const int64_t irow = f_irow();
     if (kp.kpts) {
       const float* pa = kp.kpts + (irow * kp.n_kp + kp.h_task[row]) * 3;
       const int o = kp.h_origin[row];
@@ -283,32 +293,39 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       for (int i = 0; i < 3; ++i) rv[i] = r[i];
     }
   };
-  auto xl = [&](int s) -> float {  // regularisation target of own joint s (see dexr_quad.hpp)
+  auto xl = [&](int s, const float* lastp, int t_seq) -> float {  // regularisation target of own joint s (see dexr_quad.hpp)
     float v;
     if (seq && t_seq > 0)
-      v = __hip_atomic_load(const_cast<float*>(lastp) + tb.api[jsel[s]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = __hip_atomic_load(const_cast<float*>(lastp) + tb.api[jsel(s)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else
-      v = lastp[tb.api[jsel[s]]];
-    return seq ? fminf(fmaxf(v, jlo[s] + kp.clip_eps), jhi[s] - kp.clip_eps) : v;
+      v = lastp[tb.api[jsel(s)]];
+    return seq ? fminf(fmaxf(v, BOXw[2 * jo_[s]] + kp.clip_eps), BOXw[2 * jo_[s] + 1] - kp.clip_eps) : v;
   };
   auto load_frame = [&](int64_t it, int t) {
-    item = it;
-    t_seq = t;
-    lrow = row_of(it);
-    irow = seq ? (int64_t)t * kp.seq_stride + lrow : lrow;
-    lastp = (seq && t > 0) ? kp.qout + (irow - kp.seq_stride) * ld : kp.last + lrow * ld;
+    const int t_seq = t;
+    const int64_t lrow = row_of(it);
+    const int64_t irow = seq ? (int64_t)t * kp.seq_stride + lrow : lrow;
+    const float* lastp = (seq && t > 0) ? kp.qout + (irow - kp.seq_stride) * ld : kp.last + lrow * ld;
+    uint32_t nst = (seq && t > 0) ? f_nst() : 0u;  // (sequence mode: the previous frame's bits are the carried state)
+    FS64[0] = irow;
+    FS64[1] = lrow;
+    FS64[2] = it;
+    FS32[0] = t;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int s = 0; s < NJ2; ++s) {
       xj[s] = 0;
-      xlast[s] = 0;
+      float xlast = 0;
       if (jopt[s]) {
-        xlast[s] = xl(s);
-        const float v = (kp.x0 && !(seq && t_seq > 0)) ? kp.x0[lrow * ld + tb.api[jsel[s]]] : xlast[s];
-        xj[s] = fminf(fmaxf(v, jlo[s]), jhi[s]);
+        xlast = xl(s, lastp, t_seq);
+        const float v = (kp.x0 && !(seq && t_seq > 0)) ? kp.x0[lrow * ld + tb.api[jsel(s)]] : xlast;
+        xj[s] = fminf(fmaxf(v, BOXw[2 * jo_[s]]), BOXw[2 * jo_[s] + 1]);
       } else if (jfix[s]) {
-        xj[s] = tb.mult[jsel[s]] * kp.fixed[irow * kp.n_fixed + tb.src_idx[jsel[s]]] + tb.off[jsel[s]];
+        xj[s] = tb.mult[jsel(s)] * kp.fixed[irow * kp.n_fixed + tb.src_idx[jsel(s)]] + tb.off[jsel(s)];
       }
       xacc[s] = xj[s];
+      if (jin[s]) XLl[jo_[s]] = xlast;
     }
     if (MIMIC) {
 #pragma unroll
@@ -341,6 +358,9 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
           ++idx;
         }
     }
+    FS32[1] = (int32_t)nst;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   };
   // target vector and weight of one term (optimizer.py:246, 479-507)
   auto term_target = [&](int row, float (&tv)[3], float& wgt) {
@@ -349,7 +369,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     wgt = 1.f;
     if (dexpilot) {
       if (row < n_pair) {
-        if ((nst >> row) & 1u) {
+        if ((f_nst() >> row) & 1u) {
           const float dist = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
           const float eta = row < len_s1 ? kp.eta1 : kp.eta2;
 #pragma unroll
@@ -369,6 +389,14 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     }
   };
 
+  // idle rows run the passes on stale data: their bookkeeping block must address valid rows (row 0) from the start
+  FS64[0] = 0;
+  FS64[1] = 0;
+  FS64[2] = 0;
+  FS32[0] = 0;
+  FS32[1] = 0;
+  if (l < NMAX) XLl[l] = 0.f;
+  if (NJ2 > 1 && l + 16 < NMAX) XLl[l + 16] = 0.f;
   // frames on the fixed base never move
   if (l < tb.n_base_frame) {
 #pragma unroll
@@ -540,7 +568,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 #pragma unroll
     for (int s = 0; s < NJ2; ++s)
       if (jopt[s]) {
-        const double dx = (double)xj[s] - (double)xlast[s];
+        const double dx = (double)xj[s] - (double)XLl[jo_[s]];
         Fv += (double)delta * dx * dx;
       }
     Fv = row_sum64(Fv);
@@ -936,7 +964,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       // F(x0) hold 91 % of the frames with >= 15 iterations)
       const double F0 = terms();
       if (active) {
-        if (l == 0) kp.screen[lrow] = (float)F0;
+        if (l == 0) kp.screen[f_lrow()] = (float)F0;
         screen_acc += (l == 0) ? (float)F0 : 0.f;
         active = false;
         done = true;
@@ -996,7 +1024,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 #pragma unroll
         for (int s = 0; s < NJ2; ++s) {
           xacc[s] = xj[s];
-          gacc[s] = jopt[s] ? gnew[s] + 2.f * delta * (xj[s] - xlast[s]) : 0.f;
+          gacc[s] = jopt[s] ? gnew[s] + 2.f * delta * (xj[s] - XLl[jo_[s]]) : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i)
@@ -1010,7 +1038,8 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       bool fr[NJ2];
 #pragma unroll
       for (int s = 0; s < NJ2; ++s) {
-        const bool act = (xacc[s] <= jlo[s] && gacc[s] > 0) || (xacc[s] >= jhi[s] && gacc[s] < 0);
+        const float2 bx = *reinterpret_cast<const float2*>(BOXw + 2 * (jin[s] ? jo_[s] : 0));
+        const bool act = (xacc[s] <= bx.x && gacc[s] > 0) || (xacc[s] >= bx.y && gacc[s] < 0);
         fr[s] = jopt[s] && !act;
         if (jin[s]) GVl[jo_[s]] = gacc[s];
       }
@@ -1045,7 +1074,8 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 #pragma unroll
       for (int s = 0; s < NJ2; ++s)
         if (jin[s] && ((freemask >> jo_[s]) & 1u)) {
-          const float xt = fminf(fmaxf(xacc[s] + alpha * dstep[s], jlo[s]), jhi[s]);
+          const float2 bx = *reinterpret_cast<const float2*>(BOXw + 2 * jo_[s]);
+          const float xt = fminf(fmaxf(xacc[s] + alpha * dstep[s], bx.x), bx.y);
           sl = fmaxf(sl, fabsf(xt - xacc[s]));
           xj[s] = xt;
         }
@@ -1072,22 +1102,25 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 #pragma unroll
       for (int s = 0; s < NJ2; ++s)
         if (jopt[s]) {
-          const float v = bad ? xlast[s] : xacc[s];
-          const int api = tb.api[jsel[s]];
+          const float v = bad ? XLl[jo_[s]] : xacc[s];
+          const int api = tb.api[jsel(s)];
+          const int64_t irow = f_irow();
           kp.qout[irow * ld + api] = v;
           if (kp.qout64) kp.qout64[irow * ld + api] = (double)v;
         }
       if (l == 0) {
+        const int64_t irow = f_irow();
         if (kp.status) atomicMax(&kp.status[irow], status);
         if (kp.iters) atomicMax(&kp.iters[irow], my_iters);
         if (kp.fval) atomicAdd(&kp.fval[irow], (float)F);
       }
+      const int t_seq = seq ? FS32[0] : 0;
       if (seq && t_seq + 1 < kp.T) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the next frame's start point is the row just written
-        load_frame(item, t_seq + 1);
+        load_frame(FS64[2], t_seq + 1);
         reset_state();
       } else {
-        if (l == 0 && dexpilot && kp.state && comp == 0) kp.state[lrow] = nst;
+        if (l == 0 && dexpilot && kp.state && comp == 0) kp.state[f_lrow()] = f_nst();
         active = false;
         done = true;
       }
