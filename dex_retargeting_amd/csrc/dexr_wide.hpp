@@ -111,6 +111,9 @@ struct WideLds {
                                                        // the sequence, DexPilot bits (registers are the scarce resource)
   static constexpr int XL = FS + 32;                   // NMAX floats: regularisation target (the frame's start row)
   static constexpr int SLOT = XL + NMAX * 4;
+  // LDS decides the occupancy: two blocks of four waves per CU (160 KB); the 16-row joint grid is built for three
+  static_assert(2 * 4 * (SLOT0 + 4 * SLOT) <= 160 * 1024, "two blocks per CU must fit");
+  static_assert(MIMIC || NMAX != 16 || 3 * (4 * (SLOT0 + 4 * SLOT) + 512) <= 160 * 1024, "three blocks per CU must fit");
   static constexpr int WAVE = SLOT0 + 4 * SLOT;
 };
 
@@ -263,12 +266,12 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   auto f_nst = [&]() -> uint32_t { return (uint32_t)FS32[1]; };
   bool active = false;
   float xj[NJ2], xacc[NJ2];  // own joints: trial value, accepted value (the regularisation target is in LDS: XLl)
-  float gacc[NJ2];                       // own joints: gradient at the accepted point (incl. regulariser)
+  // (the gradient at the accepted point, incl. regulariser, lives in LDS: GVl)
   constexpr int NP = NR / 2;             // column pairs of the local Hessian block
   wv2 Ha[NR][NP];                        // Hessian grid entries (4 i + a, 4 j + b), j <= i, at the accepted point;
                                          // pair jj holds local columns 2 jj, 2 jj + 1 (packed FMAs)
 #pragma unroll
-  for (int s = 0; s < NJ2; ++s) { xj[s] = 0; xacc[s] = 0; gacc[s] = 0; }
+  for (int s = 0; s < NJ2; ++s) { xj[s] = 0; xacc[s] = 0; }
 #pragma unroll
   for (int i = 0; i < NR; ++i)
 #pragma unroll
@@ -1024,7 +1027,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 #pragma unroll
         for (int s = 0; s < NJ2; ++s) {
           xacc[s] = xj[s];
-          gacc[s] = jopt[s] ? gnew[s] + 2.f * delta * (xj[s] - XLl[jo_[s]]) : 0.f;
+          if (jin[s]) GVl[jo_[s]] = jopt[s] ? gnew[s] + 2.f * delta * (xj[s] - XLl[jo_[s]]) : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i)
@@ -1039,9 +1042,9 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 #pragma unroll
       for (int s = 0; s < NJ2; ++s) {
         const float2 bx = *reinterpret_cast<const float2*>(BOXw + 2 * (jin[s] ? jo_[s] : 0));
-        const bool act = (xacc[s] <= bx.x && gacc[s] > 0) || (xacc[s] >= bx.y && gacc[s] < 0);
+        const float ga = GVl[jin[s] ? jo_[s] : 0];
+        const bool act = (xacc[s] <= bx.x && ga > 0) || (xacc[s] >= bx.y && ga < 0);
         fr[s] = jopt[s] && !act;
-        if (jin[s]) GVl[jo_[s]] = gacc[s];
       }
       const unsigned long long b0 = __ballot(fr[0]);
       freemask = (uint32_t)((b0 >> (16 * slot)) & 0xFFFFull);
@@ -1061,7 +1064,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       for (int s = 0; s < NJ2; ++s)
         if (jin[s] && ((freemask >> jo_[s]) & 1u)) {
           dmaxl = fmaxf(dmaxl, fabsf(dstep[s]));
-          gdl -= gacc[s] * dstep[s];
+          gdl -= GVl[jo_[s]] * dstep[s];
           ddl += dstep[s] * dstep[s];
         }
       const float dmax = row_max(dmaxl), gd = row_sum(gdl), dd = row_sum(ddl);
