@@ -1,25 +1,32 @@
-// dexr_wide.hpp -- solve kernel for LARGE DENSE components (9..32 joints, no mimic joints): SIXTEEN LANES PER FRAME.
+// dexr_wide.hpp -- solve kernel for LARGE DENSE components (9..32 joints): SIXTEEN LANES PER FRAME.
 //
 // Why: a launch of the four-lanes-per-frame kernel (dexr_quad.hpp) over 65 536 Shadow-DexPilot frames is bound by its
 // SLOWEST frame, not by its throughput -- a frame that needs 44 iterations is a serial chain of ~56 wave passes of
 // ~37 000 instructions each (0.12 ms per pass, 6.5 ms per launch, while the mean frame needs 5 iterations; see
-// DESIGN.md "tail").  A pass therefore has to become short.  Here a frame is spread over a 16-lane DPP row, a wave
+// DESIGN.md section 4).  A pass therefore has to become short.  Here a frame is spread over a 16-lane DPP row, a wave
 // holds four frames, and every stage of a pass is parallel over the 16 lanes:
-//   * forward kinematics (float64): lane l walks root-to-leaf chain l of the kinematic tree (one finger each; the
-//     shared wrist / free-base prefix is recomputed by every lane), 5-13 joints deep instead of all 24-30 in sequence;
+//   * sines / cosines of all joints (float64), one or two joints per lane; then forward kinematics (float64): lane l
+//     walks root-to-leaf chain l of the kinematic tree (one finger each; the shared wrist / free-base prefix is
+//     recomputed by every lane), 5-13 joints deep instead of all 24-30 in sequence;
 //   * residuals, Huber weights, DexPilot targets: lane t evaluates term t (<= 16 terms per component);
 //   * Jacobian: lane l forms the columns of joints l and l + 16 for the term in flight, accumulates their gradient
-//     entries and second-order vectors, and publishes the four rows (three coordinates + the Huber rank-one row) of
-//     the term's Jacobian in LDS;
+//     entries and second-order vectors, and publishes the four rows (three coordinates + the Huber rank-one row,
+//     pre-multiplied by the square roots of their weights) of the term's Jacobian in LDS;
 //   * Hessian: 2-D cyclic over a 4 x 4 lane grid -- lane (a, b) owns H[r][c], r = a (mod 4), c = b (mod 4), 21 floats
-//     at n = 24 -- accumulated as weighted outer products of the published rows; the second-order (Newton) term is
-//     a_c . CF_r for every revolute ancestor c of r, added once per pass from per-joint sums CF_r;
-//   * Cholesky on that grid: the pivot travels by ds_bpermute, the pivot column by one DPP quad broadcast (row side)
-//     and one ds_bpermute (column side) per local row; triangular solves with quad / stride-4 DPP reductions.
-// The accepted point's Hessian and gradient stay in registers, so a REJECTED step costs no extra pass (the quad kernel
-// re-assembles): every pass evaluates a new trial point.
-// 256 VGPRs and 15 KB of LDS per wave: two waves per SIMD (the 16-row grid: 168 VGPRs, 12 KB, three waves).  Damping /
-// termination rules are those of dexr_quad.hpp.
+//     at n = 24, kept as register pairs (v_pk_fma_f32) -- accumulated as outer products of the published rows; the
+//     second-order (Newton) term is a_c . CF_r for every revolute ancestor c of r, added once per pass from per-joint
+//     sums CF_r;
+//   * Cholesky on that grid: the pivot travels by a DPP quad broadcast + a stride-4 DPP sum, the pivot column by one DPP
+//     quad broadcast (row side) and one ds_bpermute (column side) per local row; the right-hand side rides along as an
+//     extra matrix row (forward substitution for free); backward substitution with stride-4 DPP sums.
+// The accepted point's Hessian stays in registers (its gradient in LDS), so a REJECTED step costs no extra pass (the
+// quad kernel re-assembles): every pass evaluates a new trial point.
+// MIMIC instantiation: the grid is that of the <= 16 optimised VARIABLES; lane v forms and sums the columns of the <= 3
+// joints that move with variable v, the second-order term comes from a host-built list of (joint, revolute ancestor)
+// pairs bucketed by the lane that owns the target entry.  MODCHOL (with MIMIC): the damping rules of dexr_red.hpp.
+// Budgets: 256 VGPRs and 15-20 KB of LDS per wave = two waves per SIMD; the 16-row joint grid is built for three (168
+// VGPRs, 13 KB).  Everything that is read once or twice per pass lives in LDS or the tables, not in registers.
+// Damping / termination rules are those of dexr_quad.hpp.
 #pragma once
 
 #include "dexr_big.hpp"  // sincos_f64
