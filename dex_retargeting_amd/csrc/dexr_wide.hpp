@@ -183,6 +183,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   const int nj = tb.n_joint, nt = tb.n_term;
   const int ng = MIMIC ? tb.n_var : nj;  // rows of the Hessian grid in use
   const int depth = wt.depth;
+  const bool fk_rows3 = wt.n_chain <= 5;  // three lanes per kinematic chain (see fk)
   const float delta = kp.norm_delta;
   const int64_t nB = kp.bucket ? (int64_t)kp.bucket[1] : kp.B;
   const int64_t pbase = kp.bucket ? (int64_t)kp.bucket[0] : 0;
@@ -446,6 +447,63 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (fk_rows3) {
+      // <= 5 chains (every shipped hand): THREE lanes per chain, lane 3 c + i carries row i of the chain's rotation and
+      // coordinate i of its position -- a joint costs 16 float64 operations per lane instead of 48, and 15 of the 16
+      // lanes work instead of 5
+      const int ch = l / 3, ri = l - 3 * ch;
+      double r0 = ri == 0 ? 1.0 : 0.0, r1 = ri == 1 ? 1.0 : 0.0, r2 = ri == 2 ? 1.0 : 0.0, pi = 0.0;
+      unsigned cb = depth > 0 ? CH[ch * 16] : 0xFFu;
+      int kf = cb != 0xFFu ? (int)(cb & 0x7Fu) : 0;
+      float4 x0 = *reinterpret_cast<const float4*>(XT + kf * 16);
+      float4 x1 = *reinterpret_cast<const float4*>(XT + kf * 16 + 4);
+      float4 x2 = *reinterpret_cast<const float4*>(XT + kf * 16 + 8);
+      float4 x3 = *reinterpret_cast<const float4*>(XT + kf * 16 + 12);
+      double scs = SCl[2 * kf], scc = SCl[2 * kf + 1];
+#pragma clang loop unroll(disable) vectorize(disable)
+      for (int s = 0; s < depth; ++s) {
+        const unsigned cbn = (s + 1 < depth) ? CH[ch * 16 + s + 1] : 0xFFu;
+        const int kn = cbn != 0xFFu ? (int)(cbn & 0x7Fu) : 0;
+        const float4 y0 = *reinterpret_cast<const float4*>(XT + kn * 16);
+        const float4 y1 = *reinterpret_cast<const float4*>(XT + kn * 16 + 4);
+        const float4 y2 = *reinterpret_cast<const float4*>(XT + kn * 16 + 8);
+        const float4 y3 = *reinterpret_cast<const float4*>(XT + kn * 16 + 12);
+        const double scsn = SCl[2 * kn], sccn = SCl[2 * kn + 1];
+        if (cb != 0xFFu) {
+          const int k = (int)(cb & 0x7Fu);
+          pi += r0 * (double)x2.y + r1 * (double)x2.z + r2 * (double)x2.w;  // X[9..11]: translation
+          const double n0 = r0 * (double)x0.x + r1 * (double)x0.w + r2 * (double)x1.z;  // X[0], X[3], X[6]
+          const double n1 = r0 * (double)x0.y + r1 * (double)x1.x + r2 * (double)x1.w;  // X[1], X[4], X[7]
+          const double n2 = r0 * (double)x0.z + r1 * (double)x1.y + r2 * (double)x2.x;  // X[2], X[5], X[8]
+          if ((revmask >> k) & 1u) {
+            r0 = scc * n0 + scs * n1;
+            r1 = scc * n1 - scs * n0;
+            r2 = n2;
+          } else {
+            r0 = n0;
+            r1 = n1;
+            r2 = n2;
+            pi += scs * n2;
+          }
+          if (cb & 0x80u) {  // this chain publishes the joint: each of its lanes its own coordinate
+            AXl[k * 4 + ri] = (float)r2;
+            OGl[k * 4 + ri] = (float)pi;
+            const int fbe = __float_as_int(x3.x);
+            const int fb = fbe & 0xFF, fe = fbe >> 8;
+            for (int f = fb; f < fe; ++f) {
+              const float4 fo = *reinterpret_cast<const float4*>(FO + f * 4);
+              Pl[f * 3 + ri] = pi + r0 * (double)fo.x + r1 * (double)fo.y + r2 * (double)fo.z;
+            }
+          }
+        }
+        cb = cbn;
+        x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+        scs = scsn; scc = sccn;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      return;
+    }
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pp[3] = {0, 0, 0};
     // the tables of step s + 1 are fetched while step s is computed (two LDS round trips per step off the chain) --
     // except in the three-waves-per-SIMD build of the 16-row grid, where the 20 extra live registers spill
