@@ -159,9 +159,10 @@ class Workload:
                 "tile_max_mean": float(tm.mean()),
                 "active_lane_fraction": float((it[: len(tm) * 64] + 1).sum() / (64.0 * (tm + 1).sum()))}
 
-    def timed(self, batches, steps, warmup, opts=None, pipe=None, dist=None):
+    def timed(self, batches, steps, warmup, opts=None, pipe=None, comm=None):
         """warmup untimed steps, then exactly `steps` steps bracketed by barrier + synchronize; returns
-        (elapsed wall seconds, mean launch ms from HIP events on the launch stream)."""
+        (elapsed wall seconds = MAX over ranks, mean launch ms from HIP events on the launch stream).  `comm` is the
+        native communicator (libdexr: dexr_comm_barrier / dexr_comm_max_f64 on RCCL); `pipe` a NativeGather."""
         torch = self.torch
         n = [0]
 
@@ -177,10 +178,9 @@ class Workload:
             step()
         if pipe is not None:
             pipe.finish()
-            n[0] = (n[0] + pipe.G - 1) // pipe.G * pipe.G  # the timed steps start a fresh group
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        if dist is not None:
-            dist.barrier()
+        if comm is not None:
+            comm.barrier(self.stream.cuda_stream)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ev0.record(self.stream)
@@ -190,14 +190,12 @@ class Workload:
         if pipe is not None:
             pipe.finish()
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        if comm is not None:
+            comm.barrier(self.stream.cuda_stream)
         elapsed = time.perf_counter() - t0
         kernel_ms = float(ev0.elapsed_time(ev1)) / steps
-        if dist is not None:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
+        if comm is not None:
+            elapsed = float(comm.max_f64([elapsed], self.stream.cuda_stream)[0])
         return elapsed, kernel_ms
 
     def timed_two_streams(self, batches, steps, warmup):
@@ -337,6 +335,94 @@ def sequence_record(wl, torch, T=100, reps=3):
     return out
 
 
+ONLINE_ROBOTS = [("teleop/allegro_hand_right.yml", "Allegro vector (BASELINE configs[0])"),
+                 ("teleop/shadow_hand_right.yml", "Shadow vector"),
+                 ("teleop/leap_hand_right.yml", "LEAP vector"),
+                 ("teleop/allegro_hand_right_dexpilot.yml", "Allegro DexPilot"),
+                 ("teleop/shadow_hand_right_dexpilot.yml", "Shadow DexPilot")]
+
+
+def online_run(rel):
+    """The reference's own benchmark shape (/root/reference/example/profiling/profile_online_retargeting.py:18-36,50-73):
+    the 621-frame human fixture, ONE SeqRetargeting.retarget(ref_value) call per frame (B = 1, host arrays in and out),
+    only the call itself inside the timer.  Returns per-frame seconds, the answers, and the per-frame seconds of the bare
+    C-ABI call (dexr_retarget through ctypes, same inputs) for the same frames."""
+    import bench_data
+    from dex_retargeting_amd.retargeting_config import RetargetingConfig
+
+    data = np.load(bench_data.HUMAN_FIXTURE)
+    seq = RetargetingConfig.load_from_file(os.path.join(bench_data.CONFIG_DIR, rel)).build()
+    opt = seq.optimizer
+    indices = opt.target_link_human_indices
+    position = opt.retargeting_type == "POSITION"
+    # untimed: compile the tables, create the device model and run one call through the handle's staging buffers
+    # (through the C-ABI directly, so that neither last_qpos nor the DexPilot state of `seq` has seen a frame)
+    r0 = data[0][indices, :] if position else data[0][indices[1, :], :] - data[0][indices[0, :], :]
+    opt.device_model().retarget(r0[None].astype(np.float32), None, seq.last_qpos[None].astype(np.float32),
+                                state=np.zeros(1, np.uint32) if opt.retargeting_type == "DEXPILOT" else None)
+    dt, qs, refs, lasts = [], [], [], []
+    for joint_pos in data:
+        ref_value = joint_pos[indices, :] if position else joint_pos[indices[1, :], :] - joint_pos[indices[0, :], :]
+        lasts.append(np.clip(seq.last_qpos, seq.joint_limits[:, 0], seq.joint_limits[:, 1]).astype(np.float32))
+        tic = time.perf_counter()
+        q = seq.retarget(ref_value)
+        dt.append(time.perf_counter() - tic)
+        qs.append(q)
+        refs.append(ref_value.astype(np.float32))
+    # the bare C-ABI call on the same (ref, last) pairs: what a C / C++ caller of libdexr.so pays per frame
+    model = opt.device_model()
+    dexpilot = opt.retargeting_type == "DEXPILOT"
+    st = np.zeros(1, np.uint32) if dexpilot else None
+    dt_abi = []
+    for r, l in zip(refs, lasts):
+        r1, l1 = r[None], l[None]
+        tic = time.perf_counter()
+        model.retarget(r1, None, l1, state=st)
+        dt_abi.append(time.perf_counter() - tic)
+    return np.array(dt), np.array(qs), np.array(dt_abi), np.array(refs), np.array(lasts), seq
+
+
+def online_record(no_cpu=False):
+    """Sub-record `online_teleop` (BASELINE configs[0]; SURVEY.md row 13 MEASUREMENT TEMPLATE)."""
+    out = {"frames": 621, "protocol": "profile_online_retargeting.py:18-36: one SeqRetargeting.retarget(ref_value) per fixture "
+                                    "frame, perf_counter around the call only, B = 1, host arrays",
+           "robots": {}}
+    for rel, title in ONLINE_ROBOTS:
+        try:
+            dt, qs, dt_abi, refs, lasts, seq = online_run(rel)
+        except Exception as e:  # never lose the headline line to a sub-record
+            out["robots"][rel] = {"error": repr(e)}
+            continue
+        rec = {"title": title, "fps": len(dt) / dt.sum(), "mean_ms": float(dt.mean() * 1e3),
+               "p50_ms": float(np.percentile(dt, 50) * 1e3), "p99_ms": float(np.percentile(dt, 99) * 1e3),
+               "max_ms": float(dt.max() * 1e3),
+               "c_abi_call": {"mean_ms": float(dt_abi.mean() * 1e3), "p50_ms": float(np.percentile(dt_abi, 50) * 1e3),
+                              "p99_ms": float(np.percentile(dt_abi, 99) * 1e3),
+                              "note": "dexr_retarget (host pointers) alone, through ctypes: pack -> one H2D -> solve "
+                                      "kernel -> one D2H on the handle's private stream -> hipStreamSynchronize"}}
+        if rel == ONLINE_ROBOTS[0][0] and not no_cpu:
+            # the CPU port on the SAME loop (checker code, imported here, after every GPU timing of this record)
+            from oracle import cases, solvers
+
+            prob = cases.problem_from_config(rel)
+            n_cpu = 150
+            last = lasts[0].astype(np.float64)
+            t_cpu, dq = [], []
+            lo, hi = seq.joint_limits[:, 0], seq.joint_limits[:, 1]
+            for i in range(n_cpu):
+                tic = time.perf_counter()
+                q_ref, _ = solvers.solve_ref_as_configured(prob, refs[i][None], None, np.clip(last, lo, hi)[None].astype(np.float32))
+                t_cpu.append(time.perf_counter() - tic)
+                last = q_ref[0].astype(np.float64)
+            t_cpu = np.array(t_cpu)
+            rec["cpu_port_same_loop"] = {"frames": n_cpu, "fps": n_cpu / t_cpu.sum(), "mean_ms": float(t_cpu.mean() * 1e3),
+                                         "p99_ms": float(np.percentile(t_cpu, 99) * 1e3), "kind": "port", "cores": 1,
+                                         "note": "oracle restatement of the objective + scipy SLSQP at the reference's ftol, "
+                                                 "its own warm-start chain over the first 150 fixture frames"}
+        out["robots"][rel] = rec
+    return out
+
+
 def parity_block(wl, batch, q_gpu, n_par, n_slsqp):
     """Checker (oracle) section: max |dq| against the float64 oracle minimiser of F on the first n_par frames of
     `batch`, and the distance to the reference-as-configured SLSQP answers on the first n_slsqp."""
@@ -387,25 +473,57 @@ def parity_block(wl, batch, q_gpu, n_par, n_slsqp):
     return out, prob, ref, last, kw_for
 
 
-def run_single(args):
-    import torch
-
+def job_env(args):
+    """(rank, local_rank, world, launched): read from the environment torch.distributed.run sets."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    return rank, local_rank, world, os.environ.get("RANK") is not None
+
+
+def gather_records(timed_fn, comm, B, n_cols, dev, steps, warmup, world):
+    """The N > 1 figures (also taken with ONE rank when launched by torch.distributed.run, so that the RCCL side runs on a
+    1-GPU box): one dexr_allgather per step.  Returns (elapsed, kernel_ms, record dict).
+
+    headline  = the collective on a second HIP stream, ordered after the solve by an event: the next step's solve
+                overlaps it; every gather has completed when the timed region ends;
+    secondary = the collective on the solve stream itself (strictly serial: what one captured graph of
+                [solve, all-gather] per step does)."""
+    from dex_retargeting_amd.distributed import NativeGather
+
+    depth = min(8, steps + warmup + 1)
+    elapsed, kernel_ms = timed_fn(NativeGather(comm, B, n_cols, dev, depth=depth, overlap=True))
+    e2, _ = timed_fn(NativeGather(comm, B, n_cols, dev, depth=depth, overlap=False))
+    shard_mb = B * n_cols * 4 / 1e6
+    rec = {"collective": "dexr_allgather (C-ABI of libdexr.so -> RCCL ncclAllGather, bound with dlopen), one per step, "
+                         "enqueued on a second HIP stream behind an event recorded after the solve; all gathers "
+                         "complete inside the timed region",
+           "rccl_world_size": world, "rccl_version": comm.rccl_version(),
+           "gather_on_solve_stream": {"value": world * B * steps / e2, "unit": "frames/s", "ms_per_step": e2 / steps * 1e3,
+                                      "note": "same steps with the all-gather enqueued on the solve stream (serial)"},
+           "xgmi": {"shard_MB_per_rank_per_step": shard_mb, "received_MB_per_gpu_per_step": shard_mb * (world - 1),
+                    "note": "every GPU receives (N-1) shards per step over its 7 xGMI links (~76.8 GB/s per link and "
+                            "direction, 537 GB/s aggregate ingest at best): the all-gather lower bound per step is "
+                            f"{shard_mb * (world - 1) / 537.0 * 1e3:.1f} us at N={world} if all links carry it, "
+                            f"{shard_mb * (world - 1) / 76.8 * 1e3:.1f} us on a single ring direction"}}
+    return elapsed, kernel_ms, rec
+
+
+def run_single(args):
+    import torch
+
+    rank, local_rank, world, launched = job_env(args)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
+    comm = None
     # launched by torch.distributed.run (RANK set): take the N > 1 path even with one rank, so that the RCCL side of
     # this script can be exercised on a 1-GPU box too
-    if world > 1 or (os.environ.get("RANK") is not None and os.environ.get("DEXR_BENCH_DIST", "1") != "0"):
-        import torch.distributed as dist
+    if world > 1 or (launched and os.environ.get("DEXR_BENCH_DIST", "1") != "0"):
+        from dex_retargeting_amd.distributed import native_comm
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        comm = native_comm(rank, world)
 
     from dex_retargeting_amd import _lib
 
@@ -414,25 +532,13 @@ def run_single(args):
     diag = wl.diagnostics(wl.tracking)
 
     # ---- headline: float32 tracking -----------------------------------------------------------------------------
-    pipe, pipelined = None, None
-    if dist is not None:
-        from dex_retargeting_amd.distributed import PipelinedAllGather
-
-        # SURVEY.md 8d definition: ONE RCCL all-gather of this rank's (B, n_opt) result per step, issued right after the
-        # solve that produced it (RCCL's stream waits for the solve; the next solve writes another buffer); every
-        # gather has completed when the timed region ends.
-        pipe = PipelinedAllGather(B, wl.n_opt, torch.float32, dev, depth=min(16, args.steps + args.warmup + 2),
-                                  steps_per_gather=1)
-    elapsed, kernel_ms = wl.timed(wl.tracking, args.steps, args.warmup, pipe=pipe, dist=dist)
-    if dist is not None:
-        # second figure: four steps share one collective (fewer, larger collectives; the host cost of issuing an async
-        # collective through torch.distributed, ~100 us, exceeds one 80 us solve)
-        G = int(os.environ.get("DEXR_BENCH_GATHER_EVERY", "4"))
-        pipe4 = PipelinedAllGather(B, wl.n_opt, torch.float32, dev, depth=min(16, (args.steps + args.warmup) // G + 3),
-                                   steps_per_gather=G)
-        e4, k4 = wl.timed(wl.tracking, args.steps, args.warmup, pipe=pipe4, dist=dist)
-        pipelined = {"value": world * B * args.steps / e4, "unit": "frames/s", "ms_per_step": e4 / args.steps * 1e3,
-                     "gather_every_steps": G, "note": f"{G} steps share one all-gather of {G} x B rows per rank"}
+    coll = None
+    if comm is not None:
+        elapsed, kernel_ms, coll = gather_records(
+            lambda pipe: wl.timed(wl.tracking, args.steps, args.warmup, pipe=pipe, comm=comm),
+            comm, B, wl.n_opt, dev, args.steps, args.warmup, world)
+    else:
+        elapsed, kernel_ms = wl.timed(wl.tracking, args.steps, args.warmup)
     # per-step answers of the last timed step's batch for the parity check
     last_batch = wl.tracking[(args.steps + args.warmup - 1) % N_BATCHES]
     wl.launch(last_batch, wl.t_q)
@@ -476,6 +582,12 @@ def run_single(args):
             sub["sequence_mode"] = sequence_record(wl, torch)
         except Exception as e:  # never lose the headline line to a sub-record
             sub["sequence_mode"] = {"error": repr(e)}
+    if rank == 0 and not args.headline_only and args.workload == "allegro_vector":
+        torch.cuda.synchronize()
+        try:
+            sub["online_teleop"] = online_record(no_cpu=args.no_cpu_baseline)
+        except Exception as e:
+            sub["online_teleop"] = {"error": repr(e)}
     also = {}
     if rank == 0 and not args.headline_only and args.workload == "allegro_vector":
         for name in ("shadow_dexpilot", "leap_position"):
@@ -495,13 +607,10 @@ def run_single(args):
                            "roofline": w2.roofline(k2, d2["iters_mean"]), "two_streams": ts2})
 
     if rank != 0:
-        dist.destroy_process_group()
+        comm.close()
         return
 
     frames = world * B * args.steps
-    coll = "none"
-    if dist is not None:
-        coll = "rccl all_gather of qpos, one per step, issued after the solve and complete when the timed region ends"
     out = {
         "metric": json.load(open(os.path.join(REPO, "BASELINE.json")))["metric"],
         "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -509,8 +618,9 @@ def run_single(args):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{wl.title}, {B} frames/GPU, human-keypoint refs (fixture frame b mod 621 + 2 mm noise), "
                                f"warm start = previous frame's solution; {N_BATCHES} staged batches rotated over the steps",
-                   "config_file": wl.rel, "batch_per_gpu": B, "n_opt": wl.n_opt, "n_ref": wl.n_ref, "collective": coll,
-                   "rccl_world_size": world if dist is not None else None},
+                   "config_file": wl.rel, "batch_per_gpu": B, "n_opt": wl.n_opt, "n_ref": wl.n_ref,
+                   "collective": "none" if coll is None else coll["collective"],
+                   "rccl_world_size": None if coll is None else coll["rccl_world_size"]},
         "solver": dict(diag, tol_rad=2e-6, newton=1),
         "roofline": dict(wl.roofline(kernel_ms, diag["iters_mean"], world=world),
                          traffic_note="bytes per launch from the rocprofv3 --pmc passes in profiles/ (same command, same "
@@ -518,8 +628,8 @@ def run_single(args):
                          note="path is FP32 VALU/latency bound (n_dof <= 24 per lane, no dense contraction); the HBM "
                               "fraction is reported as north_star asks, see DESIGN.md section 4"),
     }
-    if pipelined is not None:
-        out["pipelined_gather"] = pipelined
+    if coll is not None:
+        out["multi_gpu"] = coll
     out.update(sub)
 
     # ---- checker sections (oracle = checker only; nothing above this line touches oracle/) -------------------------
@@ -577,8 +687,47 @@ def run_single(args):
                     "sample": f"first {res[0]} frames, {procs} processes x {per_proc} frames started together, same "
                               f"solver as cpu_baseline; {avail} CPUs available to the process"}
     print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.close()
+
+
+def relaunch(args):
+    """`python bench.py --gpus N` with no launcher around it: start N ranks (one process per GPU) by re-executing this
+    command under torch.distributed.run -- exactly how the driver launches the N > 1 runs."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def dry_run_launch(args):
+    """--dry-run-launch: the launch / rendezvous plumbing of an N-rank run with NO GPU work (what the CPU test suite
+    runs with N = 2): every rank joins the job's store, the 128-byte id rank 0 publishes reaches every rank (the same
+    exchange native_comm() performs for the RCCL unique id), a gloo all-gather collects one row per rank, and rank 0
+    prints the line."""
+    import torch
+    import torch.distributed as dist
+
+    from dex_retargeting_amd.distributed import exchange_bytes, rendezvous_store
+
+    rank, local_rank, world, launched = job_env(args)
+    store = rendezvous_store(rank, world)
+    uid = exchange_bytes(store, rank, "dexr/dry_run_id", lambda: bytes(range(128)))
+    dist.init_process_group("gloo", rank=rank, world_size=world, store=dist.PrefixStore("dexr_dry", store))
+    mine = torch.tensor([[float(rank), float(local_rank), float(len(uid)), float(sum(uid))]], dtype=torch.float64)
+    full = torch.empty((world, 4), dtype=torch.float64)
+    dist.all_gather_into_tensor(full, mine)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "world_size": world, "launched_by_torchrun": launched,
+                          "ranks": full[:, 0].tolist(), "local_ranks": full[:, 1].tolist(),
+                          "id_bytes": full[:, 2].tolist(), "id_checksum": full[:, 3].tolist()}))
+    dist.destroy_process_group()
 
 
 def main():
@@ -591,7 +740,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every host-CPU solve (baseline and SLSQP distance)")
     ap.add_argument("--headline-only", action="store_true", help="skip the f64 / cold-start / other-config sub-records")
     ap.add_argument("--cpu-sample", type=int, default=1200, help="frames of the workload timed on the host CPU")
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="launch + rendezvous plumbing only (no GPU work): used by the CPU tests of the N > 1 launcher")
     args = ap.parse_args()
+    if args.gpus > 1 and os.environ.get("RANK") is None:
+        return relaunch(args)  # does not return
+    if args.dry_run_launch:
+        return dry_run_launch(args)
     if args.workload == "mixed_fleet":
         import bench_fleet
 

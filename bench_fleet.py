@@ -27,20 +27,16 @@ def run(args):
     from dex_retargeting_amd.fleet import MixedFleet
     from dex_retargeting_amd.retargeting_config import RetargetingConfig
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    from bench import gather_records, job_env
+
+    rank, local_rank, world, launched = job_env(args)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or (os.environ.get("RANK") is not None and os.environ.get("DEXR_BENCH_DIST", "1") != "0"):
-        import torch.distributed as dist
+    comm = None
+    if world > 1 or (launched and os.environ.get("DEXR_BENCH_DIST", "1") != "0"):
+        from dex_retargeting_amd.distributed import native_comm
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        comm = native_comm(rank, world)
 
     RetargetingConfig.set_default_urdf_dir(str(DEFAULT_URDF_DIR))
     seqs = [RetargetingConfig.load_from_file(os.path.join(bench_data.CONFIG_DIR, r)).build() for r in FLEET]
@@ -66,52 +62,54 @@ def run(args):
     t_state = torch.zeros(B, dtype=torch.int32, device=dev)
     t_out = torch.zeros((B, fleet.n_max), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream()
-    pipe = None
-    if dist is not None:
-        from dex_retargeting_amd.distributed import PipelinedAllGather
+    last_b = [None]
 
-        pipe = PipelinedAllGather(B, fleet.n_max, torch.float32, dev, depth=min(16, args.steps + args.warmup + 2),
-                                  steps_per_gather=1)
-    n = [0]
+    def timed(pipe):
+        n = [0]
 
-    def step():
-        k = n[0]
-        b = batches[k % N_BATCHES]
-        t_state.copy_(b["t_state0"])
-        out = t_out if pipe is None else pipe.shard(k)
-        fleet.retarget(b["t_mid"], b["t_kp"], b["t_last"], t_state, out=out)
+        def step():
+            k = n[0]
+            b = batches[k % N_BATCHES]
+            t_state.copy_(b["t_state0"])
+            out = t_out if pipe is None else pipe.shard(k)
+            fleet.retarget(b["t_mid"], b["t_kp"], b["t_last"], t_state, out=out)
+            if pipe is not None:
+                pipe.gather(k)
+            n[0] += 1
+            last_b[0] = b
+
+        for _ in range(args.warmup):
+            step()
         if pipe is not None:
-            pipe.gather(k)
-        n[0] += 1
-        return b
+            pipe.finish()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if comm is not None:
+            comm.barrier(stream.cuda_stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(args.steps):
+            step()
+        ev1.record(stream)
+        if pipe is not None:
+            pipe.finish()
+        torch.cuda.synchronize()
+        if comm is not None:
+            comm.barrier(stream.cuda_stream)
+        elapsed = time.perf_counter() - t0
+        if comm is not None:
+            elapsed = float(comm.max_f64([elapsed], stream.cuda_stream)[0])
+        return elapsed, float(ev0.elapsed_time(ev1)) / args.steps
 
-    for _ in range(args.warmup):
-        step()
-    if pipe is not None:
-        pipe.finish()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        last_b = step()
-    ev1.record(stream)
-    if pipe is not None:
-        pipe.finish()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    step_ms = float(ev0.elapsed_time(ev1)) / args.steps
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    coll = None
+    if comm is not None:
+        elapsed, step_ms, coll = gather_records(timed, comm, B, fleet.n_max, dev, args.steps, args.warmup, world)
+    else:
+        elapsed, step_ms = timed(None)
     if rank != 0:
-        dist.destroy_process_group()
+        comm.close()
         return
+    last_b = last_b[0]
     # answers of the last step's batch (re-issued into a plain buffer) for the checker
     t_state.copy_(last_b["t_state0"])
     q = fleet.retarget(last_b["t_mid"], last_b["t_kp"], last_b["t_last"], t_state, out=torch.zeros_like(t_out)).cpu().numpy()
@@ -128,8 +126,8 @@ def run(args):
         "config": {"workload": f"{WORKLOADS['mixed_fleet'][1]}; {B} frames/GPU, model id uniform at random per frame, "
                                f"human-keypoint refs, warm start = previous frame's solution; {N_BATCHES} staged batches rotated",
                    "models": FLEET, "batch_per_gpu": B,
-                   "collective": "none" if dist is None else "rccl all_gather of the (B, n_max) qpos rows, one per step",
-                   "rccl_world_size": world if dist is not None else None},
+                   "collective": "none" if coll is None else coll["collective"],
+                   "rccl_world_size": None if coll is None else coll["rccl_world_size"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": step_ms,
                      "algorithmic_bytes_per_frame": bpf,
@@ -162,6 +160,8 @@ def run(args):
     if cpu_n:
         out_json["cpu_baseline"] = {"value": cpu_n / cpu_t, "unit": "frames/s", "cores": 1, "kind": "port",
                                     "sample": "60 frames of each of the four models, reference-as-configured port"}
+    if coll is not None:
+        out_json["multi_gpu"] = coll
     print(json.dumps(out_json))
-    if dist is not None:
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.close()

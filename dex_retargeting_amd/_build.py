@@ -55,7 +55,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     objs = []
     api_s, api_o = os.path.join(CSRC, "dexr_api.hip"), os.path.join(BUILD, "dexr_api.o")
     objs.append(api_o)
-    if force or _stale(api_o, [api_s] + HEADERS):
+    if force or _stale(api_o, [api_s, os.path.join(CSRC, "dexr_hostctx.hpp")] + HEADERS):
         jobs.append((api_s, api_o, []))
     prep_s, prep_o = os.path.join(CSRC, "dexr_prep.hip"), os.path.join(BUILD, "dexr_prep.o")
     objs.append(prep_o)
@@ -65,6 +65,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     objs.append(aux_o)
     if force or _stale(aux_o, [aux_s, os.path.join(INCLUDE, "dexr.h")]):
         jobs.append((aux_s, aux_o, []))
+    comm_s, comm_o = os.path.join(CSRC, "dexr_comm.hip"), os.path.join(BUILD, "dexr_comm.o")
+    objs.append(comm_o)
+    if force or _stale(comm_o, [comm_s, os.path.join(INCLUDE, "dexr.h")]):
+        jobs.append((comm_s, comm_o, []))
     inst_s = os.path.join(CSRC, "dexr_inst.hip")
     # developer shortcut: DEXR_BUILD_ONLY="4,8" rebuilds only those buckets and reuses the other objects as they are
     # (only valid while KernelParams / the launcher signature are unchanged)
@@ -145,7 +149,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(compile_one, jobs))
     if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")

@@ -41,7 +41,9 @@ EXPORTS = ["dexr_last_error", "dexr_version", "dexr_device_count", "dexr_default
            "dexr_retarget_dev", "dexr_retarget_seq_dev", "dexr_seq_compose_dev", "dexr_fleet_workspace_bytes",
            "dexr_retarget_multi_dev", "dexr_retarget", "dexr_retarget_f64",
            "dexr_retarget_kp_dev", "dexr_retarget_kp", "dexr_eval", "dexr_fk", "dexr_mano_keypoints_dev",
-           "dexr_mano_keypoints"]
+           "dexr_mano_keypoints", "dexr_comm_unique_id", "dexr_comm_create", "dexr_comm_destroy", "dexr_comm_info",
+           "dexr_allgather", "dexr_comm_max_f64", "dexr_comm_barrier"]
+UNIQUE_ID_BYTES = 128
 
 
 def load() -> C.CDLL:
@@ -92,6 +94,14 @@ def load() -> C.CDLL:
     lib.dexr_fk.argtypes = [vp, i64, f64p, f64p]
     lib.dexr_mano_keypoints_dev.argtypes = [i64, vp, f32p, vp, vp, vp]
     lib.dexr_mano_keypoints.argtypes = [i64, f32p, f32p, f32p, f32p]
+    lib.dexr_comm_unique_id.argtypes = [vp]
+    lib.dexr_comm_create.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(vp)]
+    lib.dexr_comm_destroy.argtypes = [vp]
+    lib.dexr_comm_destroy.restype = None
+    lib.dexr_comm_info.argtypes = [vp, i32p, i32p, i32p]
+    lib.dexr_allgather.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    lib.dexr_comm_max_f64.argtypes = [vp, f64p, C.c_int32, vp]
+    lib.dexr_comm_barrier.argtypes = [vp, vp]
     _lib = lib
     return lib
 
@@ -272,3 +282,47 @@ def retarget_multi_dev(models, B: int, model_id_ptr: int, kp_ptr: int, last_ptr:
                                          state_ptr or None, q_ptr or None, status_ptr or None,
                                          C.byref(opts) if opts is not None else None, ws_ptr or None, ws_bytes,
                                          stream or None))
+
+
+def comm_unique_id() -> bytes:
+    """Rank 0: the RCCL unique id every rank of a communicator has to be handed (dexr_comm_unique_id)."""
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    check(load().dexr_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """Owns one dexr_comm: an RCCL communicator bound to the current HIP device (collective constructor)."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int):
+        if len(unique_id) != UNIQUE_ID_BYTES:
+            raise ValueError(f"unique id must be {UNIQUE_ID_BYTES} bytes")
+        self._h = C.c_void_p()
+        buf = C.create_string_buffer(unique_id, UNIQUE_ID_BYTES)
+        check(load().dexr_comm_create(buf, rank, world, C.byref(self._h)))
+        self.rank, self.world = rank, world
+
+    def close(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value and _lib is not None:
+            _lib.dexr_comm_destroy(h)
+            self._h = None
+
+    __del__ = close
+
+    def rccl_version(self) -> int:
+        v = C.c_int32()
+        check(load().dexr_comm_info(self._h, None, None, C.byref(v)))
+        return int(v.value)
+
+    def allgather(self, send_ptr: int, recv_ptr: int, bytes_per_rank: int, stream: int = 0):
+        """recv[r] = rank r's send block; device addresses; enqueued on `stream` (no synchronisation)."""
+        check(load().dexr_allgather(self._h, send_ptr or None, recv_ptr or None, bytes_per_rank, stream or None))
+
+    def max_f64(self, values, stream: int = 0) -> np.ndarray:
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        check(load().dexr_comm_max_f64(self._h, _ptr(v, C.c_double), len(v), stream or None))
+        return v
+
+    def barrier(self, stream: int = 0):
+        check(load().dexr_comm_barrier(self._h, stream or None))

@@ -3,15 +3,18 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <atomic>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "dexr.h"
+#include "dexr_hostctx.hpp"
 #include "dexr_launch.hpp"
 
 namespace {
@@ -34,16 +37,18 @@ int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(DEXR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));     \
   } while (0)
 
-struct DevBuf {  // RAII device buffer for the host-pointer wrappers
-  void* p = nullptr;
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
-  }
-  hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
-  template <typename T> T* as() { return static_cast<T*>(p); }
-};
-
 }  // namespace
+
+// error reporting for the other translation units of the library (dexr_comm.hip)
+int dexr_set_error(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
 
 struct dexr_model {
   dexr_model_header h;
@@ -85,6 +90,9 @@ struct dexr_model {
   int max_slot = -1;      // deepest saved-transform slot any component uses
   bool has_mimic = false;
   dexr_tuning tune;       // launch / damping parameters (dexr_model_set_tuning); never read from the environment
+  float lam_jump_user = -1.f;  // >= 0: the caller overrode dexr_tuning.lam_jump; otherwise every launch uses the default
+                               // of the kernel family it actually dispatches (family_lam_jump)
+  mutable dexr::HostCtx host;  // private stream + persistent pinned / device staging of the host-pointer entry points
 };
 
 namespace {
@@ -96,6 +104,19 @@ int pick_bucket(int nj) {
   return -1;
 }
 
+// Default damping jump of a kernel family.  The parameter's MEANING differs per family: the quad kernel and the plain
+// sixteen-lane kernel scale the curvature along the failed step (1.0), the others scale mean diag H (3.0 for the small
+// components, 0.3 from 9 joints on).  float64 launches (precision = 1, the polish pass) always run the register kernel.
+enum Family { FAM_REGISTER, FAM_QUAD, FAM_BIG, FAM_RED, FAM_WIDE };
+float family_lam_jump(const dexr_model* m, Family fam) {
+  if (m->lam_jump_user >= 0.f) return m->lam_jump_user;
+  if (fam == FAM_QUAD || (fam == FAM_WIDE && !m->wide_modchol)) return 1.0f;
+  return m->bucket <= 8 ? 3.0f : 0.3f;
+}
+Family selected_family(const dexr_model* m) {
+  return m->red ? FAM_RED : m->wide ? FAM_WIDE : m->quad ? FAM_QUAD : m->big ? FAM_BIG : FAM_REGISTER;
+}
+
 void fill_params(const dexr_model* m, dexr::KernelParams& kp, int64_t B) {
   std::memset(&kp, 0, sizeof(kp));
   const dexr_model_header& h = m->h;
@@ -105,7 +126,7 @@ void fill_params(const dexr_model* m, dexr::KernelParams& kp, int64_t B) {
   // damping dynamics (measured, tools/term_sweep.py): a rejected step raises lambda at least to lam_jump x the mean
   // curvature instead of creeping up by x2, x4, ...; small components also drop it by 10x (not 3x) after a step the
   // model predicted well.  Allegro vector, 65 536 frames: 0.143 -> 0.119 ms; Shadow DexPilot: 19.4 -> 15.4 ms.
-  kp.lam_jump = m->tune.lam_jump;
+  kp.lam_jump = family_lam_jump(m, FAM_REGISTER);  // launch() sets the dispatched family's value
   kp.lam_fastdec = m->tune.lam_fastdec;
   kp.floor_scale = m->tune.floor_scale;
   kp.step_cap = m->tune.step_cap;
@@ -406,12 +427,13 @@ int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStr
   if (kp.B <= 0) return DEXR_OK;
   // fleet buckets / frame sequences / padded rows need the kernels with extended addressing (KernelParams)
   const bool ext = kp.perm != nullptr || kp.bucket != nullptr || kp.T > 0 || kp.ld != kp.n_opt;
-  if (mode == dexr::MODE_SOLVE && !f64 && m->red) return launch_red(m, kp, st);
-  if (mode == dexr::MODE_SOLVE && !f64 && m->wide) return launch_wide(m, kp, st);
-  if (mode == dexr::MODE_SOLVE && !f64 && m->quad) {
-    return launch_quad(m, kp, st);
+  if (mode == dexr::MODE_SOLVE && !f64 && selected_family(m) != FAM_REGISTER) {
+    const Family fam = selected_family(m);
+    kp.lam_jump = family_lam_jump(m, fam);
+    return fam == FAM_RED ? launch_red(m, kp, st) : fam == FAM_WIDE ? launch_wide(m, kp, st)
+         : fam == FAM_QUAD ? launch_quad(m, kp, st) : launch_big(m, kp, st);
   }
-  if (mode == dexr::MODE_SOLVE && !f64 && m->big) return launch_big(m, kp, st);
+  kp.lam_jump = family_lam_jump(m, FAM_REGISTER);
   if (m->bucket == 32 && mode == dexr::MODE_SOLVE) f64 = 1;  // see find_launcher: bucket 32 is float64 only
   const size_t real_sz = f64 ? 8 : 4;
   const size_t per_wave = 64 * real_sz * (size_t)(3 * m->lds_frames + 4 * m->lds_terms);
@@ -696,7 +718,7 @@ int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out) {
   default_tuning(m);
   m->wide_ok = build_wide_tables(m);
   select_kernels(m);
-  if (m->quad || (m->wide && !m->wide_modchol)) m->tune.lam_jump = 1.0f;  // the quad kernel scales the jump by the curvature along the failed step
+  m->tune.lam_jump = family_lam_jump(m, selected_family(m));  // reported value; launches derive it per family
   if (m->bucket < 0) {
     delete m;
     return fail(DEXR_ERR_UNSUPPORTED, "component with %d joints exceeds the largest kernel bucket", maxj);
@@ -767,8 +789,13 @@ int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning) {
     return fail(DEXR_ERR_INVALID, "negative launch parameter");
   if (!(t.step_cap >= 0) || !(t.lam_jump >= 0) || !(t.lam_fastdec >= 0) || !(t.floor_scale >= 0) || !(t.blind_tol_scale >= 0))
     return fail(DEXR_ERR_INVALID, "negative or non-finite damping parameter");
+  // lam_jump: a value that differs from what get_tuning reports is a caller override and then holds for every family;
+  // otherwise each launch keeps using the default of the family it dispatches (which select_kernels may change now)
+  if (tuning->struct_size >= offsetof(dexr_tuning, lam_jump) + sizeof(float) && t.lam_jump != m->tune.lam_jump)
+    m->lam_jump_user = t.lam_jump;
   m->tune = t;
   select_kernels(m);
+  m->tune.lam_jump = family_lam_jump(m, selected_family(m));
   return DEXR_OK;
 }
 
@@ -853,51 +880,41 @@ static int retarget_host(const dexr_model* m, int64_t B, const float* ref, const
   const size_t ref_b = nb * (ref_is_keypoints ? m->h.n_keypoints : m->h.n_ref) * 3 * sizeof(float);
   const size_t fix_b = nb * m->h.n_fixed * sizeof(float);
   const size_t q_b = nb * m->h.n_opt * sizeof(float);
-  DevBuf d_ref, d_fix, d_last, d_state, d_q, d_q64, d_status, d_iters, d_fval;
-  HIP_TRY(d_ref.alloc(ref_b));
-  HIP_TRY(d_fix.alloc(fix_b));
-  HIP_TRY(d_last.alloc(q_b));
-  HIP_TRY(d_q.alloc(q_b));
-  HIP_TRY(d_q64.alloc(q64 ? nb * m->h.n_opt * sizeof(double) : 0));
-  HIP_TRY(d_state.alloc(nb * sizeof(uint32_t)));
-  HIP_TRY(d_status.alloc(nb * sizeof(int32_t)));
-  HIP_TRY(d_iters.alloc(nb * sizeof(int32_t)));
-  HIP_TRY(d_fval.alloc(nb * sizeof(float)));
-  HIP_TRY(hipMemcpy(d_ref.p, ref, ref_b, hipMemcpyHostToDevice));
-  if (fix_b) HIP_TRY(hipMemcpy(d_fix.p, fixed, fix_b, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_last.p, last, q_b, hipMemcpyHostToDevice));
-  if (state) HIP_TRY(hipMemcpy(d_state.p, state, nb * sizeof(uint32_t), hipMemcpyHostToDevice));
-  else HIP_TRY(hipMemset(d_state.p, 0, nb * sizeof(uint32_t)));
-  HIP_TRY(hipMemset(d_status.p, 0, nb * sizeof(int32_t)));
-  HIP_TRY(hipMemset(d_iters.p, 0, nb * sizeof(int32_t)));
-  HIP_TRY(hipMemset(d_fval.p, 0, nb * sizeof(float)));
+  // one packed block, one copy each way, private stream (dexr_hostctx.hpp)
+  std::lock_guard<std::mutex> lock(m->host.mu);
+  dexr::HostCtx& hc = m->host;
+  dexr::Staging sg;
+  const int i_ref = sg.add(dexr::Staging::IN, ref, nullptr, ref_b);
+  const int i_fix = sg.add(dexr::Staging::IN, fixed, nullptr, fix_b);
+  const int i_last = sg.add(dexr::Staging::IN, last, nullptr, q_b);
+  const int i_state = sg.add(dexr::Staging::INOUT, state, state, nb * sizeof(uint32_t));
+  const int i_status = sg.add(dexr::Staging::INOUT, nullptr, status_out, nb * sizeof(int32_t));  // zeroed: the
+  const int i_iters = sg.add(dexr::Staging::INOUT, nullptr, iters_out, nb * sizeof(int32_t));    // kernels combine
+  const int i_fval = sg.add(dexr::Staging::INOUT, nullptr, fval_out, nb * sizeof(float));        // components atomically
+  const int i_q = sg.add(dexr::Staging::OUT, nullptr, q32, q_b);
+  const int i_q64 = sg.add(dexr::Staging::OUT, nullptr, q64, q64 ? nb * m->h.n_opt * sizeof(double) : 0);
+  HIP_TRY(sg.upload(hc));
   dexr::KernelParams kp;
   fill_params(m, kp, B);
   apply_options(m, kp, opt);
-  if (ref_is_keypoints) kp.kpts = d_ref.as<float>();
-  else kp.ref = d_ref.as<float>();
-  kp.fixed = d_fix.as<float>();
-  kp.last = d_last.as<float>();
-  kp.state = d_state.as<uint32_t>();
-  kp.qout = d_q.as<float>();
-  kp.qout64 = q64 ? d_q64.as<double>() : nullptr;
-  kp.status = d_status.as<int32_t>();
-  kp.iters = d_iters.as<int32_t>();
-  kp.fval = d_fval.as<float>();
+  if (ref_is_keypoints) kp.kpts = sg.dev<float>(hc, i_ref);
+  else kp.ref = sg.dev<float>(hc, i_ref);
+  kp.fixed = sg.dev<float>(hc, i_fix);
+  kp.last = sg.dev<float>(hc, i_last);
+  kp.state = sg.dev<uint32_t>(hc, i_state);
+  kp.qout = sg.dev<float>(hc, i_q);
+  kp.qout64 = q64 ? sg.dev<double>(hc, i_q64) : nullptr;
+  kp.status = sg.dev<int32_t>(hc, i_status);
+  kp.iters = sg.dev<int32_t>(hc, i_iters);
+  kp.fval = sg.dev<float>(hc, i_fval);
   if (verify_every_step) kp.blind_tol = 0.f;  // dexr_retarget_f64 is the validation path: every step it reports has been verified
-  int rc = launch(m, dexr::MODE_SOLVE, f64, kp, nullptr);
+  int rc = launch(m, dexr::MODE_SOLVE, f64, kp, hc.st);
   if (rc != DEXR_OK) return rc;
   if (!f64) {
-    rc = polish_launch(m, kp, opt, nullptr);
+    rc = polish_launch(m, kp, opt, hc.st);
     if (rc != DEXR_OK) return rc;
   }
-  HIP_TRY(hipDeviceSynchronize());
-  if (q32) HIP_TRY(hipMemcpy(q32, d_q.p, q_b, hipMemcpyDeviceToHost));
-  if (q64) HIP_TRY(hipMemcpy(q64, d_q64.p, nb * m->h.n_opt * sizeof(double), hipMemcpyDeviceToHost));
-  if (state) HIP_TRY(hipMemcpy(state, d_state.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  if (status_out) HIP_TRY(hipMemcpy(status_out, d_status.p, nb * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (iters_out) HIP_TRY(hipMemcpy(iters_out, d_iters.p, nb * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (fval_out) HIP_TRY(hipMemcpy(fval_out, d_fval.p, nb * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(sg.download(hc));
   return DEXR_OK;
 }
 
@@ -933,37 +950,29 @@ int dexr_eval(const dexr_model* m, int64_t B, const float* ref, const float* fix
   const size_t nb = (size_t)B;
   const size_t ref_b = nb * m->h.n_ref * 3 * sizeof(float), fix_b = nb * m->h.n_fixed * sizeof(float);
   const size_t q_b = nb * m->h.n_opt * sizeof(float), x_b = nb * m->h.n_opt * sizeof(double);
-  DevBuf d_ref, d_fix, d_last, d_x, d_state, d_f, d_g;
-  HIP_TRY(d_ref.alloc(ref_b));
-  HIP_TRY(d_fix.alloc(fix_b));
-  HIP_TRY(d_last.alloc(q_b));
-  HIP_TRY(d_x.alloc(x_b));
-  HIP_TRY(d_state.alloc(nb * sizeof(uint32_t)));
-  HIP_TRY(d_f.alloc(nb * sizeof(double)));
-  HIP_TRY(d_g.alloc(x_b));
-  HIP_TRY(hipMemcpy(d_ref.p, ref, ref_b, hipMemcpyHostToDevice));
-  if (fix_b) HIP_TRY(hipMemcpy(d_fix.p, fixed, fix_b, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_last.p, last, q_b, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_x.p, x, x_b, hipMemcpyHostToDevice));
-  if (state) HIP_TRY(hipMemcpy(d_state.p, state, nb * sizeof(uint32_t), hipMemcpyHostToDevice));
-  else HIP_TRY(hipMemset(d_state.p, 0, nb * sizeof(uint32_t)));
-  HIP_TRY(hipMemset(d_f.p, 0, nb * sizeof(double)));
-  HIP_TRY(hipMemset(d_g.p, 0, x_b));
+  std::lock_guard<std::mutex> lock(m->host.mu);
+  dexr::HostCtx& hc = m->host;
+  dexr::Staging sg;
+  const int i_ref = sg.add(dexr::Staging::IN, ref, nullptr, ref_b);
+  const int i_fix = sg.add(dexr::Staging::IN, fixed, nullptr, fix_b);
+  const int i_last = sg.add(dexr::Staging::IN, last, nullptr, q_b);
+  const int i_x = sg.add(dexr::Staging::IN, x, nullptr, x_b);
+  const int i_state = sg.add(dexr::Staging::INOUT, state, state, nb * sizeof(uint32_t));
+  const int i_f = sg.add(dexr::Staging::INOUT, nullptr, f_out, nb * sizeof(double));  // zeroed: summed over components
+  const int i_g = sg.add(dexr::Staging::INOUT, nullptr, grad_out, x_b);
+  HIP_TRY(sg.upload(hc));
   dexr::KernelParams kp;
   fill_params(m, kp, B);
-  kp.ref = d_ref.as<float>();
-  kp.fixed = d_fix.as<float>();
-  kp.last = d_last.as<float>();
-  kp.xin = d_x.as<double>();
-  kp.state = d_state.as<uint32_t>();
-  kp.f64out = d_f.as<double>();
-  kp.g64out = d_g.as<double>();
-  int rc = launch(m, dexr::MODE_EVAL, 1, kp, nullptr);
+  kp.ref = sg.dev<float>(hc, i_ref);
+  kp.fixed = sg.dev<float>(hc, i_fix);
+  kp.last = sg.dev<float>(hc, i_last);
+  kp.xin = sg.dev<double>(hc, i_x);
+  kp.state = sg.dev<uint32_t>(hc, i_state);
+  kp.f64out = sg.dev<double>(hc, i_f);
+  kp.g64out = sg.dev<double>(hc, i_g);
+  int rc = launch(m, dexr::MODE_EVAL, 1, kp, hc.st);
   if (rc != DEXR_OK) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(f_out, d_f.p, nb * sizeof(double), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(grad_out, d_g.p, x_b, hipMemcpyDeviceToHost));
-  if (state) HIP_TRY(hipMemcpy(state, d_state.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(sg.download(hc));
   return DEXR_OK;
 }
 
@@ -974,19 +983,19 @@ int dexr_fk(const dexr_model* m, int64_t B, const double* q, double* pos_out) {
   if (B == 0) return DEXR_OK;
   const size_t nb = (size_t)B;
   const size_t q_b = nb * m->h.n_q * sizeof(double), p_b = nb * m->h.n_ref * 3 * sizeof(double);
-  DevBuf d_q, d_p;
-  HIP_TRY(d_q.alloc(q_b));
-  HIP_TRY(d_p.alloc(p_b));
-  HIP_TRY(hipMemcpy(d_q.p, q, q_b, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(d_p.p, 0, p_b));
+  std::lock_guard<std::mutex> lock(m->host.mu);
+  dexr::HostCtx& hc = m->host;
+  dexr::Staging sg;
+  const int i_q = sg.add(dexr::Staging::IN, q, nullptr, q_b);
+  const int i_p = sg.add(dexr::Staging::INOUT, nullptr, pos_out, p_b);
+  HIP_TRY(sg.upload(hc));
   dexr::KernelParams kp;
   fill_params(m, kp, B);
-  kp.xin = d_q.as<double>();
-  kp.f64out = d_p.as<double>();
-  int rc = launch(m, dexr::MODE_FK, 1, kp, nullptr);
+  kp.xin = sg.dev<double>(hc, i_q);
+  kp.f64out = sg.dev<double>(hc, i_p);
+  int rc = launch(m, dexr::MODE_FK, 1, kp, hc.st);
   if (rc != DEXR_OK) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(pos_out, d_p.p, p_b, hipMemcpyDeviceToHost));
+  HIP_TRY(sg.download(hc));
   return DEXR_OK;
 }
 
@@ -1052,6 +1061,28 @@ int dexr_seq_compose_dev(int64_t B, int32_t T, int32_t n_q, int32_t n_opt, int32
   return DEXR_OK;
 }
 
+namespace {
+// Fork / join streams for entry points that enqueue INDEPENDENT launches (one per model of a fleet batch): the launches go
+// to internal streams ordered after the caller's stream by one event and the caller's stream is ordered after all of them
+// before the call returns, so the call keeps plain stream semantics while the launches' tails overlap.  Legal inside a
+// stream capture (the internal streams join the capture through the fork event).  One pool per device, lazily created.
+struct ForkPool {
+  std::mutex mu;
+  hipStream_t aux[DEXR_FLEET_MAX_MODELS] = {};
+  hipEvent_t join[DEXR_FLEET_MAX_MODELS] = {};
+  hipEvent_t fork = nullptr;
+};
+ForkPool* fork_pool() {
+  static ForkPool* pools[64] = {};
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!pools[dev]) pools[dev] = new ForkPool();
+  return pools[dev];
+}
+}  // namespace
+
 size_t dexr_fleet_workspace_bytes(int64_t B) { return (dexr_fleet_ws_ints() + (size_t)(B > 0 ? B : 0)) * sizeof(int32_t); }
 
 int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, int64_t B, const int32_t* model_id,
@@ -1081,8 +1112,28 @@ int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, i
   if (status_out) HIP_TRY(hipMemsetAsync(status_out, 0, (size_t)B * sizeof(int32_t), st));
   const int32_t* bucket = ws + 2 * DEXR_FLEET_MAX_MODELS;
   const int32_t* perm = ws + dexr_fleet_ws_ints();
+  // The models' buckets are disjoint rows: their launches are independent.  Model 0 stays on the caller's stream, the
+  // others fork to internal streams, so the slow tail of one model's launch (a few waves) overlaps the bulk of the
+  // next one instead of idling the GPU n_models times per call.
+  ForkPool* fp = n_models > 1 ? fork_pool() : nullptr;
+  std::unique_lock<std::mutex> lock;
+  if (fp) {
+    lock = std::unique_lock<std::mutex>(fp->mu);
+    if (!fp->fork) HIP_TRY(hipEventCreateWithFlags(&fp->fork, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(fp->fork, st));
+  }
+  int rc_all = DEXR_OK;
+  int forked = 0;
   for (int i = 0; i < n_models; ++i) {
     const dexr_model* m = models[i];
+    hipStream_t si = st;
+    if (fp && i > 0) {
+      if (!fp->aux[i]) HIP_TRY(hipStreamCreateWithFlags(&fp->aux[i], hipStreamNonBlocking));
+      if (!fp->join[i]) HIP_TRY(hipEventCreateWithFlags(&fp->join[i], hipEventDisableTiming));
+      si = fp->aux[i];
+      HIP_TRY(hipStreamWaitEvent(si, fp->fork, 0));
+      forked = i;
+    }
     dexr::KernelParams kp;
     fill_params(m, kp, B);  // B: upper bound of the bucket size (launch geometry); the kernel reads the real count
     apply_options(m, kp, opt);
@@ -1094,12 +1145,20 @@ int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, i
     kp.ld = ld;
     kp.perm = perm;
     kp.bucket = bucket + 2 * i;
-    int rc = launch(m, dexr::MODE_SOLVE, 0, kp, st);
-    if (rc != DEXR_OK) return rc;
-    rc = polish_launch(m, kp, opt, st);
-    if (rc != DEXR_OK) return rc;
+    int rc = launch(m, dexr::MODE_SOLVE, 0, kp, si);
+    if (rc == DEXR_OK) rc = polish_launch(m, kp, opt, si);
+    if (rc != DEXR_OK) {  // still join what has been forked, then report
+      rc_all = rc;
+      break;
+    }
   }
-  return DEXR_OK;
+  std::string err = g_err;
+  for (int i = 1; i <= forked; ++i) {
+    HIP_TRY(hipEventRecord(fp->join[i], fp->aux[i]));
+    HIP_TRY(hipStreamWaitEvent(st, fp->join[i], 0));
+  }
+  if (rc_all != DEXR_OK) g_err = err;
+  return rc_all;
 }
 
 int dexr_mano_keypoints_dev(int64_t B, const float* keypoints, const float* operator2mano, float* joint_pos_out,
@@ -1118,17 +1177,19 @@ int dexr_mano_keypoints(int64_t B, const float* keypoints, const float* operator
   if (B < 0) return fail(DEXR_ERR_INVALID, "negative batch");
   if (B == 0) return DEXR_OK;
   const size_t kp_b = (size_t)B * 21 * 3 * sizeof(float), r_b = (size_t)B * 9 * sizeof(float);
-  DevBuf d_in, d_out, d_rot;
-  HIP_TRY(d_in.alloc(kp_b));
-  HIP_TRY(d_out.alloc(kp_b));
-  HIP_TRY(d_rot.alloc(wrist_rot_out ? r_b : 0));
-  HIP_TRY(hipMemcpy(d_in.p, keypoints, kp_b, hipMemcpyHostToDevice));
-  const int rc = dexr_mano_keypoints_dev(B, d_in.as<float>(), operator2mano, d_out.as<float>(),
-                                         wrist_rot_out ? d_rot.as<float>() : nullptr, nullptr);
+  // no model handle on this entry point: one process-wide staging context (never destroyed: the HIP runtime may be
+  // gone by the time static destructors run)
+  static dexr::HostCtx& ctx = *new dexr::HostCtx();
+  std::lock_guard<std::mutex> lock(ctx.mu);
+  dexr::Staging sg;
+  const int i_in = sg.add(dexr::Staging::IN, keypoints, nullptr, kp_b);
+  const int i_out = sg.add(dexr::Staging::OUT, nullptr, joint_pos_out, kp_b);
+  const int i_rot = sg.add(dexr::Staging::OUT, nullptr, wrist_rot_out, wrist_rot_out ? r_b : 0);
+  HIP_TRY(sg.upload(ctx));
+  const int rc = dexr_mano_keypoints_dev(B, sg.dev<float>(ctx, i_in), operator2mano, sg.dev<float>(ctx, i_out),
+                                         wrist_rot_out ? sg.dev<float>(ctx, i_rot) : nullptr, ctx.st);
   if (rc != DEXR_OK) return rc;
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(joint_pos_out, d_out.p, kp_b, hipMemcpyDeviceToHost));
-  if (wrist_rot_out) HIP_TRY(hipMemcpy(wrist_rot_out, d_rot.p, r_b, hipMemcpyDeviceToHost));
+  HIP_TRY(sg.download(ctx));
   return DEXR_OK;
 }
 

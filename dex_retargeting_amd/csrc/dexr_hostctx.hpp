@@ -1,0 +1,159 @@
+// dexr_hostctx.hpp -- persistent staging for the HOST-pointer entry points of libdexr.so.
+//
+// The reference's callers hand over one frame at a time (SeqRetargeting.retarget, 621 calls in
+// /root/reference/example/profiling/profile_online_retargeting.py:18-36): for that regime the cost of a call is the
+// host path around the kernel, not the kernel.  A context owns
+//   * a private non-blocking stream (no hipDeviceSynchronize: other streams of the process are never stalled),
+//   * one grow-only pinned host buffer and one grow-only device buffer,
+// and a call packs every array into ONE contiguous block laid out  [ inputs | in-out | outputs ]  so that it costs one
+// host-to-device copy of [inputs | in-out], the launches, and one device-to-host copy of [in-out | outputs], all on the
+// private stream, then one hipStreamSynchronize.  No hipMalloc / hipFree on the call path once the buffers have grown.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+
+namespace dexr {
+
+struct HostCtx {
+  std::mutex mu;  // host-pointer calls through one context are serialised (the staging block is shared)
+  hipStream_t st = nullptr;
+  unsigned char* pin = nullptr;
+  size_t pin_bytes = 0;
+  unsigned char* dev = nullptr;
+  size_t dev_bytes = 0;
+  // above this size the pinned mirror is not grown further: the block is copied piecewise from / to the caller's
+  // (pageable) arrays instead; 64 MiB covers 65 536 frames of every shipped model with diagnostics
+  static constexpr size_t PIN_MAX = (size_t)64 << 20;
+
+  ~HostCtx() { release(); }
+  void release() {
+    if (dev) (void)hipFree(dev);
+    if (pin) (void)hipHostFree(pin);
+    if (st) (void)hipStreamDestroy(st);
+    dev = pin = nullptr;
+    st = nullptr;
+    dev_bytes = pin_bytes = 0;
+  }
+  hipError_t ensure(size_t bytes) {
+    hipError_t e = hipSuccess;
+    if (!st) {
+      e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+      if (e != hipSuccess) return e;
+    }
+    if (dev_bytes < bytes) {
+      if (dev) {
+        e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return e;
+        (void)hipFree(dev);
+        dev = nullptr;
+        dev_bytes = 0;
+      }
+      size_t want = dev_bytes ? dev_bytes : 4096;
+      while (want < bytes) want *= 2;
+      e = hipMalloc((void**)&dev, want);
+      if (e != hipSuccess) return e;
+      dev_bytes = want;
+    }
+    if (pin_bytes < bytes && bytes <= PIN_MAX) {
+      if (pin) {
+        e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return e;
+        (void)hipHostFree(pin);
+        pin = nullptr;
+        pin_bytes = 0;
+      }
+      size_t want = 4096;
+      while (want < bytes) want *= 2;
+      e = hipHostMalloc((void**)&pin, want, hipHostMallocDefault);
+      if (e != hipSuccess) return e;
+      pin_bytes = want;
+    }
+    return hipSuccess;
+  }
+};
+
+// One packed block.  Segments are declared in the order inputs, in-outs, outputs; a NULL host pointer on an input /
+// in-out segment means "zeros", on an output segment "not wanted" (the device region still exists).
+class Staging {
+ public:
+  enum Dir { IN = 0, INOUT = 1, OUT = 2 };
+  static constexpr int MAXSEG = 16;
+
+  // returns the segment's index; offsets are 16-byte aligned
+  int add(Dir dir, const void* src, void* dst, size_t bytes) {
+    Seg& s = seg_[n_];
+    s.dir = dir;
+    s.src = src;
+    s.dst = dst;
+    s.bytes = bytes;
+    s.off = total_;
+    total_ += (bytes + 15) & ~(size_t)15;
+    if (dir == IN) in_end_ = total_;
+    if (dir != OUT) h2d_end_ = total_;
+    return n_++;
+  }
+  size_t total() const { return total_ ? total_ : 16; }
+
+  hipError_t upload(HostCtx& c) {
+    hipError_t e = c.ensure(total());
+    if (e != hipSuccess) return e;
+    pinned_ = c.pin && c.pin_bytes >= total();
+    if (pinned_) {
+      for (int i = 0; i < n_; ++i) {
+        const Seg& s = seg_[i];
+        if (s.dir == OUT || !s.bytes) continue;
+        if (s.src) std::memcpy(c.pin + s.off, s.src, s.bytes);
+        else std::memset(c.pin + s.off, 0, s.bytes);
+      }
+      if (h2d_end_) e = hipMemcpyAsync(c.dev, c.pin, h2d_end_, hipMemcpyHostToDevice, c.st);
+      return e;
+    }
+    for (int i = 0; i < n_ && e == hipSuccess; ++i) {  // large batches: straight from the caller's arrays
+      const Seg& s = seg_[i];
+      if (s.dir == OUT || !s.bytes) continue;
+      if (s.src) e = hipMemcpyAsync(c.dev + s.off, s.src, s.bytes, hipMemcpyHostToDevice, c.st);
+      else e = hipMemsetAsync(c.dev + s.off, 0, s.bytes, c.st);
+    }
+    return e;
+  }
+
+  // copies back, waits for the private stream, scatters into the caller's arrays
+  hipError_t download(HostCtx& c) {
+    hipError_t e = hipSuccess;
+    if (pinned_) {
+      if (total_ > in_end_) e = hipMemcpyAsync(c.pin + in_end_, c.dev + in_end_, total_ - in_end_, hipMemcpyDeviceToHost, c.st);
+      if (e == hipSuccess) e = hipStreamSynchronize(c.st);
+      if (e != hipSuccess) return e;
+      for (int i = 0; i < n_; ++i) {
+        const Seg& s = seg_[i];
+        if (s.dir != IN && s.dst && s.bytes) std::memcpy(s.dst, c.pin + s.off, s.bytes);
+      }
+      return hipSuccess;
+    }
+    for (int i = 0; i < n_ && e == hipSuccess; ++i) {
+      const Seg& s = seg_[i];
+      if (s.dir != IN && s.dst && s.bytes) e = hipMemcpyAsync(s.dst, c.dev + s.off, s.bytes, hipMemcpyDeviceToHost, c.st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c.st);
+    return e;
+  }
+
+  template <typename T> T* dev(const HostCtx& c, int i) const { return reinterpret_cast<T*>(c.dev + seg_[i].off); }
+
+ private:
+  struct Seg {
+    Dir dir;
+    const void* src;
+    void* dst;
+    size_t bytes, off;
+  };
+  Seg seg_[MAXSEG];
+  int n_ = 0;
+  size_t total_ = 0, in_end_ = 0, h2d_end_ = 0;
+  bool pinned_ = false;
+};
+
+}  // namespace dexr

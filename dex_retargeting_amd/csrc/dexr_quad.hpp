@@ -670,7 +670,10 @@ __global__ void __launch_bounds__(256, DEXR_QUAD_MINW) dexr_quad_kernel(const Ke
       }
       if (seq && t_seq + 1 < kp.T) {
         // next frame of this quad's sequence: its start point / regularisation target is the row lane 0 of the quad
-        // has just written (same wave, program order: the loads below come after the stores above)
+        // has just written.  The other three lanes read it back with agent-scope loads: program order within a wave
+        // is not a memory-model guarantee across lanes, so the stores are released first (as dexr_wide.hpp does)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_wave_barrier();
         load_frame(item, t_seq + 1);
         done = false;
         pending = false;

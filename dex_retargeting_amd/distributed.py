@@ -2,7 +2,16 @@
 
 Every frame is an independent solve, so a batch shards with no data-path exchange: rank r solves the contiguous
 slice [lo_r, hi_r) and ONE all-gather reassembles the (B, n_opt) qpos tensor on every rank (BASELINE.json
-north_star; the reference has no distributed mode)."""
+north_star; the reference has no distributed mode).
+
+Two ways to issue that collective:
+
+* ``NativeGather`` -- the data path: ``dexr_allgather`` of the C-ABI (RCCL bound inside libdexr.so), enqueued on a HIP
+  stream right behind the solve, no host round trip, hipGraph-capturable.  ``native_comm`` builds the communicator; the
+  128-byte RCCL unique id travels through a ``torch.distributed`` TCP store (the one ``torch.distributed.run`` already
+  hosts, when launched by it).
+* ``ShardedRetargeter`` / ``PipelinedAllGather`` -- the same partition over ``torch.distributed`` process groups (gloo on
+  CPU: what the world-size-2 tests run; nccl = RCCL through torch)."""
 from __future__ import annotations
 
 from typing import Callable, Optional, Tuple
@@ -150,4 +159,99 @@ class PipelinedAllGather:
         order = sorted((kw[0], s) for s, kw in enumerate(self._work) if kw is not None)
         for _, slot in order:
             self._retire(slot)
+        return None if self._last is None else self._full[self._last]
+
+
+# ---- native collective (libdexr.so: dexr_comm_* / dexr_allgather) -----------------------------------------------------
+
+def rendezvous_store(rank: int, world: int, timeout_s: float = 300.0):
+    """The key-value store the ranks of this job share: the TCP store of ``torch.distributed.run`` when it launched us
+    (TORCHELASTIC_USE_AGENT_STORE: every worker is a client), else one hosted by rank 0 on MASTER_ADDR:MASTER_PORT."""
+    import datetime
+    import os
+
+    from torch.distributed import TCPStore
+
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", "29511"))
+    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
+    return TCPStore(addr, port, world, is_master=(rank == 0 and not agent), timeout=datetime.timedelta(seconds=timeout_s),
+                    wait_for_workers=False)
+
+
+def exchange_bytes(store, rank: int, key: str, make) -> bytes:
+    """Rank 0 publishes ``make()`` under `key`; every rank returns it (``store.get`` blocks until it is there)."""
+    if rank == 0:
+        blob = make()
+        store.set(key, blob)
+        return blob
+    return bytes(store.get(key))
+
+
+def native_comm(rank: int, world: int, store=None, key: str = "dexr/unique_id"):
+    """An RCCL communicator over all ranks, bound to the CURRENT HIP device (call torch.cuda.set_device first)."""
+    from . import _lib
+
+    if world == 1:
+        return _lib.Comm(_lib.comm_unique_id(), 0, 1)
+    if store is None:
+        store = rendezvous_store(rank, world)
+    uid = exchange_bytes(store, rank, key, _lib.comm_unique_id)
+    return _lib.Comm(uid, rank, world)
+
+
+class NativeGather:
+    """Per-step all-gather of this rank's (per, n) float32 result rows through ``dexr_allgather``.
+
+    ``depth`` (shard, full) buffer pairs rotate.  Per step k::
+
+        out = ng.shard(k)    # this rank's rows of step k; the solve stream first waits for the gather that last read
+                             # this pair (an event, no host wait)
+        ... enqueue the solve that writes `out` on the current stream ...
+        ng.gather(k)         # overlap=True: the collective runs on a second stream ordered after the solve by an event, so
+                             # the next step's solve overlaps it;  overlap=False: on the solve stream itself (strictly
+                             # serial, what a single captured hipGraph of [solve, all-gather] does)
+
+    ``finish()`` makes the current stream wait for every gather in flight and returns the last full (world, per, n)
+    tensor.  Nothing here blocks the host."""
+
+    def __init__(self, comm, per: int, n: int, device, depth: int = 4, overlap: bool = True):
+        import torch
+
+        self.torch, self.comm, self.depth, self.overlap = torch, comm, depth, overlap
+        self.bytes_per_rank = per * n * 4
+        self._shard = [torch.zeros((per, n), dtype=torch.float32, device=device) for _ in range(depth)]
+        self._full = [torch.empty((comm.world, per, n), dtype=torch.float32, device=device) for _ in range(depth)]
+        self._done = [None] * depth
+        self._comm_stream = torch.cuda.Stream(device=device) if overlap else None
+        self._last = None
+
+    def shard(self, k: int):
+        slot = k % self.depth
+        if self._done[slot] is not None:
+            self.torch.cuda.current_stream().wait_event(self._done[slot])
+        return self._shard[slot]
+
+    def gather(self, k: int):
+        torch = self.torch
+        slot = k % self.depth
+        cur = torch.cuda.current_stream()
+        if self.overlap:
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            self._comm_stream.wait_event(ready)
+            st = self._comm_stream
+        else:
+            st = cur
+        self.comm.allgather(self._shard[slot].data_ptr(), self._full[slot].data_ptr(), self.bytes_per_rank, st.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(st)
+        self._done[slot] = done
+        self._last = slot
+
+    def finish(self):
+        cur = self.torch.cuda.current_stream()
+        for ev in self._done:
+            if ev is not None:
+                cur.wait_event(ev)
         return None if self._last is None else self._full[self._last]

@@ -28,7 +28,13 @@ class MixedFleet:
         self.n_opt = [o.opt_dof for o in self.optimizers]
         self.n_max = max(self.n_opt)
         self._ws = None
-        self._opts = None
+        # dexr_retarget_multi_dev takes ONE dexr_solve_options for the whole batch: a fleet whose optimizers carry
+        # different solve_options would silently solve some of them differently from their own retarget_batch
+        so = [dict(o.solve_options) for o in self.optimizers]
+        if any(x != so[0] for x in so[1:]):
+            raise ValueError("MixedFleet: the optimizers carry different solve_options; a fleet batch is solved with one "
+                             "set of options (set them equal, or run the models in separate calls)")
+        self._opts = self.optimizers[0]._options()
 
     def retarget(self, model_id, keypoints, last_qpos, state: Optional["object"] = None, out=None, status=None):
         """model_id (B,) int32, keypoints (B,21,3) f32, last_qpos (B,n_max) f32 (columns >= n_opt[m] ignored),
@@ -43,8 +49,16 @@ class MixedFleet:
                 raise ValueError(f"{name} must be a contiguous tensor on {self.device}")
         if keypoints.dtype != torch.float32 or last_qpos.dtype != torch.float32 or tuple(last_qpos.shape) != (B, self.n_max):
             raise ValueError(f"keypoints / last_qpos must be float32, last_qpos of shape ({B}, {self.n_max})")
+        for t, name in ((state, "state"), (status, "status")):  # raw pointers go to the kernels: insist on the layout
+            if t is not None and (t.dtype not in (torch.int32, torch.uint32) or tuple(t.shape) != (B,) or
+                                  not t.is_contiguous() or t.device != self.device):
+                raise ValueError(f"{name} must be a contiguous int32 tensor of shape ({B},) on {self.device}")
+        if state is None and any(o.retargeting_type == "DEXPILOT" for o in self.optimizers):
+            raise ValueError("the fleet contains a DexPilot model: state (B,) int32 is required")
         if out is None:
             out = torch.zeros((B, self.n_max), dtype=torch.float32, device=self.device)
+        elif out.dtype != torch.float32 or tuple(out.shape) != (B, self.n_max) or not out.is_contiguous() or out.device != self.device:
+            raise ValueError(f"out must be a contiguous float32 tensor of shape ({B}, {self.n_max}) on {self.device}")
         need = _lib.fleet_workspace_bytes(B)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)

@@ -212,6 +212,29 @@ int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, i
                             int32_t* status_out, const dexr_solve_options* opt, void* workspace, size_t workspace_bytes,
                             void* stream);
 
+/* ---- multi-GPU: reassembling the qpos tensor (BASELINE.json north_star; SURVEY.md section 8b `dexr_allgather`, 8e) -------
+ * One process per GPU.  Frames are independent, so ranks solve contiguous shards with no exchange; the only collective of
+ * the path is ONE all-gather of the (B/N, n_opt) result rows.  It runs on RCCL (bound at run time with dlopen: a copy
+ * already mapped into the process -- torch's -- is reused, else librccl.so.1 from the loader path / /opt/rocm/lib) and is
+ * enqueued on the caller's stream like every "_dev" entry point: solve -> all-gather needs no host round trip and can be
+ * captured into one hipGraph.  The reference is single-process (no counterpart).
+ *   dexr_comm_unique_id  rank 0 fills DEXR_UNIQUE_ID_BYTES bytes; the HOST application hands them to every rank (any
+ *                        transport: a torch.distributed store, MPI, a file)
+ *   dexr_comm_create     collective over all ranks; binds the communicator to the CURRENT HIP device
+ *   dexr_allgather       recv[r * bytes_per_rank ...] = rank r's `send` block, DEVICE pointers, recv holds world blocks;
+ *                        in-place (send == recv + rank * bytes_per_rank) is allowed
+ *   dexr_comm_max_f64    control plane: element-wise MAX of n <= 8 HOST doubles over the ranks (timing brackets);
+ *                        synchronises `stream`;  dexr_comm_barrier = the same with a dummy value                        */
+typedef struct dexr_comm dexr_comm;
+#define DEXR_UNIQUE_ID_BYTES 128
+int dexr_comm_unique_id(void* id_out);
+int dexr_comm_create(const void* unique_id, int32_t rank, int32_t world, dexr_comm** out);
+void dexr_comm_destroy(dexr_comm* c);
+int dexr_comm_info(const dexr_comm* c, int32_t* rank, int32_t* world, int32_t* rccl_version);
+int dexr_allgather(dexr_comm* c, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+int dexr_comm_max_f64(dexr_comm* c, double* values_inout, int32_t n, void* stream);
+int dexr_comm_barrier(dexr_comm* c, void* stream);
+
 /* The step right before the path: raw detector keypoints -> wrist-centred keypoints in the MANO frame, x B.
  *   kp_c = kp - kp[0];  R = estimate_frame_from_hand_points(kp_c);  joint_pos = kp_c @ R @ operator2mano
  * (example/vector_retargeting/single_hand_detector.py:102-104,129-158; OPERATOR2MANO_RIGHT/LEFT constants.py:7-21).

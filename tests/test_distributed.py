@@ -147,3 +147,34 @@ def test_pipelined_all_gather_two_ranks_gloo(tmp_path, G):
         for k, t in d["seen"].items():
             want = torch.stack([torch.full((5, 3), float(100 * k + r)) for r in range(2)])
             assert torch.equal(t, want), (rank, k)
+
+
+def test_bench_gpus_n_starts_n_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE in the environment must start two ranks (the way
+    the driver invokes the N = 1 run).  --dry-run-launch keeps the GPU out of it: every rank joins the job's store,
+    receives the 128-byte id rank 0 published (the exchange native_comm performs for the RCCL unique id) and takes part
+    in a gloo all-gather; rank 0's line carries n_gpus = world_size = 2."""
+    import json
+    import subprocess
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "TORCHELASTIC_USE_AGENT_STORE")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--dry-run-launch"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["world_size"] == 2 and rec["launched_by_torchrun"] is True
+    assert rec["ranks"] == [0.0, 1.0] and rec["local_ranks"] == [0.0, 1.0]
+    assert rec["id_bytes"] == [128.0, 128.0] and rec["id_checksum"] == [float(sum(range(128)))] * 2
+
+
+def test_unique_id_is_created_without_a_gpu_and_has_the_abi_size():
+    from dex_retargeting_amd import _lib
+
+    a, b = _lib.comm_unique_id(), _lib.comm_unique_id()
+    assert len(a) == _lib.UNIQUE_ID_BYTES == 128 and a != b
+    with pytest.raises(ValueError):
+        _lib.Comm(b"short", 0, 1)

@@ -1041,3 +1041,129 @@ def test_tuning_rejects_unknown_values():
         with pytest.raises(_lib.DexrError):
             model.tune(**bad)
     model.tune(kernel=_lib.KERNEL_AUTO)
+
+
+# ---- round 3: host-pointer latency path, native collective, family-dependent damping default ------------------------
+@pytest.mark.parametrize("rel", ["teleop/allegro_hand_right.yml", "teleop/shadow_hand_right_dexpilot.yml",
+                                 "offline/inspire_hand_right.yml"])
+@pytest.mark.parametrize("B", [1, 3, 300])
+def test_host_pointer_path_equals_device_pointer_path_bitwise(rel, B):
+    """dexr_retarget packs every array into the handle's persistent staging block (one copy each way, private stream);
+    its answers, DexPilot bits and diagnostics are bitwise those of dexr_retarget_dev on the same inputs, and calling
+    it repeatedly (growing and shrinking batches through the same grow-only buffers) changes nothing."""
+    torch = pytest.importorskip("torch")
+    seq, prob = build(rel)
+    model = seq.optimizer.device_model()
+    d = cases.reachable_set(prob, 300, 0.05)
+    dev = torch.device("cuda:0")
+    dexpilot = prob.kind == "dexpilot"
+    for n in (B, 300, B):
+        ref, last = d["ref"][:n], d["last"][:n]
+        fixed = None if d["fixed"] is None or d["fixed"].shape[1] == 0 else d["fixed"][:n]
+        st_h = np.zeros(n, np.uint32) if dexpilot else None
+        got, info = model.retarget(ref, fixed, last, state=st_h, want_info=True)
+        t_ref, t_last = torch.from_numpy(ref).to(dev), torch.from_numpy(last).to(dev)
+        t_fix = None if fixed is None else torch.from_numpy(fixed).to(dev)
+        t_out = torch.empty_like(t_last)
+        t_st = torch.zeros(n, dtype=torch.int32, device=dev)
+        t_status = torch.empty(n, dtype=torch.int32, device=dev)
+        t_iters = torch.empty(n, dtype=torch.int32, device=dev)
+        t_fval = torch.empty(n, dtype=torch.float32, device=dev)
+        model.retarget_dev(n, t_ref.data_ptr(), 0 if t_fix is None else t_fix.data_ptr(), t_last.data_ptr(),
+                           t_st.data_ptr() if dexpilot else 0, t_out.data_ptr(), status_ptr=t_status.data_ptr(),
+                           iters_ptr=t_iters.data_ptr(), fval_ptr=t_fval.data_ptr(),
+                           stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(t_out.cpu().numpy(), got)
+        assert np.array_equal(t_status.cpu().numpy(), info["status"])
+        assert np.array_equal(t_iters.cpu().numpy(), info["iters"])
+        assert np.array_equal(t_fval.cpu().numpy(), info["fval"])
+        if dexpilot:
+            assert np.array_equal(t_st.cpu().numpy().astype(np.uint32), st_h)
+
+
+def test_host_pointer_calls_do_not_touch_other_streams():
+    """The host entry points run on the handle's private stream and wait for that stream only: a long-running launch on
+    another stream of the process is still in flight when a B = 1 call returns."""
+    torch = pytest.importorskip("torch")
+    seq, prob = build("teleop/allegro_hand_right.yml")
+    model = seq.optimizer.device_model()
+    d = cases.reachable_set(prob, 1, 0.05)
+    model.retarget(d["ref"], None, d["last"])
+    side = torch.cuda.Stream()
+    big = torch.empty(1 << 28, dtype=torch.float32, device="cuda:0")
+    done = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        for _ in range(40):
+            big.mul_(1.0001)
+        done.record(side)
+    q = model.retarget(d["ref"], None, d["last"])
+    still_running = not done.query()
+    torch.cuda.synchronize()
+    assert np.all(np.isfinite(q))
+    assert still_running, "the host-pointer call waited for an unrelated stream"
+
+
+def test_native_allgather_world_size_one_and_graph_capture():
+    """dexr_comm_* / dexr_allgather on RCCL with ONE rank (all a 1-GPU box can hold): the gather returns the shard, the
+    control-plane reductions work, and [solve, all-gather] captured into one HIP graph replays to the eager answer."""
+    torch = pytest.importorskip("torch")
+    from dex_retargeting_amd.distributed import NativeGather, native_comm
+
+    torch.cuda.set_device(0)
+    comm = native_comm(0, 1)
+    assert comm.rccl_version() > 20000
+    assert comm.max_f64([1.5, -2.0]).tolist() == [1.5, -2.0]
+    comm.barrier()
+    seq, prob = build("teleop/allegro_hand_right.yml")
+    model = seq.optimizer.device_model()
+    B = 4096
+    d = cases.reachable_set(prob, B, 0.05)
+    want = model.retarget(d["ref"], None, d["last"])
+    dev = torch.device("cuda:0")
+    ref, last = torch.from_numpy(d["ref"]).to(dev), torch.from_numpy(d["last"]).to(dev)
+    for overlap in (True, False):
+        ng = NativeGather(comm, B, prob.n_opt, dev, depth=2, overlap=overlap)
+        for k in range(5):
+            out = ng.shard(k)
+            model.retarget_dev(B, ref.data_ptr(), 0, last.data_ptr(), 0, out.data_ptr(),
+                               stream=torch.cuda.current_stream().cuda_stream)
+            ng.gather(k)
+        full = ng.finish()
+        torch.cuda.synchronize()
+        assert tuple(full.shape) == (1, B, prob.n_opt)
+        assert np.array_equal(full[0].cpu().numpy(), want)
+    # one captured graph of [solve -> all-gather]
+    shard = torch.zeros((B, prob.n_opt), dtype=torch.float32, device=dev)
+    full = torch.zeros((1, B, prob.n_opt), dtype=torch.float32, device=dev)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):  # warm-up outside the capture (RCCL sets its channels up on first use)
+        model.retarget_dev(B, ref.data_ptr(), 0, last.data_ptr(), 0, shard.data_ptr(), stream=s.cuda_stream)
+        comm.allgather(shard.data_ptr(), full.data_ptr(), B * prob.n_opt * 4, s.cuda_stream)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        model.retarget_dev(B, ref.data_ptr(), 0, last.data_ptr(), 0, shard.data_ptr(), stream=s.cuda_stream)
+        comm.allgather(shard.data_ptr(), full.data_ptr(), B * prob.n_opt * 4, s.cuda_stream)
+    full.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(full[0].cpu().numpy(), want)
+    comm.close()
+
+
+def test_damping_default_follows_the_dispatched_kernel_family():
+    """dexr_tuning.lam_jump means different things per family (curvature along the failed step vs mean diag H): after
+    tune(kernel=...) the handle reports -- and launches with -- the NEW family's default unless the caller set one."""
+    seq = RetargetingConfig.load_from_file(os.path.join(cases.CONFIG_DIR, "teleop/shadow_hand_right_dexpilot.yml")).build()
+    model = seq.optimizer.device_model()
+    assert model.kernel()[0] == _lib.KERNEL_WIDE and abs(model.get_tuning().lam_jump - 1.0) < 1e-7
+    model.tune(kernel=_lib.KERNEL_LDS)
+    assert model.kernel()[0] == _lib.KERNEL_LDS and abs(model.get_tuning().lam_jump - 0.3) < 1e-7
+    model.tune(kernel=_lib.KERNEL_QUAD)
+    assert abs(model.get_tuning().lam_jump - 1.0) < 1e-7
+    model.tune(lam_jump=0.5)  # an explicit value survives family changes
+    model.tune(kernel=_lib.KERNEL_LDS)
+    assert abs(model.get_tuning().lam_jump - 0.5) < 1e-7
