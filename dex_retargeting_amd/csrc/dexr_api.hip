@@ -502,6 +502,7 @@ void default_tuning(dexr_model* m) {
   t.blind_tol_scale = m->bucket <= 8 ? 100.f : 10.f;
   t.pivot_rule = -1;
   t.longest_first = -1;
+  t.fork_streams = -1;
 }
 
 // Which float32 solve kernel serves the model.  Measured on MI355X (65 536 frames, tools/all_configs.py,
@@ -785,6 +786,7 @@ int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning) {
   if (t.kernel < DEXR_KERNEL_AUTO || t.kernel > DEXR_KERNEL_WIDE) return fail(DEXR_ERR_INVALID, "unknown kernel family %d", t.kernel);
   if (t.pivot_rule < -1 || t.pivot_rule > 1) return fail(DEXR_ERR_INVALID, "unknown pivot rule %d", t.pivot_rule);
   if (t.longest_first < -1 || t.longest_first > 1) return fail(DEXR_ERR_INVALID, "longest_first must be -1, 0 or 1");
+  if (t.fork_streams < -1 || t.fork_streams > 1) return fail(DEXR_ERR_INVALID, "fork_streams must be -1, 0 or 1");
   if (t.persist_from < 0 || t.qchunk < 0 || t.persist_occ < 0 || t.resident_waves < 0 || t.max_blind < 0)
     return fail(DEXR_ERR_INVALID, "negative launch parameter");
   if (!(t.step_cap >= 0) || !(t.lam_jump >= 0) || !(t.lam_fastdec >= 0) || !(t.floor_scale >= 0) || !(t.blind_tol_scale >= 0))
@@ -1112,10 +1114,11 @@ int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, i
   if (status_out) HIP_TRY(hipMemsetAsync(status_out, 0, (size_t)B * sizeof(int32_t), st));
   const int32_t* bucket = ws + 2 * DEXR_FLEET_MAX_MODELS;
   const int32_t* perm = ws + dexr_fleet_ws_ints();
-  // The models' buckets are disjoint rows: their launches are independent.  Model 0 stays on the caller's stream, the
-  // others fork to internal streams, so the slow tail of one model's launch (a few waves) overlaps the bulk of the
-  // next one instead of idling the GPU n_models times per call.
-  ForkPool* fp = n_models > 1 ? fork_pool() : nullptr;
+  // The models' buckets are disjoint rows: their launches are independent.  With fork_streams on, the HEAVY models
+  // (components of 9+ joints: persistent kernels that hold a SIMD's whole register file and end in a long tail of a few
+  // slow frames) go first, each to an internal HIGH-PRIORITY stream; the light models (small components, tens of
+  // microseconds each) follow on the caller's stream and fill the CUs the heavy launches' tails leave idle.
+  ForkPool* fp = (n_models > 1 && models[0]->tune.fork_streams != 0) ? fork_pool() : nullptr;
   std::unique_lock<std::mutex> lock;
   if (fp) {
     lock = std::unique_lock<std::mutex>(fp->mu);
@@ -1123,37 +1126,46 @@ int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, i
     HIP_TRY(hipEventRecord(fp->fork, st));
   }
   int rc_all = DEXR_OK;
-  int forked = 0;
-  for (int i = 0; i < n_models; ++i) {
-    const dexr_model* m = models[i];
-    hipStream_t si = st;
-    if (fp && i > 0) {
-      if (!fp->aux[i]) HIP_TRY(hipStreamCreateWithFlags(&fp->aux[i], hipStreamNonBlocking));
-      if (!fp->join[i]) HIP_TRY(hipEventCreateWithFlags(&fp->join[i], hipEventDisableTiming));
-      si = fp->aux[i];
-      HIP_TRY(hipStreamWaitEvent(si, fp->fork, 0));
-      forked = i;
-    }
-    dexr::KernelParams kp;
-    fill_params(m, kp, B);  // B: upper bound of the bucket size (launch geometry); the kernel reads the real count
-    apply_options(m, kp, opt);
-    kp.kpts = keypoints;
-    kp.last = last;
-    kp.state = m->h.kind == DEXR_KIND_DEXPILOT ? state : nullptr;
-    kp.qout = qpos_out;
-    kp.status = status_out;
-    kp.ld = ld;
-    kp.perm = perm;
-    kp.bucket = bucket + 2 * i;
-    int rc = launch(m, dexr::MODE_SOLVE, 0, kp, si);
-    if (rc == DEXR_OK) rc = polish_launch(m, kp, opt, si);
-    if (rc != DEXR_OK) {  // still join what has been forked, then report
-      rc_all = rc;
-      break;
+  bool forked[DEXR_FLEET_MAX_MODELS] = {};
+  for (int pass = 0; pass < 2 && rc_all == DEXR_OK; ++pass) {
+    for (int i = 0; i < n_models; ++i) {
+      const dexr_model* m = models[i];
+      const bool heavy = selected_family(m) != FAM_REGISTER;
+      if (heavy != (pass == 0)) continue;
+      hipStream_t si = st;
+      if (fp && heavy) {
+        if (!fp->aux[i]) {
+          int lo = 0, hi = 0;
+          HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+          HIP_TRY(hipStreamCreateWithPriority(&fp->aux[i], hipStreamNonBlocking, hi));
+        }
+        if (!fp->join[i]) HIP_TRY(hipEventCreateWithFlags(&fp->join[i], hipEventDisableTiming));
+        si = fp->aux[i];
+        HIP_TRY(hipStreamWaitEvent(si, fp->fork, 0));
+        forked[i] = true;
+      }
+      dexr::KernelParams kp;
+      fill_params(m, kp, B);  // B: upper bound of the bucket size (launch geometry); the kernel reads the real count
+      apply_options(m, kp, opt);
+      kp.kpts = keypoints;
+      kp.last = last;
+      kp.state = m->h.kind == DEXR_KIND_DEXPILOT ? state : nullptr;
+      kp.qout = qpos_out;
+      kp.status = status_out;
+      kp.ld = ld;
+      kp.perm = perm;
+      kp.bucket = bucket + 2 * i;
+      int rc = launch(m, dexr::MODE_SOLVE, 0, kp, si);
+      if (rc == DEXR_OK) rc = polish_launch(m, kp, opt, si);
+      if (rc != DEXR_OK) {  // still join what has been forked, then report
+        rc_all = rc;
+        break;
+      }
     }
   }
   std::string err = g_err;
-  for (int i = 1; i <= forked; ++i) {
+  for (int i = 0; i < n_models; ++i) {
+    if (!forked[i]) continue;
     HIP_TRY(hipEventRecord(fp->join[i], fp->aux[i]));
     HIP_TRY(hipStreamWaitEvent(st, fp->join[i], 0));
   }

@@ -12,57 +12,96 @@ namespace {
 
 constexpr int FLEET_MAX_MODELS = DEXR_FLEET_MAX_MODELS;
 
-// counts[m] = number of frames of model m.  One LDS histogram per block, then one atomic per model and block.
-__global__ void __launch_bounds__(256) fleet_count_kernel(const int32_t* __restrict__ model_id, int64_t B, int n_models,
-                                                          int32_t* __restrict__ counts, int32_t* __restrict__ bad) {
-  __shared__ int32_t h[FLEET_MAX_MODELS];
-  if (threadIdx.x < FLEET_MAX_MODELS) h[threadIdx.x] = 0;
+// Mixed-fleet bucketing = a STABLE partition of the frame indices by model id, in three launches and without a single
+// contended atomic (the first version took its list slots from one cursor word per model: 8 192 returning atomics on 4
+// addresses = 95 us for 131 072 frames, the rate one word sustains; this one is launch-bound, ~5 us per kernel, and
+// its index lists are deterministic and keep neighbouring frames together):
+//   1. every block histograms ITS contiguous chunk of the batch in LDS -> blockcnt[block][model];
+//   2. one block turns the per-block counts into bucket offsets and per-(block, model) list positions (exclusive scan);
+//   3. every block walks its chunk again, 256 frames at a time, and writes each frame's index to its model's list at
+//      (block base + frames of that model seen so far in the chunk): ballot ranks within a wave, LDS across the waves.
+constexpr int FLEET_MAX_BLOCKS = 1024;
+
+__global__ void __launch_bounds__(256) fleet_count_kernel(const int32_t* __restrict__ model_id, int64_t B, int64_t chunk,
+                                                          int n_models, int32_t* __restrict__ blockcnt,
+                                                          int32_t* __restrict__ bad) {
+  __shared__ int32_t h[FLEET_MAX_MODELS + 1];
+  if (threadIdx.x <= FLEET_MAX_MODELS) h[threadIdx.x] = 0;
   __syncthreads();
-  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t b0 = (int64_t)blockIdx.x * chunk, b1 = b0 + chunk < B ? b0 + chunk : B;
+  for (int64_t b = b0 + threadIdx.x; b < b1; b += blockDim.x) {
     const int m = model_id[b];
-    if (m >= 0 && m < n_models) atomicAdd(&h[m], 1);
-    else atomicAdd(bad, 1);  // frames with an unknown model id are left untouched and counted
+    atomicAdd(&h[(m >= 0 && m < n_models) ? m : FLEET_MAX_MODELS], 1);  // LDS atomics; unknown ids are counted apart
   }
   __syncthreads();
-  if (threadIdx.x < n_models && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
+  if (threadIdx.x < FLEET_MAX_MODELS) blockcnt[(size_t)blockIdx.x * FLEET_MAX_MODELS + threadIdx.x] = h[threadIdx.x];
+  if (threadIdx.x == 0 && h[FLEET_MAX_MODELS]) atomicAdd(bad, h[FLEET_MAX_MODELS]);  // frames left untouched
 }
 
-// bucket[2m] = first slot of model m in the index list, bucket[2m+1] = its frame count; cursors reset.
-__global__ void fleet_offsets_kernel(int n_models, const int32_t* __restrict__ counts, int32_t* __restrict__ bucket,
-                                     int32_t* __restrict__ cursor) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
+// bucket[2m] = first slot of model m in the index list, bucket[2m+1] = its frame count;
+// blockcnt[block][m] becomes the list position of block `block`'s first frame of model m.
+__global__ void __launch_bounds__(256) fleet_offsets_kernel(int n_models, int nblocks, int32_t* __restrict__ blockcnt,
+                                                            int32_t* __restrict__ counts, int32_t* __restrict__ bucket) {
+  __shared__ int32_t part[16][FLEET_MAX_MODELS];
+  __shared__ int32_t base[FLEET_MAX_MODELS];
+  const int m = threadIdx.x & 15, g = threadIdx.x >> 4;  // 16 groups of consecutive blocks x 16 models
+  const int per = (nblocks + 15) / 16;
+  const int k0 = g * per, k1 = (k0 + per < nblocks) ? k0 + per : nblocks;
+  int32_t s = 0;
+  for (int k = k0; k < k1; ++k) s += blockcnt[(size_t)k * FLEET_MAX_MODELS + m];
+  part[g][m] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
     int32_t off = 0;
-    for (int m = 0; m < n_models; ++m) {
-      bucket[2 * m] = off;
-      bucket[2 * m + 1] = counts[m];
-      cursor[m] = 0;
-      off += counts[m];
+    for (int mm = 0; mm < FLEET_MAX_MODELS; ++mm) {
+      int32_t tot = 0;
+      for (int gg = 0; gg < 16; ++gg) tot += part[gg][mm];
+      base[mm] = off;
+      if (mm < n_models) {
+        bucket[2 * mm] = off;
+        bucket[2 * mm + 1] = tot;
+        counts[mm] = tot;
+      }
+      off += tot;
     }
+  }
+  __syncthreads();
+  int32_t run = base[m];
+  for (int gg = 0; gg < g; ++gg) run += part[gg][m];
+  for (int k = k0; k < k1; ++k) {
+    const int32_t c = blockcnt[(size_t)k * FLEET_MAX_MODELS + m];
+    blockcnt[(size_t)k * FLEET_MAX_MODELS + m] = run;
+    run += c;
   }
 }
 
-// perm[bucket[2m] + k] = b for the k-th frame b of model m.  Within a wave, lanes of the same model take consecutive
-// slots from ONE atomic (match-any by ballot over the model id), so the list keeps runs of neighbouring frames together.
-__global__ void __launch_bounds__(256) fleet_scatter_kernel(const int32_t* __restrict__ model_id, int64_t B, int n_models,
-                                                            const int32_t* __restrict__ bucket, int32_t* __restrict__ cursor,
+__global__ void __launch_bounds__(256) fleet_scatter_kernel(const int32_t* __restrict__ model_id, int64_t B, int64_t chunk,
+                                                            int n_models, const int32_t* __restrict__ blockcnt,
                                                             int32_t* __restrict__ perm) {
-  const int lane = threadIdx.x & 63;
-  for (int64_t b0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x - lane); b0 < B; b0 += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t b = b0 + lane;
-    const int m = b < B ? model_id[b] : -1;
+  __shared__ int32_t run[FLEET_MAX_MODELS];
+  __shared__ int32_t wcnt[4][FLEET_MAX_MODELS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x < FLEET_MAX_MODELS) run[threadIdx.x] = blockcnt[(size_t)blockIdx.x * FLEET_MAX_MODELS + threadIdx.x];
+  const int64_t b0 = (int64_t)blockIdx.x * chunk, b1 = b0 + chunk < B ? b0 + chunk : B;
+  for (int64_t s0 = b0; s0 < b1; s0 += 256) {  // block-uniform trip count
+    const int64_t b = s0 + threadIdx.x;
+    const int m = b < b1 ? model_id[b] : -1;
     const bool ok = m >= 0 && m < n_models;
-    for (int mm = 0; mm < n_models; ++mm) {  // wave-uniform loop: one atomic per (wave, model present in it)
+    int rank = 0;
+    for (int mm = 0; mm < n_models; ++mm) {  // wave-uniform loop
       const unsigned long long mask = __ballot(ok && m == mm);
-      if (mask == 0ull) continue;
-      const int leader = __ffsll((long long)mask) - 1;
-      int32_t base = 0;
-      if (lane == leader) base = atomicAdd(&cursor[mm], (int32_t)__popcll(mask));
-      base = __shfl(base, leader, 64);
-      if (ok && m == mm) {
-        const int rank = (int)__popcll(mask & ((1ull << lane) - 1ull));
-        perm[bucket[2 * mm] + base + rank] = (int32_t)b;
-      }
+      if (lane == 0) wcnt[w][mm] = (int32_t)__popcll(mask);
+      if (ok && m == mm) rank = (int)__popcll(mask & ((1ull << lane) - 1ull));
     }
+    __syncthreads();
+    if (ok) {
+      int32_t pos = run[m] + rank;
+      for (int ww = 0; ww < w; ++ww) pos += wcnt[ww][m];
+      perm[pos] = (int32_t)b;
+    }
+    __syncthreads();
+    if (threadIdx.x < n_models) run[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
+    __syncthreads();
   }
 }
 
@@ -122,22 +161,25 @@ __global__ void __launch_bounds__(256) seq_compose_kernel(int64_t B, int T, int 
 }  // namespace
 
 // ---- launch helpers used by dexr_api.hip --------------------------------------------------------------------------
-// workspace layout (int32): counts[MAX] | cursor[MAX] | bucket[2 MAX] | bad[1] | pad | perm[B]
-size_t dexr_fleet_ws_ints() { return 4 * (size_t)FLEET_MAX_MODELS + 16; }
+// workspace layout (int32): counts[MAX] | (unused)[MAX] | bucket[2 MAX] | bad[1] | pad | blockcnt[MAX_BLOCKS x MAX] | perm[B]
+size_t dexr_fleet_ws_ints() { return 4 * (size_t)FLEET_MAX_MODELS + 16 + (size_t)FLEET_MAX_BLOCKS * FLEET_MAX_MODELS; }
 
 hipError_t dexr_fleet_bucket_launch(int n_models, int64_t B, const int32_t* model_id, int32_t* ws, hipStream_t st) {
   int32_t* counts = ws;
-  int32_t* cursor = ws + FLEET_MAX_MODELS;
   int32_t* bucket = ws + 2 * FLEET_MAX_MODELS;
   int32_t* bad = ws + 4 * FLEET_MAX_MODELS;
+  int32_t* blockcnt = ws + 4 * FLEET_MAX_MODELS + 16;
   int32_t* perm = ws + dexr_fleet_ws_ints();
-  hipError_t e = hipMemsetAsync(ws, 0, dexr_fleet_ws_ints() * sizeof(int32_t), st);
+  hipError_t e = hipMemsetAsync(ws, 0, (4 * (size_t)FLEET_MAX_MODELS + 16) * sizeof(int32_t), st);
   if (e != hipSuccess) return e;
-  const int64_t want = (B + 255) / 256;
-  const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
-  hipLaunchKernelGGL(fleet_count_kernel, dim3(blocks), dim3(256), 0, st, model_id, B, n_models, counts, bad);
-  hipLaunchKernelGGL(fleet_offsets_kernel, dim3(1), dim3(64), 0, st, n_models, counts, bucket, cursor);
-  hipLaunchKernelGGL(fleet_scatter_kernel, dim3(blocks), dim3(256), 0, st, model_id, B, n_models, bucket, cursor, perm);
+  // contiguous chunks of >= 2 048 frames, at most FLEET_MAX_BLOCKS of them
+  int64_t chunk = (B + FLEET_MAX_BLOCKS - 1) / FLEET_MAX_BLOCKS;
+  chunk = (chunk + 255) / 256 * 256;
+  if (chunk < 2048) chunk = 2048;
+  const int nblocks = (int)((B + chunk - 1) / chunk);
+  hipLaunchKernelGGL(fleet_count_kernel, dim3(nblocks), dim3(256), 0, st, model_id, B, chunk, n_models, blockcnt, bad);
+  hipLaunchKernelGGL(fleet_offsets_kernel, dim3(1), dim3(256), 0, st, n_models, nblocks, blockcnt, counts, bucket);
+  hipLaunchKernelGGL(fleet_scatter_kernel, dim3(nblocks), dim3(256), 0, st, model_id, B, chunk, n_models, blockcnt, perm);
   return hipGetLastError();
 }
 

@@ -1077,7 +1077,8 @@ def test_host_pointer_path_equals_device_pointer_path_bitwise(rel, B):
         assert np.array_equal(t_out.cpu().numpy(), got)
         assert np.array_equal(t_status.cpu().numpy(), info["status"])
         assert np.array_equal(t_iters.cpu().numpy(), info["iters"])
-        assert np.array_equal(t_fval.cpu().numpy(), info["fval"])
+        # fval is summed over the frame's components with float atomics: equal up to the order of the additions
+        assert np.allclose(t_fval.cpu().numpy(), info["fval"], rtol=1e-5, atol=0)
         if dexpilot:
             assert np.array_equal(t_st.cpu().numpy().astype(np.uint32), st_h)
 
