@@ -131,11 +131,25 @@ def gen_fk_golden():
 
     out = {}
     n_cfg = 4
-    for path in sorted(glob.glob(os.path.join(cases.URDF_DIR, "*", "*.urdf"))):
-        rel = os.path.relpath(path, cases.URDF_DIR)
+    # the shipped robot fixtures + the "messy" test URDFs (tests/urdf/: constructs exported real-world URDFs carry that the
+    # authored robot fixtures do not use; keys prefixed "testurdf__")
+    paths = [(p, os.path.relpath(p, cases.URDF_DIR).replace("/", "__").replace(".urdf", ""))
+             for p in sorted(glob.glob(os.path.join(cases.URDF_DIR, "*", "*.urdf")))]
+    paths += [(os.path.join(REPO, "tests", "urdf", n + ".urdf"), "testurdf__" + n) for n in ("messy_arm_hand",)]
+    for path, base_key in paths:
         for dummy in (False, True):
-            key = rel.replace("/", "__").replace(".urdf", "") + ("__free" if dummy else "")
+            key = base_key + ("__free" if dummy else "")
             u = ref_urdf.load_reference_urdf(path, dummy)
+            # the axes exactly as the reference's reader parsed them (yourdfpy.py:1631-1643) ...
+            moving = [j for j in u.robot.joints if j.type != "fixed"]
+            out[key + "__axis_names"] = np.array([j.name for j in moving])
+            out[key + "__axis_raw"] = np.array([np.asarray(j.axis, dtype=np.float64) for j in moving])
+            # ... and, for the FK below, normalised: yourdfpy feeds the axis to Rodrigues' formula as written (a non-unit
+            # axis gives a non-orthonormal "rotation"), whereas the model the reference actually solves with comes from
+            # pinocchio's URDF parser, which normalises it [not-in-ref: third-party behaviour; urdfdom / pinocchio
+            # JointModel{Revolute,Prismatic}Unaligned take axis.normalized()]
+            for j in moving:
+                j.axis = np.asarray(j.axis, dtype=np.float64) / np.linalg.norm(j.axis)
             lo = np.array([j.limit.lower for j in u.actuated_joints], dtype=np.float64)
             hi = np.array([j.limit.upper for j in u.actuated_joints], dtype=np.float64)
             rng = np.random.default_rng(len(key) * 1000 + len(u.robot.joints) + (7 if dummy else 0))
