@@ -402,23 +402,26 @@ def online_record(no_cpu=False):
                                       "kernel -> one D2H on the handle's private stream -> hipStreamSynchronize"}}
         if rel == ONLINE_ROBOTS[0][0] and not no_cpu:
             # the CPU port on the SAME loop (checker code, imported here, after every GPU timing of this record)
-            from oracle import cases, solvers
+            from oracle import cases, cport
 
             prob = cases.problem_from_config(rel)
-            n_cpu = 150
+            cp = cport.CProblem(prob)
+            n_cpu = len(refs)
             last = lasts[0].astype(np.float64)
             t_cpu, dq = [], []
             lo, hi = seq.joint_limits[:, 0], seq.joint_limits[:, 1]
             for i in range(n_cpu):
                 tic = time.perf_counter()
-                q_ref, _ = solvers.solve_ref_as_configured(prob, refs[i][None], None, np.clip(last, lo, hi)[None].astype(np.float32))
+                q_ref, _ = cport.solve_ref_as_configured_c(cp, refs[i][None], None, np.clip(last, lo, hi)[None].astype(np.float32))
                 t_cpu.append(time.perf_counter() - tic)
                 last = q_ref[0].astype(np.float64)
             t_cpu = np.array(t_cpu)
             rec["cpu_port_same_loop"] = {"frames": n_cpu, "fps": n_cpu / t_cpu.sum(), "mean_ms": float(t_cpu.mean() * 1e3),
                                          "p99_ms": float(np.percentile(t_cpu, 99) * 1e3), "kind": "port", "cores": 1,
-                                         "note": "oracle restatement of the objective + scipy SLSQP at the reference's ftol, "
-                                                 "its own warm-start chain over the first 150 fixture frames"}
+                                         "note": "the oracle's plain-C closure + scipy's compiled SLSQP at the reference's ftol, its "
+                                                 "own warm-start chain over the 621 fixture frames (the reference's loop, "
+                                                 "profile_online_retargeting.py:18-36, with compiled stand-ins for "
+                                                 "pinocchio / nlopt and no torch overhead)"}
         out["robots"][rel] = rec
     return out
 
@@ -655,23 +658,48 @@ def run_single(args):
         rec["parity"] = parity_block(w2, b2, q2, min(256, B), 0 if args.no_cpu_baseline else min(64, B))[0]
         out.setdefault("also", {})[name] = rec
 
-    # ---- CPU baseline: the reference path as configured (scipy SLSQP stand-in for nlopt), host cores ----------
+    # ---- CPU baseline: the reference path as configured, on the host cores (oracle = checker code only) -------------
     if world == 1 and not args.no_cpu_baseline:
-        from oracle import solvers
+        from oracle import cport, solvers
 
-        budget_s, done, t_cpu = 15.0, 0, 0.0
-        while done < min(args.cpu_sample, B) and t_cpu < budget_s:  # bounded sample: ~15 s of host work
-            sl = slice(done, min(done + 50, len(ref_now)))
-            if sl.start >= sl.stop:
-                break
-            t1 = time.perf_counter()
-            solvers.solve_ref_as_configured(prob, ref_now[sl], None, last_now[sl], **kw_for(sl))
-            t_cpu += time.perf_counter() - t1
-            done = sl.stop
+        cp = cport.CProblem(prob)
+
+        def timed_cpu(solve, budget_s, chunk):
+            done, t_cpu, evals = 0, 0.0, 0
+            while done < min(args.cpu_sample, B) and t_cpu < budget_s:  # bounded sample of the same workload
+                sl = slice(done, min(done + chunk, len(ref_now)))
+                if sl.start >= sl.stop:
+                    break
+                t1 = time.perf_counter()
+                _, ev = solve(ref_now[sl], None, last_now[sl], **kw_for(sl))
+                t_cpu += time.perf_counter() - t1
+                evals += int(ev.sum())
+                done = sl.stop
+            return done, t_cpu, evals
+
+        done, t_cpu, evals = timed_cpu(lambda *a, **k: cport.solve_ref_as_configured_c(cp, *a, **k), 12.0, 200)
+        # cost of ONE closure evaluation in the compiled port (FK + Jacobians + loss + chain rule), timed alone
+        tgt = cp.target(ref_now[0])
+        x0 = last_now[0].astype(np.float64)
+        t1 = time.perf_counter()
+        for _ in range(2000):
+            cp.evaluate(x0, tgt, None, x0)
+        t_eval = (time.perf_counter() - t1) / 2000
         out["cpu_baseline"] = {"value": done / t_cpu, "unit": "frames/s", "cores": 1, "kind": "port",
-                               "sample": f"first {done} frames of the same workload, oracle restatement of the reference "
-                                         f"objective + scipy SLSQP (ftol {prob.ftol:g}) standing in for nlopt, one process",
+                               "sample": f"first {done} frames of the same workload; per frame the reference's own procedure "
+                                         f"(optimizer.py:77-102): closure (value without / gradient with the regulariser) + "
+                                         f"SLSQP at ftol {prob.ftol:g} from last_qpos.  Closure = the oracle's plain-C "
+                                         f"restatement (oracle/csrc/dexr_oracle.c: FK, point Jacobians, SmoothL1, mimic fold); "
+                                         f"SLSQP = scipy's compiled Kraft routine standing in for nlopt's; one process",
+                               "evaluations_per_frame": evals / max(done, 1),
+                               "closure_us_per_evaluation_incl_ctypes": t_eval * 1e6,
+                               "note": "optimistic stand-in for pinocchio + nlopt + torch: the reference additionally pays "
+                                       "torch autograd overhead in every evaluation (optimizer.py:266-291)",
                                "host_cpus": os.cpu_count()}
+        d2, t2, _ = timed_cpu(lambda *a, **k: solvers.solve_ref_as_configured(prob, *a, **k), 4.0, 25)
+        out["cpu_baseline_numpy_port"] = {"value": d2 / t2, "unit": "frames/s", "cores": 1, "kind": "port",
+                                          "sample": f"first {d2} frames, the same solve with the numpy closure "
+                                                    f"(oracle/objectives.py): the figure rounds 1-2 reported"}
         # the same solve fanned over host processes (frames are independent): what the reference could do on this box
         avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         procs = int(os.environ.get("DEXR_CPU_PROCS", min(avail, 64)))
@@ -739,7 +767,7 @@ def main():
     ap.add_argument("--workload", default="allegro_vector", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every host-CPU solve (baseline and SLSQP distance)")
     ap.add_argument("--headline-only", action="store_true", help="skip the f64 / cold-start / other-config sub-records")
-    ap.add_argument("--cpu-sample", type=int, default=1200, help="frames of the workload timed on the host CPU")
+    ap.add_argument("--cpu-sample", type=int, default=20000, help="frames of the workload timed on the host CPU")
     ap.add_argument("--dry-run-launch", action="store_true",
                     help="launch + rendezvous plumbing only (no GPU work): used by the CPU tests of the N > 1 launcher")
     args = ap.parse_args()

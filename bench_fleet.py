@@ -152,14 +152,18 @@ def run(args):
         dq = np.abs(q[idx][:, : pr.n_opt].astype(np.float64) - want).max(1)
         parity[rel] = {"subset": len(idx), "max_abs_dq_rad": float(dq.max()), "frac_within_1e-4": float((dq < 1e-4).mean())}
         if not args.no_cpu_baseline and world == 1:
+            from oracle import cport
+
+            cp = cport.CProblem(pr)
             t1 = time.perf_counter()
-            solvers.solve_ref_as_configured(pr, ref[:60], None, la[:60], **{k: v[:60] for k, v in kw.items()})
+            cport.solve_ref_as_configured_c(cp, ref, None, la, **kw)
             cpu_t += time.perf_counter() - t1
-            cpu_n += 60
+            cpu_n += len(idx)
     out_json["parity"] = parity
     if cpu_n:
         out_json["cpu_baseline"] = {"value": cpu_n / cpu_t, "unit": "frames/s", "cores": 1, "kind": "port",
-                                    "sample": "60 frames of each of the four models, reference-as-configured port"}
+                                    "sample": "128 frames of each of the four models; the reference's per-frame procedure with the "
+                                              "oracle's plain-C closure + scipy's compiled SLSQP (see bench.py cpu_baseline)"}
     if coll is not None:
         out_json["multi_gpu"] = coll
     print(json.dumps(out_json))

@@ -1,8 +1,9 @@
 """ORACLE (test infrastructure only -- never imported by the product path).
 
 One host process of bench.py's ``cpu_baseline_all_cores`` leg: solves a slice of the bench workload with the
-reference-as-configured CPU solve (oracle.solvers.solve_ref_as_configured == the reference's per-frame
-``Optimizer.retarget``, optimizer.py:77-102, scipy SLSQP standing in for nlopt).
+reference-as-configured CPU solve (oracle.cport.solve_ref_as_configured_c == the reference's per-frame
+``Optimizer.retarget``, optimizer.py:77-102: the closure evaluated by the oracle's plain-C restatement, scipy's
+compiled SLSQP standing in for nlopt).
 
     python -m oracle.cpu_worker <config.yml (relative)> <inputs.npz> <start> <count> <sync dir>
 
@@ -21,14 +22,26 @@ import time
 import numpy as np
 
 
+_cp = {}
+
+
 def _solve(prob, ref, last):
-    from . import solvers
+    """The compiled-closure port (oracle/cport.py) when its library is there, the numpy port otherwise."""
+    from . import cport, solvers
 
     kw = {}
     if prob.kind == "dexpilot":
         w, rv, _ = prob.dexpilot_preamble(ref, np.zeros((ref.shape[0], prob.n_pair), bool))
         kw = dict(weights=w, dexpilot_ref=rv)
-    solvers.solve_ref_as_configured(prob, ref, None, last, **kw)
+    try:
+        if id(prob) not in _cp:
+            _cp[id(prob)] = cport.CProblem(prob)
+    except Exception:
+        _cp[id(prob)] = None
+    if _cp[id(prob)] is not None:
+        cport.solve_ref_as_configured_c(_cp[id(prob)], ref, None, last, **kw)
+    else:
+        solvers.solve_ref_as_configured(prob, ref, None, last, **kw)
 
 
 def main(argv):
