@@ -55,7 +55,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     objs = []
     api_s, api_o = os.path.join(CSRC, "dexr_api.hip"), os.path.join(BUILD, "dexr_api.o")
     objs.append(api_o)
-    if force or _stale(api_o, [api_s, os.path.join(CSRC, "dexr_hostctx.hpp")] + HEADERS):
+    if force or _stale(api_o, [api_s, os.path.join(CSRC, "dexr_hostctx.hpp"), os.path.join(CSRC, "dexr_gen.hpp")] + HEADERS):
         jobs.append((api_s, api_o, []))
     prep_s, prep_o = os.path.join(CSRC, "dexr_prep.hip"), os.path.join(BUILD, "dexr_prep.o")
     objs.append(prep_o)
@@ -69,6 +69,10 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     objs.append(comm_o)
     if force or _stale(comm_o, [comm_s, os.path.join(INCLUDE, "dexr.h")]):
         jobs.append((comm_s, comm_o, []))
+    gen_s, gen_o = os.path.join(CSRC, "dexr_gen_inst.hip"), os.path.join(BUILD, "dexr_gen.o")
+    objs.append(gen_o)
+    if force or _stale(gen_o, [gen_s, os.path.join(CSRC, "dexr_gen.hpp")] + HEADERS):
+        jobs.append((gen_s, gen_o, []))
     inst_s = os.path.join(CSRC, "dexr_inst.hip")
     # developer shortcut: DEXR_BUILD_ONLY="4,8" rebuilds only those buckets and reuses the other objects as they are
     # (only valid while KernelParams / the launcher signature are unchanged)

@@ -33,7 +33,7 @@ class Tuning(C.Structure):
                 ("pivot_rule", C.c_int32), ("longest_first", C.c_int32), ("fork_streams", C.c_int32)]
 
 
-KERNEL_AUTO, KERNEL_REGISTER, KERNEL_QUAD, KERNEL_LDS, KERNEL_REDUCED, KERNEL_WIDE = -1, 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_REGISTER, KERNEL_QUAD, KERNEL_LDS, KERNEL_REDUCED, KERNEL_WIDE, KERNEL_GENERAL = -1, 0, 1, 2, 3, 4, 5
 
 EXPORTS = ["dexr_last_error", "dexr_version", "dexr_device_count", "dexr_default_options", "dexr_model_create",
            "dexr_model_destroy", "dexr_model_info", "dexr_model_get_tuning", "dexr_model_set_tuning", "dexr_model_kernel",

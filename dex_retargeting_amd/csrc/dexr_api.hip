@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "dexr.h"
+#include "dexr_gen.hpp"
 #include "dexr_hostctx.hpp"
 #include "dexr_launch.hpp"
 
@@ -90,6 +91,9 @@ struct dexr_model {
   int max_slot = -1;      // deepest saved-transform slot any component uses
   bool has_mimic = false;
   dexr_tuning tune;       // launch / damping parameters (dexr_model_set_tuning); never read from the environment
+  bool gen = false;       // generic table (dexr_tables.h): served by the general kernel (dexr_gen.hpp), every mode, float64
+  dexr::GenTab gen_tab;   // device pointers into d_gen
+  void* d_gen = nullptr;
   float lam_jump_user = -1.f;  // >= 0: the caller overrode dexr_tuning.lam_jump; otherwise every launch uses the default
                                // of the kernel family it actually dispatches (family_lam_jump)
   mutable dexr::HostCtx host;  // private stream + persistent pinned / device staging of the host-pointer entry points
@@ -423,8 +427,22 @@ bool build_wide_tables(dexr_model* m) {
   return true;
 }
 
+int launch_gen_model(const dexr_model* m, int mode, dexr::KernelParams kp, hipStream_t st) {
+  const size_t lds = dexr::gen_lds_bytes(m->gen_tab);
+  if (lds > 160 * 1024) return fail(DEXR_ERR_UNSUPPORTED, "model needs %zu B of LDS per frame", lds);
+  // one wave per frame; as many resident waves as the LDS allows (at most 8 per CU), persistent over the batch
+  int64_t per_cu = (int64_t)((160 * 1024) / lds);
+  per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+  int64_t blocks = (int64_t)m->n_cu * per_cu;
+  if (blocks > kp.B) blocks = kp.B;
+  hipError_t e = dexr::launch_gen(mode, kp, m->gen_tab, dim3((unsigned)blocks), lds, st);
+  if (e != hipSuccess) return fail(DEXR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+  return DEXR_OK;
+}
+
 int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStream_t st) {
   if (kp.B <= 0) return DEXR_OK;
+  if (m->gen) return launch_gen_model(m, mode, kp, st);
   // fleet buckets / frame sequences / padded rows need the kernels with extended addressing (KernelParams)
   const bool ext = kp.perm != nullptr || kp.bucket != nullptr || kp.T > 0 || kp.ld != kp.n_opt;
   if (mode == dexr::MODE_SOLVE && !f64 && selected_family(m) != FAM_REGISTER) {
@@ -505,6 +523,124 @@ void default_tuning(dexr_model* m) {
   t.fork_streams = -1;
 }
 
+// A model in the generic table format (dexr_tables.h): validate every index the general kernel will follow, upload the
+// arrays in one block and point the kernel's GenTab at them.
+int create_generic(const dexr_model_header& h, const char* body, size_t nbytes, dexr_model** out) {
+  if (h.version != DEXR_TABLE_VERSION) return fail(DEXR_ERR_INVALID, "table version %u, library expects %u", h.version, DEXR_TABLE_VERSION);
+  if (nbytes < sizeof(dexr_gen_header)) return fail(DEXR_ERR_INVALID, "blob shorter than the generic-table header");
+  dexr_gen_header gh;
+  std::memcpy(&gh, body, sizeof(gh));
+  if (gh.magic != DEXR_GEN_MAGIC) return fail(DEXR_ERR_INVALID, "n_comp = 0 but no generic table follows the header");
+  const int nj = gh.n_joint, nf = gh.n_frame, nt = gh.n_term, nv = gh.n_var, nfam = gh.n_fam;
+  if (nj < 0 || nj > DEXR_GEN_MAXJ || nf < 1 || nf > DEXR_GEN_MAXJ || nt < 1 || nt > DEXR_GEN_MAXJ || nv < 0 || nv > nj ||
+      nfam < nv || nfam > nj || gh.max_depth < 0 || gh.max_depth > nj)
+    return fail(DEXR_ERR_INVALID, "generic table sizes out of range (%d joints, %d frames, %d terms, %d variables)", nj, nf, nt, nv);
+  if (h.kind != DEXR_KIND_FKONLY && nv != h.n_opt) return fail(DEXR_ERR_INVALID, "generic table has %d variables, header n_opt = %d", nv, h.n_opt);
+  if (nt != h.n_ref) return fail(DEXR_ERR_INVALID, "generic table has %d terms, header n_ref = %d", nt, h.n_ref);
+  if (h.kind == DEXR_KIND_DEXPILOT) {
+    const int F = h.num_fingers;
+    if (F < 2 || F > 8) return fail(DEXR_ERR_INVALID, "DexPilot needs 2..8 fingers (32 projection bits), got %d", F);
+    if (h.n_ref != F * (F - 1) / 2 + F) return fail(DEXR_ERR_INVALID, "DexPilot n_ref=%d does not match %d fingers", h.n_ref, F);
+  }
+  auto pad2 = [](size_t n) { return (n + 1) & ~(size_t)1; };
+  const size_t n_f64 = (size_t)nj * 12 + (size_t)nj * 3 + 2 * (size_t)nj + 2 * (size_t)nv + (size_t)nf * 3;
+  const size_t n_u64 = (size_t)nf + nj;
+  const size_t i32_sizes[14] = {(size_t)nj, (size_t)nj, (size_t)nj, (size_t)nj, (size_t)nj, (size_t)nv, (size_t)nv + 1,
+                                (size_t)nfam, (size_t)nf, (size_t)nt, (size_t)nt, (size_t)nt, (size_t)nt, (size_t)nt};
+  size_t n_i32 = 0;
+  for (size_t v : i32_sizes) n_i32 += pad2(v);
+  const size_t want = sizeof(gh) + 8 * (n_f64 + n_u64) + 4 * n_i32;
+  if (nbytes != want) return fail(DEXR_ERR_INVALID, "generic table is %zu B, its header implies %zu B", nbytes, want);
+  const char* p = body + sizeof(gh);
+  const double* f64 = reinterpret_cast<const double*>(p);
+  const unsigned long long* u64 = reinterpret_cast<const unsigned long long*>(p + 8 * n_f64);
+  const int32_t* i32 = reinterpret_cast<const int32_t*>(p + 8 * (n_f64 + n_u64));
+  const int32_t* arr[14];
+  {
+    size_t o = 0;
+    for (int i = 0; i < 14; ++i) {
+      arr[i] = i32 + o;
+      o += pad2(i32_sizes[i]);
+    }
+  }
+  const int32_t *jtype = arr[0], *parent = arr[1], *depth = arr[2], *src_idx = arr[3], *var = arr[4], *var_api = arr[5],
+                *fam_off = arr[6], *fam = arr[7], *frame_joint = arr[8], *term_task = arr[9], *term_origin = arr[10],
+                *term_ref = arr[11], *row_ho = arr[12], *row_ht = arr[13];
+  for (int k = 0; k < nj; ++k) {
+    const bool bad = (jtype[k] != DEXR_JOINT_REVOLUTE && jtype[k] != DEXR_JOINT_PRISMATIC) || parent[k] < -1 || parent[k] >= k ||
+                     depth[k] != (parent[k] < 0 ? 0 : depth[parent[k]] + 1) || depth[k] > gh.max_depth || var[k] < -1 || var[k] >= nv ||
+                     (var[k] < 0 && h.kind != DEXR_KIND_FKONLY && (src_idx[k] < 0 || src_idx[k] >= h.n_fixed)) ||
+                     (h.kind == DEXR_KIND_FKONLY && (src_idx[k] < 0 || src_idx[k] >= h.n_q));
+    if (bad) return fail(DEXR_ERR_INVALID, "generic table: joint record %d malformed", k);
+  }
+  for (int v = 0; v < nv; ++v) {
+    if (var_api[v] < 0 || var_api[v] >= h.n_opt || fam_off[v] < 0 || fam_off[v] > fam_off[v + 1] || fam_off[v + 1] > nfam)
+      return fail(DEXR_ERR_INVALID, "generic table: variable record %d malformed", v);
+    for (int e = fam_off[v]; e < fam_off[v + 1]; ++e)
+      if (fam[e] < 0 || fam[e] >= nj || var[fam[e]] != v) return fail(DEXR_ERR_INVALID, "generic table: family of variable %d malformed", v);
+  }
+  for (int f = 0; f < nf; ++f)
+    if (frame_joint[f] < -1 || frame_joint[f] >= nj) return fail(DEXR_ERR_INVALID, "generic table: frame record %d malformed", f);
+  std::vector<bool> seen((size_t)nt, false);
+  for (int t = 0; t < nt; ++t) {
+    const bool bad = term_task[t] < 0 || term_task[t] >= nf || term_origin[t] < -1 || term_origin[t] >= nf || term_ref[t] < 0 ||
+                     term_ref[t] >= nt || seen[(size_t)term_ref[t]] ||
+                     (gh.has_keypoint_map && (row_ht[t] < 0 || row_ht[t] >= h.n_keypoints || row_ho[t] < -1 || row_ho[t] >= h.n_keypoints));
+    if (bad) return fail(DEXR_ERR_INVALID, "generic table: term record %d malformed", t);
+    seen[(size_t)term_ref[t]] = true;
+  }
+  dexr_model* m = new (std::nothrow) dexr_model();
+  if (!m) return fail(DEXR_ERR_INVALID, "out of host memory");
+  m->h = h;
+  m->gen = true;
+  m->bucket = 0;
+  m->max_joints = nj;
+  m->max_vars = nv;
+  default_tuning(m);
+  m->has_mimic = nfam > nv;
+  const size_t payload = nbytes - sizeof(gh);
+  hipError_t e = hipMalloc(&m->d_gen, payload ? payload : 8);
+  if (e == hipSuccess) e = hipMemcpy(m->d_gen, p, payload, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+      m->n_cu = cus;
+  }
+  if (e != hipSuccess) {
+    if (m->d_gen) (void)hipFree(m->d_gen);
+    delete m;
+    return fail(DEXR_ERR_HIP, "uploading tables failed: %s", hipGetErrorString(e));
+  }
+  const char* d = static_cast<const char*>(m->d_gen);
+  const double* df = reinterpret_cast<const double*>(d);
+  dexr::GenTab& g = m->gen_tab;
+  g.nj = nj; g.nf = nf; g.nt = nt; g.nv = nv; g.nfam = nfam; g.max_depth = gh.max_depth; g.has_kp = gh.has_keypoint_map; g.pad_ = 0;
+  g.X = df;
+  g.axis = g.X + (size_t)nj * 12;
+  g.jmul = g.axis + (size_t)nj * 3;
+  g.joff = g.jmul + nj;
+  g.lo = g.joff + nj;
+  g.hi = g.lo + nv;
+  g.frame_off = g.hi + nv;
+  g.frame_anc = reinterpret_cast<const unsigned long long*>(d + 8 * n_f64);
+  g.joint_anc = g.frame_anc + nf;
+  const int32_t* di = reinterpret_cast<const int32_t*>(d + 8 * (n_f64 + n_u64));
+  const int32_t** dst[14] = {&g.jtype, &g.parent, &g.depth, &g.src_idx, &g.var, &g.var_api, &g.fam_off, &g.fam, &g.frame_joint,
+                             &g.term_task, &g.term_origin, &g.term_ref, &g.row_ho, &g.row_ht};
+  {
+    size_t o = 0;
+    for (int i = 0; i < 14; ++i) {
+      *dst[i] = di + o;
+      o += pad2(i32_sizes[i]);
+    }
+  }
+  (void)u64;
+  (void)f64;
+  *out = m;
+  return DEXR_OK;
+}
+
 // Which float32 solve kernel serves the model.  Measured on MI355X (65 536 frames, tools/all_configs.py,
 // tools/cmp_big.py): the LDS kernel wins where the register kernel needs its float64 polish launch on a large
 // component (position models: Inspire 8.7 vs 27 ms, Shadow + free joints 57 vs 170 ms) and loses where it does not
@@ -572,6 +708,7 @@ void apply_options(const dexr_model* m, dexr::KernelParams& kp, const dexr_solve
 // Optional float64 polish: same kernel in double precision, started at the float32 answer (x0 = qout, in place),
 // regularised towards the ORIGINAL last_qpos.  Stream-ordered after the float32 launch.
 bool polish_wanted(const dexr_model* m, const dexr_solve_options* opt) {
+  if (m->gen) return false;  // the general kernel is float64 throughout
   int polish = opt ? opt->polish : -1;
   if (polish < 0) polish = (m->h.kind == DEXR_KIND_POSITION || m->h.kind == DEXR_KIND_DEXPILOT) ? 24 : 0;
   if (polish == 0 || m->bucket == 32) return false;
@@ -646,6 +783,9 @@ int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out) {
   std::memcpy(&h, blob, sizeof(h));
   if (h.magic != DEXR_MAGIC) return fail(DEXR_ERR_INVALID, "bad magic 0x%08x", h.magic);
   if (h.version != DEXR_TABLE_VERSION) return fail(DEXR_ERR_INVALID, "table version %u, library expects %u", h.version, DEXR_TABLE_VERSION);
+  if (h.kind < DEXR_KIND_VECTOR || h.kind > DEXR_KIND_FKONLY) return fail(DEXR_ERR_INVALID, "unknown kind %d", h.kind);
+  if (h.n_opt < 0 || h.n_fixed < 0 || h.n_ref < 0 || h.n_q < 0) return fail(DEXR_ERR_INVALID, "negative size in header");
+  if (h.n_comp == 0 && h.comp_bytes == 0) return create_generic(h, static_cast<const char*>(blob) + sizeof(h), nbytes - sizeof(h), out);
   if (h.comp_bytes != (int32_t)sizeof(dexr_comp_table)) return fail(DEXR_ERR_INVALID, "component record is %d B, library expects %zu", h.comp_bytes, sizeof(dexr_comp_table));
   if (h.n_comp < 1 || h.n_comp > 4096) return fail(DEXR_ERR_INVALID, "n_comp=%d out of range", h.n_comp);
   if (h.kind < DEXR_KIND_VECTOR || h.kind > DEXR_KIND_FKONLY) return fail(DEXR_ERR_INVALID, "unknown kind %d", h.kind);
@@ -753,6 +893,7 @@ void dexr_model_destroy(dexr_model* m) {
   if (m->d_comps) (void)hipFree(m->d_comps);
   if (m->d_queue) (void)hipFree(m->d_queue);
   if (m->d_wide) (void)hipFree(m->d_wide);
+  if (m->d_gen) (void)hipFree(m->d_gen);
   for (dexr_model::LptSlot& sl : m->lpt) {
     if (sl.buf) (void)hipFree(sl.buf);
     if (sl.done) (void)hipEventDestroy(sl.done);
@@ -796,6 +937,7 @@ int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning) {
   if (tuning->struct_size >= offsetof(dexr_tuning, lam_jump) + sizeof(float) && t.lam_jump != m->tune.lam_jump)
     m->lam_jump_user = t.lam_jump;
   m->tune = t;
+  if (m->gen) return DEXR_OK;  // one kernel serves a generic model
   select_kernels(m);
   m->tune.lam_jump = family_lam_jump(m, selected_family(m));
   return DEXR_OK;
@@ -803,7 +945,8 @@ int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning) {
 
 int dexr_model_kernel(const dexr_model* m, int32_t* family, int32_t* bucket, int32_t* chain) {
   if (!m) return fail(DEXR_ERR_INVALID, "null argument");
-  if (family) *family = m->wide ? DEXR_KERNEL_WIDE : m->red ? DEXR_KERNEL_REDUCED : m->quad ? DEXR_KERNEL_QUAD : m->big ? DEXR_KERNEL_LDS : DEXR_KERNEL_REGISTER;
+  if (family && m->gen) *family = DEXR_KERNEL_GENERAL;
+  else if (family) *family = m->wide ? DEXR_KERNEL_WIDE : m->red ? DEXR_KERNEL_REDUCED : m->quad ? DEXR_KERNEL_QUAD : m->big ? DEXR_KERNEL_LDS : DEXR_KERNEL_REGISTER;
   if (bucket) *bucket = m->bucket;
   if (chain) *chain = m->chain ? 1 : 0;
   return DEXR_OK;
@@ -827,7 +970,7 @@ static int retarget_dev_impl(const dexr_model* m, int64_t B, const float* ref, b
                              int32_t* iters_out, float* fval_out, const dexr_solve_options* opt, void* stream) {
   if (!m || !ref || !last || !qpos_out) return fail(DEXR_ERR_INVALID, "null argument");
   if (m->h.kind == DEXR_KIND_FKONLY) return fail(DEXR_ERR_INVALID, "model is an FK-only table");
-  if (ref_is_keypoints && m->h.n_keypoints <= 0)
+  if (ref_is_keypoints && (m->h.n_keypoints <= 0 || (m->gen && !m->gen_tab.has_kp)))
     return fail(DEXR_ERR_INVALID, "model carries no target_link_human_indices: keypoint input not available");
   if (m->h.n_fixed > 0 && !fixed) return fail(DEXR_ERR_INVALID, "model has %d fixed joints but fixed_qpos is NULL", m->h.n_fixed);
   if (B < 0) return fail(DEXR_ERR_INVALID, "negative batch");

@@ -1,0 +1,26 @@
+// dexr_gen_inst.hip -- instantiations of the general kernel (dexr_gen.hpp): solve / objective evaluation / forward
+// kinematics for models described by the generic table format.
+#include "dexr_gen.hpp"
+#include "dexr_launch.hpp"
+
+namespace dexr {
+size_t gen_lds_bytes(const GenTab& tb) { return gen_lds_doubles(tb.nj, tb.nf, tb.nt, tb.nv) * sizeof(double); }
+
+template <int MODE> static hipError_t launch_gen_mode(const KernelParams& kp, const GenTab& tb, dim3 grid, size_t lds, hipStream_t st) {
+  static size_t configured = 0;  // dynamic LDS above 64 KB has to be requested once per kernel
+  if (lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dexr_gen_kernel<MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    configured = lds;
+  }
+  hipLaunchKernelGGL((dexr_gen_kernel<MODE>), grid, dim3(64), lds, st, kp, tb);
+  return hipGetLastError();
+}
+
+hipError_t launch_gen(int mode, const KernelParams& kp, const GenTab& tb, dim3 grid, size_t lds, hipStream_t st) {
+  if (mode == MODE_SOLVE) return launch_gen_mode<MODE_SOLVE>(kp, tb, grid, lds, st);
+  if (mode == MODE_EVAL) return launch_gen_mode<MODE_EVAL>(kp, tb, grid, lds, st);
+  return launch_gen_mode<MODE_FK>(kp, tb, grid, lds, st);
+}
+}  // namespace dexr

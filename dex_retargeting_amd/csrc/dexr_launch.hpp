@@ -74,6 +74,11 @@ static inline launch_fn find_red_launcher(int nv_bucket) {
   return nv_bucket == 8 ? launch_red_8 : nv_bucket == 16 ? launch_red_16 : nullptr;
 }
 
+// general kernel (dexr_gen.hpp): models described by the generic table format
+struct GenTab;
+hipError_t launch_gen(int mode, const KernelParams& kp, const GenTab& tb, dim3 grid, size_t lds, hipStream_t st);
+size_t gen_lds_bytes(const GenTab& tb);
+
 static inline launch_fn find_launcher(int bucket, int f64, int mode, bool chain = false, bool ext = false) {
   if (ext && mode == MODE_SOLVE && bucket <= 8) {
     if (chain && bucket == 4 && !f64) return launch_ext_chain_4_0_0;

@@ -22,7 +22,14 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
+from . import generic_tables as gt
 from .urdf import KinematicModel
+
+
+class TableOverflow(ValueError):
+    """The model does not fit the fixed-size component records (include/dexr_tables.h); compile_model / compile_fk
+    then emit the generic table, which the general kernel serves."""
+
 
 MAXJ, MAXF, MAXT, NSLOT = 32, 16, 16, 3
 MAGIC, VERSION = 0x52584544, 5
@@ -81,6 +88,7 @@ class CompiledModel:
     header: np.ndarray
     comps: np.ndarray  # structured array (n_comp,)
     comp_vars: List[List[int]] = field(default_factory=list)  # api indices solved by each component
+    generic: Optional[bytes] = None  # generic table (dexr_gen_header + arrays) of a model that outgrows the records above
 
     @property
     def n_comp(self) -> int:
@@ -91,6 +99,8 @@ class CompiledModel:
         return int(self.comps["n_joint"].max()) if self.n_comp else 0
 
     def to_blob(self) -> bytes:
+        if self.generic is not None:
+            return self.header.tobytes() + self.generic
         return self.header.tobytes() + self.comps.tobytes()
 
     def save(self, path: str) -> None:
@@ -108,6 +118,10 @@ class CompiledModel:
             raise ValueError("not a dexr table blob of this version")
         n = int(header["n_comp"])
         body = blob[HEADER_DTYPE.itemsize:]
+        if n == 0 and len(body) >= gt.GEN_HEADER_DTYPE.itemsize and \
+                int(np.frombuffer(body[:4], dtype="<u4")[0]) == gt.GEN_MAGIC:
+            return CompiledModel(int(header["kind"]), int(header["n_opt"]), int(header["n_fixed"]), int(header["n_ref"]),
+                                 int(header["n_q"]), header, np.zeros(0, dtype=COMP_DTYPE), [], generic=bytes(body))
         if int(header["comp_bytes"]) != COMP_DTYPE.itemsize or len(body) != n * COMP_DTYPE.itemsize:
             raise ValueError("blob size does not match its header")
         comps = np.frombuffer(body, dtype=COMP_DTYPE).copy()
@@ -129,11 +143,11 @@ def _build_component(model: KinematicModel, joint_set: Sequence[int], frames: Li
     pins = list(joint_set)
     nj = len(pins)
     if nj > MAXJ:
-        raise ValueError(f"component needs {nj} joints, table format supports {MAXJ}")
+        raise TableOverflow(f"component needs {nj} joints, table format supports {MAXJ}")
     if len(frames) > MAXF:
-        raise ValueError(f"component needs {len(frames)} frames, table format supports {MAXF}")
+        raise TableOverflow(f"component needs {len(frames)} frames, table format supports {MAXF}")
     if len(terms) > MAXT:
-        raise ValueError(f"component needs {len(terms)} terms, table format supports {MAXT}")
+        raise TableOverflow(f"component needs {len(terms)} terms, table format supports {MAXT}")
     local = {p: k for k, p in enumerate(pins)}
     parent_local = []
     for p in pins:
@@ -176,7 +190,7 @@ def _build_component(model: KinematicModel, joint_set: Sequence[int], frames: Li
                 free_slots.sort()
         if k in live_until and live_until[k] > k:
             if not free_slots:
-                raise ValueError("kinematic tree forks deeper than the kernel's saved-transform slots")
+                raise TableOverflow("kinematic tree forks deeper than the kernel's saved-transform slots")
             s = free_slots.pop(0)
             slot_of[k] = s
             save[k] = s
@@ -267,13 +281,12 @@ def compile_model(model: KinematicModel, kind: int, idx_pin2target: Sequence[int
                   norm_delta: float = 4e-3, scaling: float = 1.0, num_fingers: int = 0,
                   project_dist: float = 0.03, escape_dist: float = 0.05, eta1: float = 1e-4,
                   eta2: float = 3e-2, human_indices: Optional[np.ndarray] = None,
-                  n_keypoints: int = 21) -> CompiledModel:
+                  n_keypoints: int = 21, force_generic: bool = False) -> CompiledModel:
     """mimic: (mimic pin idx, source pin idx, multiplier, offset).  lower/upper: optimiser box per target joint
     (already widened; +-inf allowed)."""
     n_opt, n_fixed = len(idx_pin2target), len(idx_pin2fixed)
-    if len(terms) > MAXT:
-        raise ValueError(f"{len(terms)} reference rows (target links / vectors) exceed the table format's {MAXT} "
-                         f"(DEXR_MAXT, include/dexr_tables.h)")
+    # what the fixed-size records cannot hold goes to the generic table (one component, general kernel)
+    overflow = force_generic or len(terms) > MAXT or (kind == KIND_DEXPILOT and num_fingers > 5)
     opt_of_pin = {int(p): i for i, p in enumerate(idx_pin2target)}
     fixed_of_pin = {int(p): i for i, p in enumerate(idx_pin2fixed)}
     mimic_of_pin = {int(m): (int(s), float(a), float(b)) for (m, s, a, b) in mimic}
@@ -382,8 +395,17 @@ def compile_model(model: KinematicModel, kind: int, idx_pin2target: Sequence[int
                     jset.add(src[p][1])
                     jset.update(model.ancestors(src[p][1]))
                     changed = True
-        comps.append(_build_component(model, sorted(jset), fr_list, tl, src, lo, hi))
+        if not overflow:
+            try:
+                comps.append(_build_component(model, sorted(jset), fr_list, tl, src, lo, hi))
+            except TableOverflow:
+                overflow = True
         comp_vars.append(vars_c)
+
+    generic = None
+    if overflow:
+        generic = _generic_of(model, terms, src, lo, hi, [int(p) for p in idx_pin2target], human_indices)
+        comps, comp_vars = [], [list(range(n_opt))]
 
     n_ref = len(terms)
     inv_norm = 1.0 / (3 * n_ref) if kind == KIND_POSITION else 1.0 / max(n_ref, 1)
@@ -406,10 +428,54 @@ def compile_model(model: KinematicModel, kind: int, idx_pin2target: Sequence[int
         if task.max(initial=0) >= n_keypoints or origin.max(initial=-1) >= n_keypoints:
             raise ValueError("target_link_human_indices exceeds the keypoint count")
         header["n_keypoints"] = n_keypoints
-        header["human_origin"][:n_ref] = origin
-        header["human_task"][:n_ref] = task
+        header["human_origin"][:min(n_ref, MAXT)] = origin[:MAXT]  # generic tables carry the full map per term
+        header["human_task"][:min(n_ref, MAXT)] = task[:MAXT]
+    if generic is not None:
+        header["comp_bytes"] = 0
     return CompiledModel(kind, n_opt, n_fixed, n_ref, model.dof, header,
-                         np.array(comps, dtype=COMP_DTYPE).reshape(-1), comp_vars)
+                         np.array(comps, dtype=COMP_DTYPE).reshape(-1), comp_vars, generic=generic)
+
+
+def _human_maps(human_indices, n_ref):
+    if human_indices is None:
+        return None
+    hi = np.asarray(human_indices, dtype=np.int64)
+    return (np.full(hi.shape[0], -1), hi) if hi.ndim == 1 else (hi[0], hi[1])
+
+
+def _generic_of(model: KinematicModel, terms: Sequence[TermSpec], src: Dict[int, tuple], lo, hi,
+                opt_pins: Sequence[int], human_indices) -> bytes:
+    """The whole model as ONE generic table: every joint any term or optimised variable needs, every target link."""
+    jset = set()
+    fr_list: List[Tuple[str, int, np.ndarray]] = []
+    fr_index: Dict[str, int] = {}
+    tl: List[Tuple[int, int, int]] = []
+    for t in terms:
+        ids = []
+        for link in (t.task_link, t.origin_link):
+            if link is None:
+                ids.append(-1)
+                continue
+            if link not in fr_index:
+                f = model.frames[model.body_frame_index(link)]
+                fr_index[link] = len(fr_list)
+                fr_list.append((link, f.parent, f.placement[:3, 3].copy()))
+                if f.parent >= 0:
+                    jset.update(model.ancestors(f.parent))
+            ids.append(fr_index[link])
+        tl.append((ids[0], ids[1], t.ref_row))
+    for p in opt_pins:
+        jset.add(p)
+        jset.update(model.ancestors(p))
+    changed = True
+    while changed:  # mimic joints need their source joint in the table
+        changed = False
+        for p in list(jset):
+            if src[p][0] == SRC_MIMIC and src[p][1] not in jset:
+                jset.add(src[p][1])
+                jset.update(model.ancestors(src[p][1]))
+                changed = True
+    return gt.build_generic(model, sorted(jset), fr_list, tl, src, lo, hi, _human_maps(human_indices, len(terms)))
 
 
 def compile_fk(model: KinematicModel, link_names: Sequence[str]) -> CompiledModel:
@@ -417,6 +483,31 @@ def compile_fk(model: KinematicModel, link_names: Sequence[str]) -> CompiledMode
     (RobotWrapper.compute_forward_kinematics + get_link_pose, robot_wrapper.py:82-87).  Output row l of the
     FK kernel is the world position of link_names[l]."""
     src = {p: (SRC_DIRECT, p) for p in range(model.dof)}
+    comps = []
+    try:
+        return _compile_fk_fixed(model, link_names, src)
+    except TableOverflow:
+        pass
+    # a chain of more than DEXR_MAXJ joints (arm + hand + free joints): one generic table, general kernel
+    terms = [TermSpec(link, None, i) for i, link in enumerate(link_names)]
+    z = np.zeros(1)
+    fr_list = []
+    jset = set()
+    for i, link in enumerate(link_names):
+        f = model.frames[model.body_frame_index(link)]
+        fr_list.append((f"{link}#{i}", f.parent, f.placement[:3, 3].copy()))
+        if f.parent >= 0:
+            jset.update(model.ancestors(f.parent))
+    generic = gt.build_generic(model, sorted(jset), fr_list, [(i, -1, i) for i in range(len(link_names))], src, z, z, None)
+    header = np.zeros((), dtype=HEADER_DTYPE)
+    header["magic"], header["version"], header["kind"] = MAGIC, VERSION, KIND_FKONLY
+    header["n_ref"], header["n_q"], header["inv_norm"] = len(link_names), model.dof, 1.0
+    header["n_comp"], header["comp_bytes"] = 0, 0
+    return CompiledModel(KIND_FKONLY, 0, 0, len(link_names), model.dof, header, np.zeros(0, dtype=COMP_DTYPE), [],
+                         generic=generic)
+
+
+def _compile_fk_fixed(model: KinematicModel, link_names: Sequence[str], src) -> CompiledModel:
     comps = []
     # one component per chunk of <= MAXF links
     for c0 in range(0, len(link_names), MAXF):

@@ -72,6 +72,9 @@ class Optimizer:
         self._upper = np.full(self.opt_dof, np.inf)
         self._model: Optional[_lib.Model] = None
         self._compiled: Optional[mc.CompiledModel] = None
+        # True: compile to the generic table format even when the model fits the fixed-size records (the general kernel
+        # then serves it; used by the tests that cross-check that kernel on the shipped robots)
+        self.use_generic_tables = False
         self.solve_options = dict(max_iter=None, tol=None, lambda0=None, newton=None, precision=None, polish=None, strict=None)
         self.last_info: dict = {}
 
@@ -122,7 +125,8 @@ class Optimizer:
             self._compiled = mc.compile_model(
                 self.robot.kin, self._kind(), self.idx_pin2target.tolist(), self.idx_pin2fixed.tolist(), self._terms(),
                 lower=self._lower, upper=self._upper, mimic=mimic,
-                human_indices=self.target_link_human_indices, **self._compile_kwargs())
+                human_indices=self.target_link_human_indices, force_generic=self.use_generic_tables,
+                **self._compile_kwargs())
         return self._compiled
 
     def device_model(self) -> _lib.Model:

@@ -96,6 +96,8 @@ class RobotWrapper:
     def link_positions(self, qpos: npt.NDArray, link_indices: Sequence[int]) -> np.ndarray:
         """(B, nq) -> (B, L, 3) world positions of the given links (frame ids from get_link_index), on the GPU."""
         key = tuple(int(i) for i in link_indices)
+        if len(key) > 48:  # a generic FK table (robots of more than 32 joints) holds up to 64 links: ask in chunks
+            return np.concatenate([self.link_positions(qpos, key[c:c + 48]) for c in range(0, len(key), 48)], axis=1)
         if key not in self._fk_models:
             names = [self.kin.frames[self.kin.body_of_frame_id(i)].name for i in key]
             self._fk_models[key] = _lib.Model(compile_fk(self.kin, names).to_blob())

@@ -67,6 +67,8 @@ typedef struct dexr_solve_options {
                                   Jacobian is formed) in registers, kinematics in LDS (dexr_red.hpp)                   */
 #define DEXR_KERNEL_WIDE 4     /* sixteen lanes per frame: chain-parallel kinematics, 4 x 4 lane grid for the Hessian and
                                   its Cholesky factor, no re-assembly after a rejected step (dexr_wide.hpp)             */
+#define DEXR_KERNEL_GENERAL 5  /* reported by dexr_model_kernel for models in the generic table format (dexr_tables.h): one
+                                  wavefront per frame, every table in memory, float64 (dexr_gen.hpp); not selectable      */
 typedef struct dexr_tuning {
   uint32_t struct_size; /* sizeof(dexr_tuning) of the caller's header: lets the struct grow compatibly          */
   int32_t kernel;       /* DEXR_KERNEL_*: float32 solve kernel family (AUTO: measured policy, dexr_api.hip)      */

@@ -94,4 +94,36 @@ typedef struct dexr_model_header {
   int32_t human_task[DEXR_MAXT];
 } dexr_model_header;
 
+/* ---- generic tables: models that outgrow the fixed-size component records above -----------------------------------------
+ * (more than DEXR_MAXJ joints in one component, more than DEXR_MAXT reference rows, more than DEXR_MAXF target links,
+ * a tree that forks deeper than DEXR_NSLOT, DexPilot with more than 5 fingers: an arm + hand URDF, a 6-finger hand --
+ * anything the reference's Optimizer.__init__ accepts, optimizer.py:18-52).  The blob is then
+ *     dexr_model_header (n_comp = 0, comp_bytes = 0)  |  dexr_gen_header  |  the arrays below, in this order,
+ * and the model is served by the general kernel (csrc/dexr_gen.hpp: one wavefront per frame, every table in memory,
+ * rolled loops, float64) instead of the register / LDS-tiled families.  All joints form ONE component.
+ *
+ *   double  X[n_joint][12]        placement of joint k in its parent joint's frame (R row-major | p), fixed joints folded
+ *   double  axis[n_joint][3]      unit joint axis in the joint's own frame (no re-alignment here)
+ *   double  jmul[n_joint], joff[n_joint]   q_k = jmul * x[var[k]] + joff  (var[k] >= 0)  or  jmul * fixed[src_idx[k]] + joff
+ *                                          (FK-only tables: q_k = q_full[src_idx[k]])
+ *   double  lo[n_var], hi[n_var]  box of the optimised variables (already widened by the reference's 1e-3)
+ *   double  frame_off[n_frame][3] frame origin in its joint's frame (world coordinates for frames on the fixed base)
+ *   uint64  frame_anc[n_frame]    bit k set <=> joint k is an ancestor of the frame
+ *   uint64  joint_anc[n_joint]    bit j set <=> joint j is joint k itself or one of its ancestors
+ *   int32   jtype[n_joint], parent[n_joint] (-1 = root), depth[n_joint], src_idx[n_joint], var[n_joint] (-1: not optimised)
+ *   int32   var_api[n_var]        column of last_qpos / qpos_out rows
+ *   int32   fam_off[n_var + 1], fam[n_fam]   joints that move with each variable (kinematics_adaptor.py:102-113 folded)
+ *   int32   frame_joint[n_frame]  (-1 = fixed base)
+ *   int32   term_task[n_term], term_origin[n_term] (-1: position term), term_ref[n_term],
+ *           row_human_origin[n_term] (-1: ref row r = kp[row_human_task[r]]), row_human_task[n_term]  (indexed by REF ROW;
+ *           a generic model has exactly one term per reference row)
+ * int32 arrays are padded to a multiple of two entries so that everything stays 8-byte aligned. */
+#define DEXR_GEN_MAGIC 0x47584544u /* "DEXG" */
+#define DEXR_GEN_MAXJ 64 /* joints, variables, frames and terms of a generic model (one lane each; 64-bit ancestor masks) */
+typedef struct dexr_gen_header {
+  uint32_t magic;
+  int32_t n_joint, n_frame, n_term, n_var, n_fam, max_depth;
+  int32_t has_keypoint_map; /* term_human_* filled: raw keypoint input is available */
+} dexr_gen_header;
+
 #endif /* DEXR_TABLES_H */

@@ -296,7 +296,26 @@ def write_urdf(path: str, robot_name: str, js: List[J]):
         f.write("\n".join(lines) + "\n")
 
 
+def arm_shadow() -> List[J]:
+    """TEST fixture (tests/urdf/arm_shadow_hand_right.urdf): a 7-DoF arm carrying the Shadow hand fixture = 31 movable
+    joints in ONE kinematic chain family (37 with the 6 dummy free joints): more than the fixed-size component tables
+    hold, i.e. a model only the general kernel serves.  Arm geometry: alternating roll / pitch joints, authored."""
+    arm = [
+        rev("arm_j1", "arm_base", "arm_l1", (0, 0, 0.15), (0, 0, 1), -2.9, 2.9),
+        rev("arm_j2", "arm_l1", "arm_l2", (0, 0, 0.18), (0, 1, 0), -1.8, 1.8),
+        rev("arm_j3", "arm_l2", "arm_l3", (0, 0, 0.20), (0, 0, 1), -2.9, 2.9, rpy=(0, 0, 0.3)),
+        rev("arm_j4", "arm_l3", "arm_l4", (0.03, 0, 0.20), (0, -1, 0), -0.1, 2.6),
+        rev("arm_j5", "arm_l4", "arm_l5", (-0.03, 0, 0.19), (0, 0, 1), -2.9, 2.9),
+        rev("arm_j6", "arm_l5", "arm_l6", (0, 0, 0.19), (0, 1, 0), -1.9, 1.9),
+        rev("arm_j7", "arm_l6", "arm_l7", (0, 0, 0.08), (0, 0, 1), -3.0, 3.0),
+        fix("arm_to_hand", "arm_l7", "forearm", (0, 0, 0.02), rpy=(0, 0, 1.5707963267948966)),
+    ]
+    return arm + shadow()[1]
+
+
 def main():
+    tests_urdf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "urdf")
+    write_urdf(os.path.join(tests_urdf, "arm_shadow_hand_right.urdf"), "arm_shadow_hand_right", arm_shadow())
     for fn in (allegro, shadow, leap, ability, inspire):
         d, js = fn()
         write_urdf(os.path.join(ROOT, d, f"{d}_right.urdf"), f"{d}_right", js)
