@@ -176,19 +176,25 @@ class DeviceSeqRetargeting:
         self.num_retargeting += T
         return out
 
-    def capture(self, keypoints_seq, out=None):
+    def capture(self, keypoints_seq, out=None, fixed_seq=None):
         """Capture T lock-step frames into ONE HIP graph (``torch.cuda.CUDAGraph``): ``keypoints_seq`` is a persistent
         (T, B, 21, 3) float32 CUDA tensor the caller refills before every ``graph.replay()``; ``out`` (T, B, dof)
         float64 receives the filtered robot qpos of every frame.  The carried state (last_qpos, filter, DexPilot bits)
         lives in HBM, so consecutive replays continue the sequences: T kernel launches + ~10 T element-wise ops cost
         one graph launch.  At least one eager frame must have run before (the low-pass filter's first frame is a
-        host-side branch).  Returns (graph, out)."""
+        host-side branch).  Models with caller-supplied fixed joints take ``fixed_seq``, a persistent (T, B, n_fixed)
+        float32 CUDA tensor refilled the same way.  Returns (graph, out)."""
         torch = self.torch
         if self.alpha is not None and not self._filter_init:
             raise RuntimeError("run one eager frame first: the first frame initialises the low-pass filter")
-        if self.n_fixed:
-            raise NotImplementedError("capture() serves models without caller-supplied fixed joints")
         T = int(keypoints_seq.shape[0])
+        if self.n_fixed:
+            if fixed_seq is None:
+                raise ValueError(f"Optimizer has {self.n_fixed} joints but non_target_qpos None is given")
+            if fixed_seq.dtype != torch.float32 or not fixed_seq.is_contiguous() or fixed_seq.device != self.device or \
+                    tuple(fixed_seq.shape) != (T, self.batch, self.n_fixed):
+                raise ValueError(f"fixed_seq must be a contiguous float32 tensor of shape ({T}, {self.batch}, {self.n_fixed}) "
+                                 f"on this device")
         if keypoints_seq.dtype != torch.float32 or not keypoints_seq.is_contiguous() or keypoints_seq.device != self.device:
             raise ValueError("keypoints_seq must be a contiguous float32 tensor on this device")
         if out is None:
@@ -196,7 +202,7 @@ class DeviceSeqRetargeting:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             for t in range(T):
-                out[t].copy_(self.retarget(keypoints_seq[t], None, _keypoints=True))
+                out[t].copy_(self.retarget(keypoints_seq[t], fixed_seq[t] if self.n_fixed else None, _keypoints=True))
         self.num_retargeting -= T  # capture itself solves nothing
         return graph, out
 

@@ -1168,3 +1168,33 @@ def test_damping_default_follows_the_dispatched_kernel_family():
     model.tune(lam_jump=0.5)  # an explicit value survives family changes
     model.tune(kernel=_lib.KERNEL_LDS)
     assert abs(model.get_tuning().lam_jump - 0.5) < 1e-7
+
+
+def test_hip_graph_capture_with_caller_fixed_joints():
+    """DeviceSeqRetargeting.capture() on a model whose non-target joints arrive per frame (fixed_qpos): the captured
+    graph replays to the eager answers."""
+    torch = pytest.importorskip("torch")
+    names = ["joint_0.0", "joint_1.0", "joint_2.0", "joint_3.0", "joint_12.0", "joint_13.0", "joint_14.0", "joint_15.0",
+             "joint_5.0", "joint_9.0"]
+    cfg = dict(type="vector", urdf_path="allegro_hand/allegro_hand_right.urdf", target_joint_names=names,
+               target_origin_link_names=["wrist"] * 4,
+               target_task_link_names=["link_15.0_tip", "link_3.0_tip", "link_7.0_tip", "link_11.0_tip"],
+               target_link_human_indices=np.array([[0, 0, 0, 0], [4, 8, 12, 16]]), scaling_factor=1.6, low_pass_alpha=0.3)
+    B, T = 64, 4
+    dev = torch.device("cuda:0")
+    kp = torch.from_numpy(np.stack([cases.human_keypoints(B, seed=70 + t) for t in range(T + 1)])).to(dev)
+    fixed = (0.2 * torch.rand((T + 1, B, 6), device=dev)).contiguous()
+    eager = RetargetingConfig.from_dict(cfg).build_device(B)
+    graphd = RetargetingConfig.from_dict(cfg).build_device(B)
+    want = []
+    for t in range(T + 1):
+        want.append(eager.retarget_keypoints(kp[t], fixed[t]).clone())
+    graphd.retarget_keypoints(kp[0], fixed[0])  # the eager first frame initialises the filter
+    buf_kp, buf_fx = kp[1:].clone().contiguous(), fixed[1:].clone().contiguous()
+    with pytest.raises(ValueError, match="non_target_qpos"):
+        graphd.capture(buf_kp)
+    g, out = graphd.capture(buf_kp, fixed_seq=buf_fx)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.allclose(out, torch.stack(want[1:]), atol=1e-6, rtol=0)
+
