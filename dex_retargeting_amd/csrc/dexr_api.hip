@@ -266,11 +266,28 @@ int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st)
   kp.queue = m->d_queue + (size_t)slot * kp.n_comp;
   hipError_t qe = hipMemsetAsync(kp.queue, 0, (size_t)kp.n_comp * sizeof(unsigned), st);
   if (qe != hipSuccess) return fail(DEXR_ERR_HIP, "queue reset failed: %s", hipGetErrorString(qe));
+#ifdef DEXR_WIDE_PROF
+  static double* wprof = nullptr;  // profiling build only: stage cycles of wave 0 (dexr_wide.hpp WPROF_*)
+  if (!wprof) (void)hipMalloc((void**)&wprof, 12 * sizeof(double));
+  (void)hipMemsetAsync(wprof, 0, 12 * sizeof(double), st);
+  kp.g64out = wprof;
+#endif
   dexr::wide_launch_fn fn = m->wide_mimic ? (m->wide_modchol ? dexr::launch_wide_mc_16 : dexr::launch_wide_m_16)
                                           : dexr::find_wide_launcher(m->bucket);
   if (!fn) return fail(DEXR_ERR_UNSUPPORTED, "no sixteen-lane kernel for bucket %d", m->bucket);
   hipError_t e = fn(kp, m->d_wide, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, st);
   if (e != hipSuccess) return fail(DEXR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+#ifdef DEXR_WIDE_PROF
+  {
+    double h[12];
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h, wprof, sizeof(h), hipMemcpyDeviceToHost);
+    const char* names[9] = {"hand-out", "fk", "terms", "term loop", "2nd order", "accept/active set", "factor+solve", "step", "retire"};
+    fprintf(stderr, "[wprof] B=%lld passes(wave 0)=%.0f cycles per pass:", (long long)kp.B, h[11]);
+    for (int i = 0; i < 9; ++i) fprintf(stderr, " %s %.0f |", names[i], h[11] > 0 ? h[i] / h[11] : 0.0);
+    fprintf(stderr, "\n");
+  }
+#endif
   return DEXR_OK;
 }
 

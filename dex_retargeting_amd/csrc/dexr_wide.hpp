@@ -81,6 +81,23 @@ static __device__ __forceinline__ float wquad_bcast(float v) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), Q * 0x55, 0xF, 0xF, true));
 }
 
+// -DDEXR_WIDE_PROF=1 (tools/prof_wide_stages.sh; never in the shipped library): wave 0 of block 0 accumulates the cycles
+// (s_memtime) of every stage of its passes and adds them to kp.g64out[stage] when it retires.
+#ifdef DEXR_WIDE_PROF
+#define WPROF_DECL long long wp_t0 = 0, wp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define WPROF_START() wp_t0 = clock64()
+#define WPROF_STAGE(i)                    \
+  {                                       \
+    const long long wp_t1 = clock64();    \
+    wp_acc[i] += wp_t1 - wp_t0;           \
+    wp_t0 = wp_t1;                        \
+  }
+#else
+#define WPROF_DECL
+#define WPROF_START()
+#define WPROF_STAGE(i)
+#endif
+
 typedef float wv2 __attribute__((ext_vector_type(2)));  // register pair: v_pk_fma_f32 / v_pk_mul_f32 operands
 
 #ifndef DEXR_WIDE_MINW
@@ -101,7 +118,10 @@ struct WideLds {
   static constexpr int ANC = CH + 256;                 // NMAX words: revolute ancestors-or-self of each joint
   static constexpr int BOX = ANC + NMAX * 4;           // NMAX x (lo, hi): box of each grid variable
   static constexpr int PL = BOX + NMAX * 8;            // MIMIC: second-order pair list, 128 words + 17 lane offsets
-  static constexpr int SLOT0 = PL + (MIMIC ? 512 + 32 : 0);
+  static constexpr int TM = PL + (MIMIC ? 512 + 32 : 0);  // MIMIC: 16 terms x (ancestor mask of the task frame, of the
+                                                       // origin frame); the joint-space grids keep them in the spare
+                                                       // words 13 / 14 of XT row t
+  static constexpr int SLOT0 = TM + (MIMIC ? 128 : 0);
   // per frame slot
   static constexpr int P = 0;                          // 16 frames x 3 doubles
   static constexpr int AX = P + 384;                   // NJ x 4 floats
@@ -163,6 +183,10 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   float* BOXw = reinterpret_cast<float*>(wbase + L::BOX);
   uint32_t* PLw = reinterpret_cast<uint32_t*>(wbase + L::PL);
   unsigned char* POFF = wbase + L::PL + 512;
+  // per-term ancestor masks (mt, mo): read with the term's block at the top of every iteration of the term loop instead of
+  // two DEPENDENT scalar loads from the tables (term_task -> frame_anc: ~2 scalar-memory round trips per term and pass)
+  uint32_t* TMw = MIMIC ? reinterpret_cast<uint32_t*>(wbase + L::TM) : reinterpret_cast<uint32_t*>(wbase + L::XT) + 13;
+  constexpr int TMS = MIMIC ? 2 : 16;  // words between consecutive terms' mask pairs
   unsigned char* sbase = wbase + L::SLOT0 + (size_t)slot * L::SLOT;
   double* Pl = reinterpret_cast<double*>(sbase + L::P);
   float* AXl = reinterpret_cast<float*>(sbase + L::AX);
@@ -190,6 +214,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   auto row_of = [&](int64_t it) -> int64_t { return kp.perm ? (int64_t)kp.perm[pbase + it] : it; };
   const int ld = kp.ld;
   const bool seq = kp.T > 0;
+  WPROF_DECL
 
   // ---- wave-constant tables into LDS (lane-varying joint indices read them in the kinematics) ----------------------
   for (int k = lane; k < NJ; k += 64) {
@@ -197,9 +222,19 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 #pragma unroll
     for (int i = 0; i < 12; ++i) XT[k * 16 + i] = in ? tb.X[k][i] : 0.f;
     XT[k * 16 + 12] = __int_as_float(in ? (tb.fbeg[k] | (tb.fend[k] << 8)) : 0);
-    XT[k * 16 + 13] = __int_as_float((in && MIMIC) ? tb.var[k] + 1 : 0);  // 0: not driven by a variable (fixed joint)
-    XT[k * 16 + 14] = (in && MIMIC) ? tb.vmul[k] : 0.f;
-    XT[k * 16 + 15] = (in && MIMIC) ? tb.off[k] : 0.f;
+    if (MIMIC) {
+      XT[k * 16 + 13] = __int_as_float(in ? tb.var[k] + 1 : 0);  // 0: not driven by a variable (fixed joint)
+      XT[k * 16 + 14] = in ? tb.vmul[k] : 0.f;
+      XT[k * 16 + 15] = in ? tb.off[k] : 0.f;
+    } else {
+      XT[k * 16 + 15] = 0.f;
+    }
+  }
+  for (int t = lane; t < 16; t += 64) {
+    const bool in = t < nt;
+    const int ft = in ? tb.term_task[t] : 0, fo = in ? tb.term_origin[t] : -1;
+    TMw[t * TMS] = in ? tb.frame_anc[ft] : 0u;
+    TMw[t * TMS + 1] = (in && fo >= 0) ? tb.frame_anc[fo] : 0u;
   }
   if (MIMIC) {
     for (int i = lane; i < 128; i += 64) PLw[i] = wt.pair[i];
@@ -219,6 +254,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   for (int k = 0; k < NJ; ++k)
     if (k < nj && tb.jtype[k] == DEXR_JOINT_REVOLUTE) revmask |= 1u << k;
 
+  const bool any_prismatic = revmask != (nj >= 32 ? 0xFFFFFFFFu : ((1u << nj) - 1u));  // wave-uniform
   // ---- per-lane constants: the joints this lane owns (l, l + 16) and the ancestor masks of its Hessian rows ---------
   int jo_[NJ2];
   bool jin[NJ2], jopt[NJ2], jrev[NJ2], jfix[NJ2];
@@ -646,6 +682,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   };
   auto assemble = [&]() -> double {
     const double Fv = terms();
+    WPROF_STAGE(2)
 
     // (2) own joints' axes / origins; accumulators of the pass: data-term gradient and second-order vector
     constexpr int NCOL = MIMIC ? FAM : NJ2;  // joints whose columns this lane forms
@@ -665,6 +702,17 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     for (int i = 0; i < NR; ++i)
 #pragma unroll
       for (int j = 0; j < NP; ++j) Hn[i][j] = wv2{0.f, 0.f};
+    // packed views of the two joint slots (NJ2 == 2, joint-space grids): axes / origins, accumulators, per-lane masks
+    constexpr int S1 = (!MIMIC && NJ2 == 2) ? 1 : 0;
+    wv2 jax2[3], jog2[3], jcf2[3], gnew2 = wv2{0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      jax2[i] = wv2{jax[0][i], jax[S1][i]};
+      jog2[i] = wv2{jog[0][i], jog[S1][i]};
+      jcf2[i] = wv2{0.f, 0.f};
+    }
+    const wv2 jm2 = wv2{jopt[0] ? 1.f : 0.f, jopt[NJ2 - 1] ? 1.f : 0.f};  // optimised joints only
+    const wv2 jr2 = wv2{jrev[0] ? 1.f : 0.f, jrev[NJ2 - 1] ? 1.f : 0.f};  // revolute joints
 
     // (3) terms in sequence: lane l forms the Jacobian columns of its joints (l, l + 16), accumulates their gradient
     // entries and second-order vectors and publishes the term's four weighted Jacobian rows; then every lane adds the
@@ -673,16 +721,16 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     // 24 joints move a DexPilot pair -- with the owner lanes collecting gradient / second-order entries through LDS:
     // 37 % fewer VALU instructions in this loop, the same 1.9 ms for Shadow DexPilot and 10 % slower for the 16-joint
     // hands; the pass is bound by LDS round trips, not by VALU issue.)
-#pragma clang loop unroll(disable) vectorize(disable)
-    for (int t = 0; t < nt; ++t) {
+    const int nrow = per_coord ? 3 : 4;  // SmoothL1 per coordinate has no rank-one row
+    // columns of term t -> gradient / second-order accumulators and the term's weighted Jacobian rows in buffer `buf`
+    auto publish = [&](int t) {
+      float* JRw = JRl;
       const float* T = TBl + t * 16;
       const float4 t0 = *reinterpret_cast<const float4*>(T);
       const float4 t1 = *reinterpret_cast<const float4*>(T + 4);
       const float4 t2 = *reinterpret_cast<const float4*>(T + 8);
       const float4 t3 = *reinterpret_cast<const float4*>(T + 12);
-      const int ft = tb.term_task[t], fo = tb.term_origin[t];
-      const uint32_t mt = tb.frame_anc[ft];
-      const uint32_t mo = (fo >= 0) ? tb.frame_anc[fo] : 0u;
+      const uint32_t mt = TMw[t * TMS], mo = TMw[t * TMS + 1];
       if (MIMIC) {
         // the variable's column is the vmul-weighted sum over its joint family (kinematics_adaptor.py:102-113)
         float c0 = 0, c1 = 0, c2 = 0;
@@ -714,44 +762,76 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         }
         gnew[0] += c0 * t1.x + c1 * t1.y + c2 * t1.z;
         const int pos = (l & 3) * NRP + (l >> 2);
-        JRl[0 * 4 * NRP + pos] = c0 * t1.w;
-        JRl[1 * 4 * NRP + pos] = c1 * t2.w;
-        JRl[2 * 4 * NRP + pos] = c2 * t3.w;
-        if (!per_coord) JRl[3 * 4 * NRP + pos] = (c0 * t0.x + c1 * t0.y + c2 * t0.z) * t0.w;
+        JRw[0 * 4 * NRP + pos] = c0 * t1.w;
+        JRw[1 * 4 * NRP + pos] = c1 * t2.w;
+        JRw[2 * 4 * NRP + pos] = c2 * t3.w;
+        if (!per_coord) JRw[3 * 4 * NRP + pos] = (c0 * t0.x + c1 * t0.y + c2 * t0.z) * t0.w;
+      } else if (NJ2 == 2) {
+        // both joint slots of the lane (l, l + 16) at once in packed float32 arithmetic (v_pk_*): the two columns are
+        // the same formula on different operands, and a pass is bound by the number of VALU instructions issued.
+        //   v = in_t (p_task - o) - in_o (p_origin - o);  column = a x v (revolute)  |  (in_t - in_o) a (prismatic)
+        const wv2 ft = wv2{(float)((mt >> l) & 1u), (float)((mt >> (l + 16)) & 1u)} * jm2;
+        const wv2 fo = wv2{(float)((mo >> l) & 1u), (float)((mo >> (l + 16)) & 1u)} * jm2;
+        const wv2 sg = ft - fo;
+        wv2 v[3], c[3];
+        v[0] = ft * t2.x - fo * t3.x - sg * jog2[0];
+        v[1] = ft * t2.y - fo * t3.y - sg * jog2[1];
+        v[2] = ft * t2.z - fo * t3.z - sg * jog2[2];
+        c[0] = jax2[1] * v[2] - jax2[2] * v[1];
+        c[1] = jax2[2] * v[0] - jax2[0] * v[2];
+        c[2] = jax2[0] * v[1] - jax2[1] * v[0];
+        if (any_prismatic) {  // wave-uniform: only models with translation joints (the dummy free base) pay for the blend
+          const wv2 w = (wv2{1.f, 1.f} - jr2) * sg;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) c[i] = c[i] * jr2 + jax2[i] * w;
+        }
+        gnew2 += c[0] * t1.x + c[1] * t1.y + c[2] * t1.z;
+        jcf2[0] += c[1] * t1.z - c[2] * t1.y;
+        jcf2[1] += c[2] * t1.x - c[0] * t1.z;
+        jcf2[2] += c[0] * t1.y - c[1] * t1.x;
+        const wv2 r0 = c[0] * t1.w, r1 = c[1] * t2.w, r2 = c[2] * t3.w;
+        const wv2 r3 = (c[0] * t0.x + c[1] * t0.y + c[2] * t0.z) * t0.w;
+        // row k of the term's Jacobian^T: position (k mod 4) * NRP + k / 4 of each of the four rows (k = l, l + 16)
+        const int pos0 = (l & 3) * NRP + (l >> 2), pos1 = pos0 + 4;
+        JRw[0 * 4 * NRP + pos0] = r0.x; JRw[0 * 4 * NRP + pos1] = r0.y;
+        JRw[1 * 4 * NRP + pos0] = r1.x; JRw[1 * 4 * NRP + pos1] = r1.y;
+        JRw[2 * 4 * NRP + pos0] = r2.x; JRw[2 * 4 * NRP + pos1] = r2.y;
+        if (!per_coord) { JRw[3 * 4 * NRP + pos0] = r3.x; JRw[3 * 4 * NRP + pos1] = r3.y; }
       } else {
 #pragma unroll
-      for (int s = 0; s < NJ2; ++s) {
-        const int k = jo_[s];
-        const bool in_t = (mt >> k) & 1u, in_o = (mo >> k) & 1u;
-        float c0 = 0, c1 = 0, c2 = 0;
-        if (jopt[s] && (in_t || in_o)) {
-          if (jrev[s]) {
-            float v0 = 0, v1 = 0, v2 = 0;
-            if (in_t) { v0 += t2.x - jog[s][0]; v1 += t2.y - jog[s][1]; v2 += t2.z - jog[s][2]; }
-            if (in_o) { v0 -= t3.x - jog[s][0]; v1 -= t3.y - jog[s][1]; v2 -= t3.z - jog[s][2]; }
-            c0 = jax[s][1] * v2 - jax[s][2] * v1;
-            c1 = jax[s][2] * v0 - jax[s][0] * v2;
-            c2 = jax[s][0] * v1 - jax[s][1] * v0;
-          } else {
-            const float sg = (in_t ? 1.f : 0.f) - (in_o ? 1.f : 0.f);
-            c0 = sg * jax[s][0]; c1 = sg * jax[s][1]; c2 = sg * jax[s][2];
+        for (int s = 0; s < NJ2; ++s) {
+          const int k = jo_[s];
+          const bool in_t = (mt >> k) & 1u, in_o = (mo >> k) & 1u;
+          float c0 = 0, c1 = 0, c2 = 0;
+          if (jopt[s] && (in_t || in_o)) {
+            if (jrev[s]) {
+              float v0 = 0, v1 = 0, v2 = 0;
+              if (in_t) { v0 += t2.x - jog[s][0]; v1 += t2.y - jog[s][1]; v2 += t2.z - jog[s][2]; }
+              if (in_o) { v0 -= t3.x - jog[s][0]; v1 -= t3.y - jog[s][1]; v2 -= t3.z - jog[s][2]; }
+              c0 = jax[s][1] * v2 - jax[s][2] * v1;
+              c1 = jax[s][2] * v0 - jax[s][0] * v2;
+              c2 = jax[s][0] * v1 - jax[s][1] * v0;
+            } else {
+              const float sg = (in_t ? 1.f : 0.f) - (in_o ? 1.f : 0.f);
+              c0 = sg * jax[s][0]; c1 = sg * jax[s][1]; c2 = sg * jax[s][2];
+            }
+            gnew[s] += c0 * t1.x + c1 * t1.y + c2 * t1.z;
+            jcf[s][0] += c1 * t1.z - c2 * t1.y;
+            jcf[s][1] += c2 * t1.x - c0 * t1.z;
+            jcf[s][2] += c0 * t1.y - c1 * t1.x;
           }
-          gnew[s] += c0 * t1.x + c1 * t1.y + c2 * t1.z;
-          jcf[s][0] += c1 * t1.z - c2 * t1.y;
-          jcf[s][1] += c2 * t1.x - c0 * t1.z;
-          jcf[s][2] += c0 * t1.y - c1 * t1.x;
+          // row k of the term's Jacobian^T: position (k mod 4) * NRP + k / 4 of each of the four rows
+          const int pos = (k & 3) * NRP + (k >> 2);
+          JRw[0 * 4 * NRP + pos] = c0 * t1.w;
+          JRw[1 * 4 * NRP + pos] = c1 * t2.w;
+          JRw[2 * 4 * NRP + pos] = c2 * t3.w;
+          if (!per_coord) JRw[3 * 4 * NRP + pos] = (c0 * t0.x + c1 * t0.y + c2 * t0.z) * t0.w;
         }
-        // row k of the term's Jacobian^T: position (k mod 4) * NRP + k / 4 of each of the four rows
-        const int pos = (k & 3) * NRP + (k >> 2);
-        JRl[0 * 4 * NRP + pos] = c0 * t1.w;
-        JRl[1 * 4 * NRP + pos] = c1 * t2.w;
-        JRl[2 * 4 * NRP + pos] = c2 * t3.w;
-        if (!per_coord) JRl[3 * 4 * NRP + pos] = (c0 * t0.x + c1 * t0.y + c2 * t0.z) * t0.w;
       }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const int nrow = per_coord ? 3 : 4;  // SmoothL1 per coordinate has no rank-one row
+    };
+    // every lane adds the outer products of the rows in buffer `buf` to its Hessian entries
+    auto outer = [&]() {
+      const float* JRr = JRl;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         if (kk < nrow) {
@@ -760,8 +840,8 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 #pragma unroll
           for (int i = 0; i < NRP; i += 4) {
             if (i < NR) {
-              const float4 rv = *reinterpret_cast<const float4*>(JRl + kk * 4 * NRP + a * NRP + i);
-              const float4 cv = *reinterpret_cast<const float4*>(JRl + kk * 4 * NRP + b * NRP + i);
+              const float4 rv = *reinterpret_cast<const float4*>(JRr + kk * 4 * NRP + a * NRP + i);
+              const float4 cv = *reinterpret_cast<const float4*>(JRr + kk * 4 * NRP + b * NRP + i);
               jr[i] = rv.x; jr[i + 1] = rv.y; jr[i + 2] = rv.z; jr[i + 3] = rv.w;
               jc[i / 2] = wv2{cv.x, cv.y};
               jc[i / 2 + 1] = wv2{cv.z, cv.w};
@@ -776,10 +856,31 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
           }
         }
       }
+    };
+    // (Measured and dropped: publishing term t + 1 into a second row buffer while term t's outer products run -- one
+    // barrier per term, no exposed LDS write -> read latency -- changed nothing: tools/prof_wide_stages.sh shows the same
+    // cycles per pass for a lone wave and for two waves per SIMD, i.e. a pass is bound by the wave's own instruction
+    // issue (~8 cycles per dependent VALU instruction), not by LDS round trips.  Fewer instructions is what helps.)
+#pragma clang loop unroll(disable) vectorize(disable)
+    for (int t = 0; t < nt; ++t) {
+      publish(t);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      outer();
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
 
+    if (!MIMIC && NJ2 == 2) {
+      gnew[0] = gnew2.x;
+      gnew[NJ2 - 1] = gnew2.y;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        jcf[0][i] = jcf2[i].x;
+        jcf[S1][i] = jcf2[i].y;
+      }
+    }
+    WPROF_STAGE(3)
     // (4) second-order kinematic term: H[r][c] += a_c . CF_r for every revolute ancestor-or-self c of r
     if (newton && MIMIC) {
       // H[v][w] += sum over joint pairs (k in family v, j a revolute ancestor-or-self of k in family w) of
@@ -992,6 +1093,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   };
   float screen_acc = 0.f;  // screening launch: sum of F(x0) over the frames of this wave (lane 0 of each row)
   for (;;) {
+    WPROF_START();
     // (0) hand frames to idle rows
     const unsigned long long want = __ballot(!active);
     if (want != 0ull) {
@@ -1025,7 +1127,9 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       if (dry && pool_next >= pool_end) break;
       continue;
     }
+    WPROF_STAGE(0)
     fk();
+    WPROF_STAGE(1)
     if (kp.screen) {
       // SCREENING launch (longest-first ordering, dexr_api.hip: launch_wide): F at the start point is all that is
       // wanted of a frame -- large values mark the frames that will need many passes (DexPilot models: the top 5 % by
@@ -1040,6 +1144,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       continue;
     }
     const double Fe = assemble();
+    WPROF_STAGE(4)
     if (!done) {
       bool take = false;
       if (!pending) {
@@ -1120,7 +1225,9 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    WPROF_STAGE(5)
     const bool okf = factor_and_solve(freemask, lam);
+    WPROF_STAGE(6)
     const bool stepping = !done;
     if (stepping) {
       ok = okf;
@@ -1159,6 +1266,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       }
     }
 
+    WPROF_STAGE(7)
     // (last) retire finished frames
     if (active && done) {
       bool badl = false;
@@ -1193,7 +1301,15 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         done = true;
       }
     }
+    WPROF_STAGE(8)
+#ifdef DEXR_WIDE_PROF
+    wp_acc[11] += 1;
+#endif
   }
+#ifdef DEXR_WIDE_PROF
+  if (kp.g64out && blockIdx.x == 0 && threadIdx.x == 0)
+    for (int i = 0; i < 12; ++i) atomicAdd(&kp.g64out[i], (double)wp_acc[i]);
+#endif
   if (kp.screen && l == 0 && screen_acc != 0.f) atomicAdd(kp.screen_sum, screen_acc);
 }
 
