@@ -235,6 +235,50 @@ class Workload:
                         "and state buffers): launch tails overlap the next launch; throughput figure, the headline "
                         "value above is the single-stream one"}
 
+    def timed_graph(self, batches, steps, comm):
+        """[solve -> dexr_allgather] of len(batches) consecutive steps captured into ONE HIP graph (everything on the
+        capture stream: no host call between the launches) and replayed steps / len(batches) times inside the usual
+        barrier + synchronize bracket: the N > 1 step without the host's per-launch cost."""
+        torch = self.torch
+        from dex_retargeting_amd.distributed import NativeGather
+
+        G = len(batches)
+        if steps % G:
+            return {"skipped": f"steps must be a multiple of {G}"}
+        ng = NativeGather(comm, self.B, self.n_opt, self.dev, depth=G, overlap=False)
+        s = torch.cuda.Stream(device=self.dev)
+        states = [None if self.t_state is None else torch.empty_like(self.t_state) for _ in range(G)]
+
+        def enqueue():
+            for k, b in enumerate(batches):
+                if self.dexpilot:
+                    states[k].copy_(b["t_state0"])
+                out = ng._shard[k]
+                self.model.retarget_dev(self.B, b["t_in"].data_ptr(), 0, b["t_last"].data_ptr(),
+                                        states[k].data_ptr() if self.dexpilot else 0, out.data_ptr(),
+                                        stream=s.cuda_stream, keypoints=b["kind"] == "kp")
+                comm.allgather(out.data_ptr(), ng._full[k].data_ptr(), ng.bytes_per_rank, s.cuda_stream)
+
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            enqueue()  # warm-up outside the capture (RCCL sets its channels up on first use)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            enqueue()
+        g.replay()
+        torch.cuda.synchronize()
+        comm.barrier(self.stream.cuda_stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps // G):
+            g.replay()
+        torch.cuda.synchronize()
+        comm.barrier(self.stream.cuda_stream)
+        elapsed = float(comm.max_f64([time.perf_counter() - t0], self.stream.cuda_stream)[0])
+        return {"value": comm.world * self.B * steps / elapsed, "unit": "frames/s", "ms_per_step": elapsed / steps * 1e3,
+                "note": f"{G} steps of [solve -> all-gather] captured into one HIP graph, replayed {steps // G} times"}
+
     def roofline(self, kernel_ms, iters_mean, batch_kind="kp", precision="f32", world=1):
         bpf = algorithmic_bytes_per_frame(self.n_opt, self.dexpilot, self.n_ref, batch_kind == "kp")
         achieved = self.B * bpf / (kernel_ms * 1e-3) / 1e9
@@ -486,7 +530,7 @@ def job_env(args):
     return rank, local_rank, world, os.environ.get("RANK") is not None
 
 
-def gather_records(timed_fn, comm, B, n_cols, dev, steps, warmup, world):
+def gather_records(timed_fn, comm, B, n_cols, dev, steps, warmup, world, graph_fn=None):
     """The N > 1 figures (also taken with ONE rank when launched by torch.distributed.run, so that the RCCL side runs on a
     1-GPU box): one dexr_allgather per step.  Returns (elapsed, kernel_ms, record dict).
 
@@ -500,12 +544,19 @@ def gather_records(timed_fn, comm, B, n_cols, dev, steps, warmup, world):
     elapsed, kernel_ms = timed_fn(NativeGather(comm, B, n_cols, dev, depth=depth, overlap=True))
     e2, _ = timed_fn(NativeGather(comm, B, n_cols, dev, depth=depth, overlap=False))
     shard_mb = B * n_cols * 4 / 1e6
+    graph = None
+    if graph_fn is not None:
+        try:
+            graph = graph_fn()
+        except Exception as e:  # capture support varies with the RCCL build: never lose the line to it
+            graph = {"error": repr(e)}
     rec = {"collective": "dexr_allgather (C-ABI of libdexr.so -> RCCL ncclAllGather, bound with dlopen), one per step, "
                          "enqueued on a second HIP stream behind an event recorded after the solve; all gathers "
                          "complete inside the timed region",
            "rccl_world_size": world, "rccl_version": comm.rccl_version(),
            "gather_on_solve_stream": {"value": world * B * steps / e2, "unit": "frames/s", "ms_per_step": e2 / steps * 1e3,
                                       "note": "same steps with the all-gather enqueued on the solve stream (serial)"},
+           "graph_replay": graph,
            "xgmi": {"shard_MB_per_rank_per_step": shard_mb, "received_MB_per_gpu_per_step": shard_mb * (world - 1),
                     "note": "every GPU receives (N-1) shards per step over its 7 xGMI links (~76.8 GB/s per link and "
                             "direction, 537 GB/s aggregate ingest at best): the all-gather lower bound per step is "
@@ -539,7 +590,8 @@ def run_single(args):
     if comm is not None:
         elapsed, kernel_ms, coll = gather_records(
             lambda pipe: wl.timed(wl.tracking, args.steps, args.warmup, pipe=pipe, comm=comm),
-            comm, B, wl.n_opt, dev, args.steps, args.warmup, world)
+            comm, B, wl.n_opt, dev, args.steps, args.warmup, world,
+            graph_fn=lambda: wl.timed_graph(wl.tracking, args.steps, comm))
     else:
         elapsed, kernel_ms = wl.timed(wl.tracking, args.steps, args.warmup)
     # per-step answers of the last timed step's batch for the parity check

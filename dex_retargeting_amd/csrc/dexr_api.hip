@@ -65,6 +65,7 @@ struct dexr_model {
   bool wide_ok = false;  // the model fits that kernel (<= 16 root-to-leaf chains of <= 16 joints; with mimic joints:
                          // <= 16 variables moving <= 3 joints each)
   bool wide_mimic = false;  // ... through its variable-grid instantiation (mimic joints folded)
+  int wbucket = 0;          // grid size of the sixteen-lane kernel that serves the model (16 for components of 5-16 joints)
   // longest-first ordering (launch_wide): LSLOTS workspaces handed out round-robin; a slot's last use is fenced by an
   // event, so launches on different streams never share one
   static constexpr int LSLOTS = 4;
@@ -247,13 +248,13 @@ namespace {
 
 // sixteen lanes per frame: four frames per wave, two waves per SIMD resident; persistent rows fed like the quads
 int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
-  const size_t per_wave = m->wide_mimic ? dexr::wide_lds_per_wave_m_16() : dexr::wide_lds_per_wave(m->bucket);
+  const size_t per_wave = m->wide_mimic ? dexr::wide_lds_per_wave_m_16() : dexr::wide_lds_per_wave(m->wbucket);
   int wpb = 4;
   while (wpb > 1 && per_wave * wpb > 80 * 1024) wpb >>= 1;
   const int64_t tiles = (kp.B + 3) / 4;
   // waves per SIMD: 2 (256 VGPRs; 15-17 KB of LDS per wave); the 16-row joint grid is built for 3 (168 VGPRs, 11.8 KB):
   // LEAP DexPilot 1.24 -> 1.14 ms, Allegro DexPilot 0.84 -> 0.75 ms
-  const int occ = (!m->wide_mimic && m->bucket == 16) ? 3 : 2;
+  const int occ = (!m->wide_mimic && m->wbucket == 16) ? 3 : 2;
   int64_t resident = (int64_t)m->n_cu * 4 * occ;
   if (m->tune.resident_waves > 0) resident = m->tune.resident_waves;
   int64_t per_comp = (resident + kp.n_comp - 1) / kp.n_comp;
@@ -273,8 +274,8 @@ int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st)
   kp.g64out = wprof;
 #endif
   dexr::wide_launch_fn fn = m->wide_mimic ? (m->wide_modchol ? dexr::launch_wide_mc_16 : dexr::launch_wide_m_16)
-                                          : dexr::find_wide_launcher(m->bucket);
-  if (!fn) return fail(DEXR_ERR_UNSUPPORTED, "no sixteen-lane kernel for bucket %d", m->bucket);
+                                          : dexr::find_wide_launcher(m->wbucket);
+  if (!fn) return fail(DEXR_ERR_UNSUPPORTED, "no sixteen-lane kernel for bucket %d", m->wbucket);
   hipError_t e = fn(kp, m->d_wide, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, st);
   if (e != hipSuccess) return fail(DEXR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
 #ifdef DEXR_WIDE_PROF
@@ -354,7 +355,8 @@ int launch_wide(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
 bool build_wide_tables(dexr_model* m) {
   m->wide_tabs.clear();
   m->wide_mimic = m->has_mimic;
-  if (m->bucket < 16 || m->h.kind == DEXR_KIND_FKONLY) return false;
+  m->wbucket = m->bucket < 16 ? 16 : m->bucket;
+  if (m->bucket < 8 || m->h.kind == DEXR_KIND_FKONLY) return false;
   if (m->has_mimic && (m->max_vars > 16 || m->max_joints > 32)) return false;
   for (const dexr_comp_table& c : m->comps) {
     dexr::WideTable w;
@@ -665,6 +667,13 @@ int create_generic(const dexr_model_header& h, const char* body, size_t nbytes, 
 // joints (Shadow 6.3 ms vs 35.8 ms register + float64 polish; LEAP 3.8-4.4 vs 6.5 ms; Allegro 2.0-2.3 vs 2.1-2.6 ms) and
 // for position models with free joints (LEAP 3.3 vs 9.5 ms LDS kernel); the register kernel stays ahead for Shadow
 // vector (1.9-3.0 vs 3.2-3.9 ms).  tune.kernel overrides the policy where the chosen family supports the model.
+// One dense component of 5-8 joints (Panda gripper + 6 free joints, position objective): the register kernel solves it
+// in one lane per frame and needs its float64 polish launch; measured on MI355X (65 536 frames, tools/all_configs.py):
+// 1.06 ms there vs the sixteen-lane kernel's figure recorded in DESIGN.md section 4.
+bool wide_wins_small(const dexr_model* m) {
+  return m->bucket == 8 && m->h.n_comp == 1 && (m->h.kind == DEXR_KIND_POSITION || m->h.kind == DEXR_KIND_DEXPILOT);
+}
+
 void select_kernels(dexr_model* m) {
   const dexr_model_header& h = m->h;
   const int want = m->tune.kernel;
@@ -685,7 +694,8 @@ void select_kernels(dexr_model* m) {
   // sixteen lanes per frame: measured ahead of every other family on every model it supports (Shadow DexPilot 1.9 vs
   // 6.4 ms quad, LEAP position 2.1 vs 5.0 ms quad, Shadow vector 1.2 vs 1.9-3.0 ms register, Shadow + free joints 9.8 vs
   // 23-29 ms LDS; 65 536 frames)
-  m->wide = m->wide_ok && (want == DEXR_KERNEL_WIDE || want == DEXR_KERNEL_AUTO);
+  // (components of 5-8 joints fit the 16-row grid too: measured policy below)
+  m->wide = m->wide_ok && (want == DEXR_KERNEL_WIDE || (want == DEXR_KERNEL_AUTO && (m->bucket >= 16 || wide_wins_small(m))));
   // mimic vector models (SVH: two small components) stay on the reduced-variable kernel: 0.7-0.8 vs 0.9-1.1 ms
   if (m->wide && m->has_mimic && want == DEXR_KERNEL_AUTO && h.kind == DEXR_KIND_VECTOR && red_ok) m->wide = false;
   // (the modified-Cholesky rules are instantiated for the variable-grid kernel only)

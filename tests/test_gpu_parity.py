@@ -1084,25 +1084,34 @@ def test_host_pointer_path_equals_device_pointer_path_bitwise(rel, B):
 
 
 def test_host_pointer_calls_do_not_touch_other_streams():
-    """The host entry points run on the handle's private stream and wait for that stream only: a long-running launch on
-    another stream of the process is still in flight when a B = 1 call returns."""
+    """The host entry points run on the handle's private stream and wait for that stream only: with ~100 ms of work queued
+    on another stream of the process, a B = 1 call returns in a fraction of that time and the other stream is still busy."""
+    import time
+
     torch = pytest.importorskip("torch")
     seq, prob = build("teleop/allegro_hand_right.yml")
     model = seq.optimizer.device_model()
     d = cases.reachable_set(prob, 1, 0.05)
-    model.retarget(d["ref"], None, d["last"])
+    for _ in range(3):
+        model.retarget(d["ref"], None, d["last"])
     side = torch.cuda.Stream()
     big = torch.empty(1 << 28, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
     done = torch.cuda.Event()
+    t0 = time.perf_counter()
     with torch.cuda.stream(side):
-        for _ in range(40):
+        for _ in range(300):  # ~0.9 ms each; the host's launch queue throttles this loop, the GPU stays ~100 ms behind
             big.mul_(1.0001)
         done.record(side)
+    t1 = time.perf_counter()
     q = model.retarget(d["ref"], None, d["last"])
+    t_call = time.perf_counter() - t1
     still_running = not done.query()
     torch.cuda.synchronize()
+    t_side = time.perf_counter() - t0
     assert np.all(np.isfinite(q))
     assert still_running, "the host-pointer call waited for an unrelated stream"
+    assert t_call < 0.25 * t_side, (t_call, t_side)
 
 
 def test_native_allgather_world_size_one_and_graph_capture():
