@@ -2,9 +2,11 @@
 //
 // The reference's callers hand over one frame at a time (SeqRetargeting.retarget, 621 calls in
 // /root/reference/example/profiling/profile_online_retargeting.py:18-36): for that regime the cost of a call is the
-// host path around the kernel, not the kernel.  A context owns
-//   * a private non-blocking stream (no hipDeviceSynchronize: other streams of the process are never stalled),
-//   * one grow-only pinned host buffer and one grow-only device buffer,
+// host path around the kernel, not the kernel.  A context uses
+//   * the library's private non-blocking stream of the current device (no hipDeviceSynchronize: other streams of the
+//     process are never stalled; ONE stream per device for all handles -- HIP multiplexes streams onto a handful of
+//     hardware queues, and a stream per model handle would soon share a queue with the caller's own streams),
+//   * its own grow-only pinned host buffer and grow-only device buffer,
 // and a call packs every array into ONE contiguous block laid out  [ inputs | in-out | outputs ]  so that it costs one
 // host-to-device copy of [inputs | in-out], the launches, and one device-to-host copy of [in-out | outputs], all on the
 // private stream, then one hipStreamSynchronize.  No hipMalloc / hipFree on the call path once the buffers have grown.
@@ -17,9 +19,26 @@
 
 namespace dexr {
 
+// the library's private stream of the current device (created on first use, never destroyed)
+inline hipError_t host_stream(hipStream_t* out) {
+  static std::mutex mu;
+  static hipStream_t streams[64] = {};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!streams[dev]) {
+    e = hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+  }
+  *out = streams[dev];
+  return hipSuccess;
+}
+
 struct HostCtx {
   std::mutex mu;  // host-pointer calls through one context are serialised (the staging block is shared)
-  hipStream_t st = nullptr;
+  hipStream_t st = nullptr;  // = host_stream() of the device the context was first used on (not owned)
   unsigned char* pin = nullptr;
   size_t pin_bytes = 0;
   unsigned char* dev = nullptr;
@@ -32,7 +51,6 @@ struct HostCtx {
   void release() {
     if (dev) (void)hipFree(dev);
     if (pin) (void)hipHostFree(pin);
-    if (st) (void)hipStreamDestroy(st);
     dev = pin = nullptr;
     st = nullptr;
     dev_bytes = pin_bytes = 0;
@@ -40,7 +58,7 @@ struct HostCtx {
   hipError_t ensure(size_t bytes) {
     hipError_t e = hipSuccess;
     if (!st) {
-      e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+      e = host_stream(&st);
       if (e != hipSuccess) return e;
     }
     if (dev_bytes < bytes) {
