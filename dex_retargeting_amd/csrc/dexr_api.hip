@@ -1284,10 +1284,14 @@ int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, i
   if (status_out) HIP_TRY(hipMemsetAsync(status_out, 0, (size_t)B * sizeof(int32_t), st));
   const int32_t* bucket = ws + 2 * DEXR_FLEET_MAX_MODELS;
   const int32_t* perm = ws + dexr_fleet_ws_ints();
-  // The models' buckets are disjoint rows: their launches are independent.  With fork_streams on, the HEAVY models
-  // (components of 9+ joints: persistent kernels that hold a SIMD's whole register file and end in a long tail of a few
-  // slow frames) go first, each to an internal HIGH-PRIORITY stream; the light models (small components, tens of
-  // microseconds each) follow on the caller's stream and fill the CUs the heavy launches' tails leave idle.
+  // The models' buckets are disjoint rows: their launches are independent.  With fork_streams on, the first HEAVY model
+  // (components of 9+ joints: a persistent kernel that holds every SIMD's register file and ends in a long tail of a few
+  // slow frames) stays on the caller's stream, so it starts the moment the bucketing kernels end; further heavy models
+  // get an internal stream each; ALL light models (small components, tens of microseconds each) go to one more internal
+  // stream behind the fork event -- they reach the GPU a few microseconds later, find it full, and fill the CUs as the
+  // heavy launch's waves retire.  (Measured the other way round -- light models on the caller's stream, heavy ones
+  // forked -- the light kernels usually won the race for the CUs and the persistent blocks that had to wait stretched the
+  // heavy launch from 1.0 to 1.4 ms.)
   ForkPool* fp = (n_models > 1 && models[0]->tune.fork_streams != 0) ? fork_pool() : nullptr;
   std::unique_lock<std::mutex> lock;
   if (fp) {
@@ -1297,22 +1301,28 @@ int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, i
   }
   int rc_all = DEXR_OK;
   bool forked[DEXR_FLEET_MAX_MODELS] = {};
+  int n_heavy = 0;
+  for (int i = 0; i < n_models; ++i) n_heavy += selected_family(models[i]) != FAM_REGISTER || models[i]->gen;
+  const int light_slot = 0;  // stream slot 0 of the pool serves the light models (model 0's own slot is free: see below)
+  bool first_heavy_placed = false;
   for (int pass = 0; pass < 2 && rc_all == DEXR_OK; ++pass) {
     for (int i = 0; i < n_models; ++i) {
       const dexr_model* m = models[i];
-      const bool heavy = selected_family(m) != FAM_REGISTER;
+      const bool heavy = selected_family(m) != FAM_REGISTER || m->gen;
       if (heavy != (pass == 0)) continue;
       hipStream_t si = st;
-      if (fp && heavy) {
-        if (!fp->aux[i]) {
-          int lo = 0, hi = 0;
-          HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-          HIP_TRY(hipStreamCreateWithPriority(&fp->aux[i], hipStreamNonBlocking, hi));
-        }
-        if (!fp->join[i]) HIP_TRY(hipEventCreateWithFlags(&fp->join[i], hipEventDisableTiming));
-        si = fp->aux[i];
-        HIP_TRY(hipStreamWaitEvent(si, fp->fork, 0));
-        forked[i] = true;
+      int slot = -1;
+      if (fp && n_heavy > 0) {
+        if (heavy && first_heavy_placed) slot = 1 + (i % (DEXR_FLEET_MAX_MODELS - 1));
+        else if (!heavy) slot = light_slot;
+      }
+      if (heavy) first_heavy_placed = true;
+      if (slot >= 0) {
+        if (!fp->aux[slot]) HIP_TRY(hipStreamCreateWithFlags(&fp->aux[slot], hipStreamNonBlocking));
+        if (!fp->join[slot]) HIP_TRY(hipEventCreateWithFlags(&fp->join[slot], hipEventDisableTiming));
+        si = fp->aux[slot];
+        if (!forked[slot]) HIP_TRY(hipStreamWaitEvent(si, fp->fork, 0));
+        forked[slot] = true;
       }
       dexr::KernelParams kp;
       fill_params(m, kp, B);  // B: upper bound of the bucket size (launch geometry); the kernel reads the real count
@@ -1334,10 +1344,10 @@ int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, i
     }
   }
   std::string err = g_err;
-  for (int i = 0; i < n_models; ++i) {
-    if (!forked[i]) continue;
-    HIP_TRY(hipEventRecord(fp->join[i], fp->aux[i]));
-    HIP_TRY(hipStreamWaitEvent(st, fp->join[i], 0));
+  for (int sl = 0; sl < DEXR_FLEET_MAX_MODELS; ++sl) {
+    if (!forked[sl]) continue;
+    HIP_TRY(hipEventRecord(fp->join[sl], fp->aux[sl]));
+    HIP_TRY(hipStreamWaitEvent(st, fp->join[sl], 0));
   }
   if (rc_all != DEXR_OK) g_err = err;
   return rc_all;

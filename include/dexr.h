@@ -93,11 +93,11 @@ typedef struct dexr_tuning {
                            above 1.3 x the batch mean are solved first (a launch is otherwise bound by slow frames the
                            queue hands out late).  1 on, 0 off, -1 measured policy (currently off: the screening costs
                            more than the ordering gains with this predictor, see dexr_api.hip launch_wide)            */
-  int32_t fork_streams; /* dexr_retarget_multi_dev (read from models[0]): the launches of the models whose components have
-                           9+ joints go first, each on an internal high-priority stream ordered after `stream` by an event
-                           and joined before the call returns; the small-component models follow on `stream` and fill the
-                           CUs the big launches' tails leave idle.  1 on, 0 off (everything on `stream`), -1 policy (on:
-                           131 072 frames of 4 robots 1.38 -> 1.28 ms, the Shadow bucket alone takes 1.27)              */
+  int32_t fork_streams; /* dexr_retarget_multi_dev (read from models[0]): the first model whose components have 9+ joints
+                           stays on `stream`; the small-component models are enqueued on an internal stream ordered after
+                           `stream` by an event and joined before the call returns, so that they fill the CUs the big
+                           launch's tail leaves idle (further big models get internal streams of their own).  1 on, 0 off
+                           (everything on `stream`), -1 policy (on)                                                     */
 } dexr_tuning;
 
 const char* dexr_last_error(void);
