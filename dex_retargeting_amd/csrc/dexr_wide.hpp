@@ -137,12 +137,7 @@ struct WideLds {
   static constexpr int FS = JR + 4 * 4 * NRP * 4;      // 32 bytes: row of the frame's inputs / of its item, item, frame of
                                                        // the sequence, DexPilot bits (registers are the scarce resource)
   static constexpr int XL = FS + 32;                   // NMAX floats: regularisation target (the frame's start row)
-  // Where the LDS budget has room (the 24-row joint grid), the terms' target vectors and weights are formed ONCE per frame
-  // (when it is loaded) and kept here: otherwise every pass re-reads the frame's keypoints / ref_value rows from global
-  // memory (65 536 frames x 252 B = 16.5 MB do not stay in a 4 MB L2: those re-reads were 1/3 of the launch's HBM traffic).
-  static constexpr bool HAS_TG = !MIMIC && NMAX == 24;
-  static constexpr int TG = XL + NMAX * 4;             // 16 terms x (target vector, weight)
-  static constexpr int SLOT = TG + (HAS_TG ? 256 : 0);
+  static constexpr int SLOT = XL + NMAX * 4;
   // LDS decides the occupancy: two blocks of four waves per CU (160 KB); the 16-row joint grid is built for three
   static_assert(2 * 4 * (SLOT0 + 4 * SLOT) <= 160 * 1024, "two blocks per CU must fit");
   static_assert(MIMIC || NMAX != 16 || 3 * (4 * (SLOT0 + 4 * SLOT) + 512) <= 160 * 1024, "three blocks per CU must fit");
@@ -206,7 +201,6 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   int64_t* FS64 = reinterpret_cast<int64_t*>(sbase + L::FS);     // [0] irow, [1] lrow, [2] item
   int32_t* FS32 = reinterpret_cast<int32_t*>(sbase + L::FS) + 6;  // [0] frame of the sequence, [1] DexPilot bits
   float* XLl = reinterpret_cast<float*>(sbase + L::XL);
-  float* TGl = reinterpret_cast<float*>(sbase + L::TG);
 
   const dexr_comp_table& tb = comps[comp];
   const WideTable& wt = wtabs[comp];
@@ -442,26 +436,12 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     }
   };
 
-  // (called right after load_frame by the rows that took a frame)
-  auto cache_targets = [&]() {
-    if (L::HAS_TG) {
-      if (l < nt) {
-        float tv[3], wgt;
-        term_target(tb.term_ref[l], tv, wgt);
-        *reinterpret_cast<float4*>(TGl + l * 4) = make_float4(tv[0], tv[1], tv[2], wgt);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-  };
-
   // idle rows run the passes on stale data: their bookkeeping block must address valid rows (row 0) from the start
   FS64[0] = 0;
   FS64[1] = 0;
   FS64[2] = 0;
   FS32[0] = 0;
   FS32[1] = 0;
-  if (L::HAS_TG) *reinterpret_cast<float4*>(TGl + l * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
   if (l < NMAX) XLl[l] = 0.f;
   if (NJ2 > 1 && l + 16 < NMAX) XLl[l + 16] = 0.f;
   // frames on the fixed base never move
@@ -645,12 +625,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       const int ft = tb.term_task[l], fo = tb.term_origin[l];
       double rd[3];
       float tv[3], wgt;
-      if (L::HAS_TG) {
-        const float4 tg = *reinterpret_cast<const float4*>(TGl + l * 4);
-        tv[0] = tg.x; tv[1] = tg.y; tv[2] = tg.z; wgt = tg.w;
-      } else {
-        term_target(tb.term_ref[l], tv, wgt);
-      }
+      term_target(tb.term_ref[l], tv, wgt);
       float ptf[3], pof[3] = {0, 0, 0};
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
@@ -1143,7 +1118,6 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         pool_next += (unsigned)__popcll(__ballot(got)) >> 4;
         if (got) {
           load_frame((int64_t)cand, 0);
-          cache_targets();
           active = true;
           reset_state();
         }
@@ -1320,7 +1294,6 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       if (seq && t_seq + 1 < kp.T) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the next frame's start point is the row just written
         load_frame(FS64[2], t_seq + 1);
-        cache_targets();
         reset_state();
       } else {
         if (l == 0 && dexpilot && kp.state && comp == 0) kp.state[f_lrow()] = f_nst();
