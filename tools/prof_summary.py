@@ -51,6 +51,17 @@ for p in dbs("kt"):
         print("\n# per dispatch (view kernels): duration_us grid wg lds scratch vgpr agpr sgpr")
         for r in rows[:30]:
             print(f"{r[0][:60]:60s} {r[1] * 1e-3:10.3f} " + " ".join(str(v) for v in r[2:]))
+        # steady state: the first four dispatches of a solve kernel are the untimed staging launches (cold start from the
+        # joint-limit midpoint, 3-4 x the iterations of a tracking step) -- they are not part of any timed region
+        by = collections.defaultdict(list)
+        for r in rows:
+            by[r[0][:60]].append(r[1] * 1e-3)
+        print("\n# steady state (dispatches after the four staging launches): name, n, mean_us, min_us, max_us")
+        summary["rocprof_kernel_steady_avg_us"] = {}
+        for k, v in by.items():
+            tail = v[4:] if len(v) > 8 else v
+            print(f"{k:60s} {len(tail):4d} {sum(tail) / len(tail):10.3f} {min(tail):10.3f} {max(tail):10.3f}")
+            summary["rocprof_kernel_steady_avg_us"][k] = sum(tail) / len(tail)
     except Exception as e:
         print("# (per-dispatch view unavailable:", e, ")")
 
