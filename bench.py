@@ -8,7 +8,8 @@
 A "step" is one pass of the hot path over one batch: B = 65 536 independent frames per GPU (weak scaling) of the
 workload BASELINE.json quotes the metric on -- Allegro right hand, VectorOptimizer -- solved to the tight
 tolerance, inputs resident in HBM when the timed region starts, result qpos resident (and, for N > 1, all-gathered
-with one RCCL all-gather per step) when it ends.  Consecutive steps solve DIFFERENT batches (four pre-staged
+with one RCCL all-gather per step -- `dexr_allgather` of libdexr's C-ABI -- ) when it ends.  `--gpus N` without a
+launcher around it starts the N ranks itself (re-executes under torch.distributed.run).  Consecutive steps solve DIFFERENT batches (four pre-staged
 batches are rotated), so no step re-solves the previous step's inputs.
 
 Headline workload (synthetic, seeded): keypoints = frame (b mod 621) of the human fixture
@@ -18,6 +19,11 @@ last_qpos = the solver's own answer for the neighbouring frame (b-1), i.e. the w
 
 * "f64":        the same config timed with float64 arithmetic throughout (the reference's arithmetic type);
 * "cold_start": the reference's own test regime (tests/test_optimizer.py:27-81: reachable targets, start sigma = 0.5);
+* "online_teleop": the reference's own benchmark shape (profile_online_retargeting.py:18-36): 621 fixture frames, ONE
+                SeqRetargeting.retarget(ref) per frame, per robot: fps, mean / p99 ms per frame, the bare C-ABI call,
+                and the compiled CPU port on the same loop (BASELINE configs[0]);
+* "multi_gpu":  (launched by torch.distributed.run) the same steps with the gather on the solve stream and replayed
+                from one captured HIP graph, RCCL version, an xGMI estimate;
 * "also":       the other two single-GPU BASELINE configs (Shadow DexPilot, LEAP position), each with its own
                 roofline / HBM traffic / parity block;
 * "parity":     max |dq| against the float64 oracle on a subset, and the distance to the reference-as-configured
