@@ -30,7 +30,8 @@ class Tuning(C.Structure):
                 ("max_blind", C.c_int32), ("stall_from", C.c_int32), ("stall_ratio", C.c_float),
                 ("stall_cap", C.c_float), ("lam_jump", C.c_float), ("lam_fastdec", C.c_float),
                 ("floor_scale", C.c_float), ("step_cap", C.c_float), ("blind_tol_scale", C.c_float),
-                ("pivot_rule", C.c_int32), ("longest_first", C.c_int32), ("fork_streams", C.c_int32)]
+                ("pivot_rule", C.c_int32), ("longest_first", C.c_int32), ("lam_recover", C.c_float),
+                ("fork_streams", C.c_int32)]
 
 
 KERNEL_AUTO, KERNEL_REGISTER, KERNEL_QUAD, KERNEL_LDS, KERNEL_REDUCED, KERNEL_WIDE, KERNEL_GENERAL = -1, 0, 1, 2, 3, 4, 5

@@ -133,6 +133,7 @@ void fill_params(const dexr_model* m, dexr::KernelParams& kp, int64_t B) {
   // model predicted well.  Allegro vector, 65 536 frames: 0.143 -> 0.119 ms; Shadow DexPilot: 19.4 -> 15.4 ms.
   kp.lam_jump = family_lam_jump(m, FAM_REGISTER);  // launch() sets the dispatched family's value
   kp.lam_fastdec = m->tune.lam_fastdec;
+  kp.lam_recover = m->tune.lam_recover;
   kp.floor_scale = m->tune.floor_scale;
   kp.step_cap = m->tune.step_cap;
   kp.blind_tol = 0.f;  // set from the tolerance in apply_options
@@ -532,6 +533,7 @@ void default_tuning(dexr_model* m) {
   t.stall_cap = 20.f;
   t.lam_jump = m->bucket <= 8 ? 3.0f : 0.3f;
   t.lam_fastdec = m->bucket <= 8 ? 0.1f : 0.f;
+  t.lam_recover = 0.f;
   t.floor_scale = 1e-12f;
   t.step_cap = 0.3f;
   // small components: a verified, undamped Newton step below 100 tol (2e-4 rad) leaves an error of ~C s^2 < 1e-6 rad
@@ -957,7 +959,7 @@ int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning) {
   if (t.fork_streams < -1 || t.fork_streams > 1) return fail(DEXR_ERR_INVALID, "fork_streams must be -1, 0 or 1");
   if (t.persist_from < 0 || t.qchunk < 0 || t.persist_occ < 0 || t.resident_waves < 0 || t.max_blind < 0)
     return fail(DEXR_ERR_INVALID, "negative launch parameter");
-  if (!(t.step_cap >= 0) || !(t.lam_jump >= 0) || !(t.lam_fastdec >= 0) || !(t.floor_scale >= 0) || !(t.blind_tol_scale >= 0))
+  if (!(t.step_cap >= 0) || !(t.lam_jump >= 0) || !(t.lam_fastdec >= 0) || !(t.floor_scale >= 0) || !(t.blind_tol_scale >= 0) || !(t.lam_recover >= 0))
     return fail(DEXR_ERR_INVALID, "negative or non-finite damping parameter");
   // lam_jump: a value that differs from what get_tuning reports is a caller override and then holds for every family;
   // otherwise each launch keeps using the default of the family it dispatches (which select_kernels may change now)

@@ -58,6 +58,8 @@ struct KernelParams {
   float step_cap;                 // trust radius: a step whose largest component exceeds it is scaled down to it (0: off)
   float lam_jump;                 // on a rejected step lambda becomes at least lam_jump x mean diag(H) (0: plain x nu)
   float lam_fastdec;              // on an accepted step with rho > 0.9 lambda shrinks by this factor (0: Nielsen's 1/3)
+  float lam_recover;              // ... and by this factor while lambda is still above 10 lam0, i.e. while the damping
+                                  // that a rejection raised is being taken back (0: lam_fastdec there too)
   float floor_scale;              // mixed-precision kernels: value differences below floor_scale x |F| are unverifiable
   int32_t stall_from;             // termination at the float rounding floor (see "stalled" in the kernels): from this
   float stall_ratio;              // many unverifiable ("blind") steps on, a step that is not < stall_ratio x the
@@ -800,7 +802,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
     const unsigned QCHUNK = kp.qchunk;
     real Hs[LS::NH], gs[NMAX], xo[NMAX];
     real F = 0, lam = (real)kp.lam0, nu = 2, sprev = (real)1e30;
-    int my_iters = 0, blind = 0;
+    int my_iters = 0, blind = 0, nrej = 0;  // nrej: rejected steps of this solve (fast damping recovery only after the first)
     bool has = false, fresh = false;
     int64_t my_item = 0;
     int my_t = 0;  // sequence mode: frame of the lane's sequence being solved
@@ -855,6 +857,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
             sprev = (real)1e30;
             my_iters = 0;
             blind = 0;
+            nrej = 0;
           }
         }
       }
@@ -971,7 +974,8 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
             const real rho = (F - Ft) / fmax(pred, (real)1e-30);
             const real t = (real)2 * rho - (real)1;
             real shrink = below_floor ? (real)(1.0 / 3.0) : fmax((real)(1.0 / 3.0), (real)1 - t * t * t);
-            if (kp.lam_fastdec > 0 && rho > (real)0.9) shrink = (real)kp.lam_fastdec;
+            if (kp.lam_fastdec > 0 && rho > (real)0.9)
+              shrink = (kp.lam_recover > 0 && nrej <= 2 && lam > (real)10 * (real)kp.lam0) ? (real)kp.lam_recover : (real)kp.lam_fastdec;
             lam = fmax(lam * shrink, (real)1e-9);
             nu = 2;
             F = Ft;
@@ -987,7 +991,8 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
               lam = fmax((real)0.1 * lam, (real)0.5 * lam_ok);
             }
           } else {
-            lam = fmax(lam, (real)1e-6) * nu;
+            ++nrej;
+        lam = fmax(lam, (real)1e-6) * nu;
             if (kp.lam_jump > 0) {  // go straight to a damping that matters next to the curvature
               real ds = 0;
               int dn = 0;
@@ -1054,6 +1059,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
           sprev = (real)1e30;
           my_iters = 0;
           blind = 0;
+          nrej = 0;
         } else {
           if (kp.kind == DEXR_KIND_DEXPILOT && kp.state && comp == 0) kp.state[r0] = my_nst;
           has = false;
@@ -1083,7 +1089,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
   real lam = (real)kp.lam0, nu = 2;
   bool done = false;
   int status = ST_MAXITER;
-  int my_iters = 0, blind = 0;
+  int my_iters = 0, blind = 0, nrej = 0;
   real sprev = (real)1e30;
   real xo[NMAX];
   real F;
@@ -1175,7 +1181,8 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
         const real rho = (F - Ft) / fmax(pred, (real)1e-30);
         const real t = (real)2 * rho - (real)1;
         real shrink = below_floor ? (real)(1.0 / 3.0) : fmax((real)(1.0 / 3.0), (real)1 - t * t * t);
-        if (kp.lam_fastdec > 0 && rho > (real)0.9) shrink = (real)kp.lam_fastdec;
+        if (kp.lam_fastdec > 0 && rho > (real)0.9)
+          shrink = (kp.lam_recover > 0 && nrej <= 2 && lam > (real)10 * (real)kp.lam0) ? (real)kp.lam_recover : (real)kp.lam_fastdec;
         lam = fmax(lam * shrink, (real)1e-9);
         nu = 2;
         F = Ft;
@@ -1193,6 +1200,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
           lam = fmax((real)0.1 * lam, (real)0.5 * lam_ok);
         }
       } else {
+        ++nrej;
         lam = fmax(lam, (real)1e-6) * nu;
         if (kp.lam_jump > 0) lam = fmax(lam, (real)kp.lam_jump * hdmean);
         nu *= 2;

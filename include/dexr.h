@@ -93,6 +93,12 @@ typedef struct dexr_tuning {
                            above 1.3 x the batch mean are solved first (a launch is otherwise bound by slow frames the
                            queue hands out late).  1 on, 0 off, -1 measured policy (currently off: the screening costs
                            more than the ordering gains with this predictor, see dexr_api.hip launch_wide)            */
+  float lam_recover;    /* small components: accepted step with rho > 0.9 while lambda > 10 lambda0 and at most two steps of
+                           the solve were rejected (the damping a rejection raised is being taken back): lambda *=
+                           lam_recover.  0 (default): lam_fastdec there too.  Measured at 0.003 (65 536 tracking frames):
+                           Allegro vector 61.5 -> 56 us, Inspire 67 -> 64, Ability 87 -> 84, but LEAP vector 54 -> 62: the
+                           frames with >= 8 passes drop everywhere (LEAP: 108 -> 30), the single slowest frame -- which
+                           sets a launch's duration -- moves either way (LEAP: 11 -> 14 passes), hence opt-in          */
   int32_t fork_streams; /* dexr_retarget_multi_dev (read from models[0]): the first model whose components have 9+ joints
                            stays on `stream`; the small-component models are enqueued on an internal stream ordered after
                            `stream` by an event and joined before the call returns, so that they fill the CUs the big
