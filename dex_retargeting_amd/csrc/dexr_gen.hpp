@@ -36,9 +36,12 @@ struct GenTab {  // device pointers into the uploaded generic table
 };
 
 // doubles of LDS one wave needs
-__host__ __device__ inline size_t gen_lds_doubles(int nj, int nf, int nt, int nv) {
-  return (size_t)nj * 12 + nj * 3 + nj + (size_t)nf * 3 + (size_t)nt * 3 + nt + (size_t)nt * 3 + nt + (size_t)nt * 3 +
-         (size_t)nt * 3 + (size_t)nv * 8 + 2 * (size_t)nv * nv + (size_t)nj * 3 + (size_t)nv * 3 + nj + 8;
+__host__ __device__ inline size_t gen_lds_doubles(int nj, int nf, int nt, int nv, int nfam) {
+  const size_t state = (size_t)nj * 12 + nj * 3 + nj + (size_t)nf * 3 + (size_t)nt * 3 + nt + (size_t)nt * 3 + nt + (size_t)nt * 3 +
+                       (size_t)nt * 3 + (size_t)nv * 8 + 2 * (size_t)nv * nv + (size_t)nj * 3 + (size_t)nv * 3 + nj + 8;
+  // wave-local copies of the tables the inner loops index (see "tables" in the kernel)
+  const size_t ints = 3 * (size_t)nj + (size_t)nv + 1 + (size_t)nfam + (size_t)nf + 2 * (size_t)nt;
+  return state + (size_t)nj /* jmul */ + (size_t)nf + (size_t)nj /* masks */ + (ints + 1) / 2;
 }
 
 __device__ __forceinline__ double gen_wave_sum(double v) {
@@ -81,6 +84,38 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
   double* vcol = jcol + nj * 3;         // nv x 3
   double* tmp = vcol + nv * 3;          // nj
   double* flag = tmp + nj;              // 8 scalars
+  // tables the inner loops index with data-dependent subscripts (families of a variable, parents along a chain,
+  // ancestor masks): read from global memory they cost two dependent ~1 us round trips per access -- the first version of
+  // this kernel spent ~90 % of a pass waiting for them -- so every wave keeps its own copy in LDS
+  double* l_jmul = flag + 8;                                                      // nj
+  unsigned long long* l_fanc = reinterpret_cast<unsigned long long*>(l_jmul + nj);  // nf
+  unsigned long long* l_janc = l_fanc + nf;                                       // nj
+  int32_t* l_jtype = reinterpret_cast<int32_t*>(l_janc + nj);                     // nj
+  int32_t* l_parent = l_jtype + nj;                                               // nj
+  int32_t* l_var = l_parent + nj;                                                 // nj
+  int32_t* l_famoff = l_var + nj;                                                 // nv + 1
+  int32_t* l_fam = l_famoff + nv + 1;                                             // nfam
+  int32_t* l_fjoint = l_fam + tb.nfam;                                            // nf
+  int32_t* l_ttask = l_fjoint + nf;                                               // nt
+  int32_t* l_torigin = l_ttask + nt;                                              // nt
+  for (int i = lane; i < nj; i += 64) {
+    l_jmul[i] = tb.jmul[i];
+    l_janc[i] = tb.joint_anc[i];
+    l_jtype[i] = tb.jtype[i];
+    l_parent[i] = tb.parent[i];
+    l_var[i] = tb.var[i];
+  }
+  for (int i = lane; i < nf; i += 64) {
+    l_fanc[i] = tb.frame_anc[i];
+    l_fjoint[i] = tb.frame_joint[i];
+  }
+  for (int i = lane; i <= nv; i += 64) l_famoff[i] = tb.fam_off[i];
+  for (int i = lane; i < tb.nfam; i += 64) l_fam[i] = tb.fam[i];
+  for (int i = lane; i < nt; i += 64) {
+    l_ttask[i] = tb.term_task[i];
+    l_torigin[i] = tb.term_origin[i];
+  }
+  __syncthreads();
 
   const int64_t cnt = kp.bucket ? (int64_t)kp.bucket[1] : kp.B;
   const int64_t boff = kp.bucket ? (int64_t)kp.bucket[0] : 0;
@@ -182,17 +217,17 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
       // ---- one evaluation at xs: kinematics, terms, value; with `model` also gradient + Hessian of F -------------------
       auto eval_at = [&](const double* xs, bool model) -> double {
         if (lane < nj) {
-          const int v = tb.var[lane];
+          const int v = l_var[lane];
           double q;
           if (MODE == MODE_FK) q = kp.xin[it * kp.n_q + tb.src_idx[lane]];
-          else if (v >= 0) q = tb.jmul[lane] * xs[v] + tb.joff[lane];
-          else q = tb.jmul[lane] * (double)kp.fixed[it * kp.n_fixed + tb.src_idx[lane]] + tb.joff[lane];
+          else if (v >= 0) q = l_jmul[lane] * xs[v] + tb.joff[lane];
+          else q = l_jmul[lane] * (double)kp.fixed[it * kp.n_fixed + tb.src_idx[lane]] + tb.joff[lane];
           qj[lane] = q;
         }
         __syncthreads();
         for (int d = 0; d <= tb.max_depth; ++d) {
           if (lane < nj && tb.depth[lane] == d) {
-            const int k = lane, pa = tb.parent[k];
+            const int k = lane, pa = l_parent[k];
             double Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pp[3] = {0, 0, 0};
             if (pa >= 0) {
               for (int i = 0; i < 9; ++i) Rp[i] = Tw[pa * 12 + i];
@@ -209,7 +244,7 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
                          a2 = Ra[6] * ax + Ra[7] * ay + Ra[8] * az;
             aw[k * 3] = a0; aw[k * 3 + 1] = a1; aw[k * 3 + 2] = a2;
             const double q = qj[k];
-            if (tb.jtype[k] == DEXR_JOINT_REVOLUTE) {  // Rodrigues about the local axis: I + sin K + (1 - cos) K^2
+            if (l_jtype[k] == DEXR_JOINT_REVOLUTE) {  // Rodrigues about the local axis: I + sin K + (1 - cos) K^2
               double sn, cs;
               sincos(q, &sn, &cs);
               const double c1 = 1.0 - cs;
@@ -230,7 +265,7 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
           __syncthreads();
         }
         if (lane < nf) {
-          const int j = tb.frame_joint[lane];
+          const int j = l_fjoint[lane];
           const double* o = tb.frame_off + (size_t)lane * 3;
           if (j < 0) {
             for (int i = 0; i < 3; ++i) P[lane * 3 + i] = o[i];
@@ -243,7 +278,7 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
         if (MODE == MODE_FK) return 0.0;
         double fpart = 0.0;
         if (lane < nt) {
-          const int ft = tb.term_task[lane], fo = tb.term_origin[lane];
+          const int ft = l_ttask[lane], fo = l_torigin[lane];
           double r[3];
           for (int i = 0; i < 3; ++i) r[i] = P[ft * 3 + i] - (fo >= 0 ? P[fo * 3 + i] : 0.0) - tgt[lane * 3 + i];
           if (kp.kind == DEXR_KIND_POSITION) {  // SmoothL1 per coordinate, mean over 3 P entries (optimizer.py:163-166)
@@ -278,12 +313,12 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
         }
         __syncthreads();
         for (int t = 0; t < nt; ++t) {
-          const int ft = tb.term_task[t], fo = tb.term_origin[t];
-          const unsigned long long at = tb.frame_anc[ft], ao = fo >= 0 ? tb.frame_anc[fo] : 0ull;
+          const int ft = l_ttask[t], fo = l_torigin[t];
+          const unsigned long long at = l_fanc[ft], ao = fo >= 0 ? l_fanc[fo] : 0ull;
           if (lane < nj) {
             const int k = lane;
             double c[3] = {0, 0, 0};
-            const bool rev = tb.jtype[k] == DEXR_JOINT_REVOLUTE;
+            const bool rev = l_jtype[k] == DEXR_JOINT_REVOLUTE;
             for (int side = 0; side < 2; ++side) {
               const bool on = ((side ? ao : at) >> k) & 1ull;
               if (!on) continue;
@@ -303,9 +338,9 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
           __syncthreads();
           if (lane < nv) {
             double c[3] = {0, 0, 0};
-            for (int e = tb.fam_off[lane]; e < tb.fam_off[lane + 1]; ++e) {
-              const int k = tb.fam[e];
-              const double m = tb.jmul[k];
+            for (int e = l_famoff[lane]; e < l_famoff[lane + 1]; ++e) {
+              const int k = l_fam[e];
+              const double m = l_jmul[k];
               for (int i = 0; i < 3; ++i) c[i] += m * jcol[k * 3 + i];
             }
             for (int i = 0; i < 3; ++i) vcol[lane * 3 + i] = c[i];
@@ -335,11 +370,11 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
               const int fr = side ? fo : ft;
               if (fr < 0) continue;
               const double sg = side ? -1.0 : 1.0;
-              for (int k = tb.frame_joint[fr]; k >= 0; k = tb.parent[k]) {  // wave-uniform walk up the chain
-                const int vk = tb.var[k];
+              for (int k = l_fjoint[fr]; k >= 0; k = l_parent[k]) {  // wave-uniform walk up the chain
+                const int vk = l_var[k];
                 if (vk < 0) continue;
                 double ck[3];
-                if (tb.jtype[k] == DEXR_JOINT_REVOLUTE) {
+                if (l_jtype[k] == DEXR_JOINT_REVOLUTE) {
                   const double dx = P[fr * 3] - Tw[k * 12 + 9], dy = P[fr * 3 + 1] - Tw[k * 12 + 10], dz = P[fr * 3 + 2] - Tw[k * 12 + 11];
                   ck[0] = aw[k * 3 + 1] * dz - aw[k * 3 + 2] * dy;
                   ck[1] = aw[k * 3 + 2] * dx - aw[k * 3] * dz;
@@ -347,22 +382,22 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
                 } else {
                   for (int i = 0; i < 3; ++i) ck[i] = aw[k * 3 + i];
                 }
-                const unsigned long long ak = tb.joint_anc[k];
+                const unsigned long long ak = l_janc[k];
                 if (lane < nj) {
                   const int j = lane;
                   double val = 0.0;
-                  if (((ak >> j) & 1ull) && tb.jtype[j] == DEXR_JOINT_REVOLUTE && tb.var[j] >= 0) {
+                  if (((ak >> j) & 1ull) && l_jtype[j] == DEXR_JOINT_REVOLUTE && l_var[j] >= 0) {
                     const double cx = aw[j * 3 + 1] * ck[2] - aw[j * 3 + 2] * ck[1], cy = aw[j * 3 + 2] * ck[0] - aw[j * 3] * ck[2],
                                  cz = aw[j * 3] * ck[1] - aw[j * 3 + 1] * ck[0];
-                    val = sg * tb.jmul[j] * tb.jmul[k] * (tg[t * 3] * cx + tg[t * 3 + 1] * cy + tg[t * 3 + 2] * cz);
-                    if (j != k && tb.var[j] == vk) val *= 2.0;  // both orders of an unordered pair inside one family
+                    val = sg * l_jmul[j] * l_jmul[k] * (tg[t * 3] * cx + tg[t * 3 + 1] * cy + tg[t * 3 + 2] * cz);
+                    if (j != k && l_var[j] == vk) val *= 2.0;  // both orders of an unordered pair inside one family
                   }
                   tmp[j] = val;
                 }
                 __syncthreads();
                 if (lane < nv) {
                   double sum = 0.0;
-                  for (int e = tb.fam_off[lane]; e < tb.fam_off[lane + 1]; ++e) sum += tmp[tb.fam[e]];
+                  for (int e = l_famoff[lane]; e < l_famoff[lane + 1]; ++e) sum += tmp[l_fam[e]];
                   if (sum != 0.0) {
                     const int hi_ = lane > vk ? lane : vk, lo_ = lane > vk ? vk : lane;
                     H[(size_t)hi_ * nv + lo_] += sum;
