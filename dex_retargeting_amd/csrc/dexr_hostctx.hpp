@@ -43,9 +43,11 @@ struct HostCtx {
   size_t pin_bytes = 0;
   unsigned char* dev = nullptr;
   size_t dev_bytes = 0;
-  // above this size the pinned mirror is not grown further: the block is copied piecewise from / to the caller's
-  // (pageable) arrays instead; 64 MiB covers 65 536 frames of every shipped model with diagnostics
-  static constexpr size_t PIN_MAX = (size_t)64 << 20;
+  // above this size the block is copied piecewise from / to the caller's (pageable) arrays instead of through the pinned
+  // mirror: packing costs a host memcpy per array, which pays for small calls (one copy each way instead of six) and
+  // loses for large ones -- measured, Allegro vector through dexr_retarget_kp: 65 536 frames 1.20 ms packed vs 0.6 ms
+  // piecewise (tools/host_path_rate.py)
+  static constexpr size_t PIN_MAX = (size_t)1 << 20;
 
   ~HostCtx() { release(); }
   void release() {
