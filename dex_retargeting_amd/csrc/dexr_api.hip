@@ -785,7 +785,7 @@ extern "C" {
 
 const char* dexr_last_error(void) { return g_err.c_str(); }
 
-const char* dexr_version(void) { return "dexr 0.2 (gfx950; table v5)"; }
+const char* dexr_version(void) { return "dexr 0.3 (gfx950; table v5 + generic tables)"; }
 
 int dexr_device_count(void) {
   int n = 0;

@@ -364,3 +364,80 @@ def test_reduced_variable_assembly_matches_oracle_model(rel):
         assert abs(FF - F[b]) < 1e-6 * max(1.0, abs(F[b]))
         assert np.abs(gg - g[b]).max() < 2e-6 * max(1.0, np.abs(g[b]).max()), rel   # float32 table entries
         assert np.abs(HH - H[b]).max() < 2e-5 * max(1.0, np.abs(H[b]).max()), rel
+
+
+# ---- literal mirrors of the reference's tests/test_retargeting_config.py:54-125 ------------------------------------------
+def test_dict_config_parsing_like_the_reference():
+    import yaml
+
+    from dex_retargeting_amd.seq_retarget import SeqRetargeting
+
+    cfg_str = """
+    type: position
+    urdf_path: ability_hand/ability_hand_right.urdf
+    wrist_link_name: "base_link"
+
+    target_joint_names: ['index_q1', 'middle_q1', 'pinky_q1', 'ring_q1', 'thumb_q1', 'thumb_q2']
+    target_link_names: [ "thumb_tip",  "index_tip", "middle_tip", "ring_tip", "pinky_tip" ]
+
+    target_link_human_indices: [ 4, 8, 12, 16, 20 ]
+
+    low_pass_alpha: 1
+    """
+    retargeting = RetargetingConfig.from_dict(yaml.safe_load(cfg_str)).build()
+    assert isinstance(retargeting, SeqRetargeting)
+    assert retargeting.optimizer.retargeting_type == "POSITION" and retargeting.optimizer.opt_dof == 6
+
+
+def test_multi_dict_config_parsing_like_the_reference():
+    import yaml
+
+    from dex_retargeting_amd.seq_retarget import SeqRetargeting
+
+    cfg_str = """
+    - type: vector
+      urdf_path: allegro_hand/allegro_hand_right.urdf
+      wrist_link_name: "wrist"
+
+      target_joint_names: null
+      target_origin_link_names: [ "wrist", "wrist", "wrist", "wrist" ]
+      target_task_link_names: [ "link_15.0_tip", "link_3.0_tip", "link_7.0_tip", "link_11.0_tip" ]
+      scaling_factor: 1.6
+
+      # The joint indices of human hand joint which corresponds to each link in the target_link_names
+      target_link_human_indices: [ [ 0, 0, 0, 0 ], [ 4, 8, 12, 16 ] ]
+
+      low_pass_alpha: 0.2
+
+    - type: DexPilot
+      urdf_path: leap_hand/leap_hand_right.urdf
+      wrist_link_name: "base"
+
+      target_joint_names: null
+      finger_tip_link_names: [ "thumb_tip_head", "index_tip_head", "middle_tip_head", "ring_tip_head" ]
+      scaling_factor: 1.6
+
+      low_pass_alpha: 0.2
+    """
+    kinds = []
+    for cfg_dict in yaml.safe_load(cfg_str):
+        retargeting = RetargetingConfig.from_dict(cfg_dict).build()
+        assert isinstance(retargeting, SeqRetargeting)
+        kinds.append(retargeting.optimizer.retargeting_type)
+        # the tables compile on the host (no GPU needed for that): 4 vector components / one DexPilot component
+        cm = retargeting.optimizer.compiled_model()
+        assert cm.n_ref == (4 if kinds[-1] == "VECTOR" else 10)
+    assert kinds == ["VECTOR", "DEXPILOT"]
+
+
+@pytest.mark.parametrize("robot_name", ROBOT_NAMES)
+def test_add_dummy_joint_like_the_reference(robot_name):
+    """tests/test_retargeting_config.py:106-125, on the offline (position) configs as there."""
+    path = get_default_config_path(robot_name, RetargetingType.position, HandType.right)
+    r0 = RetargetingConfig.load_from_file(path, {"add_dummy_free_joint": False}).build()
+    dof0, act0 = r0.optimizer.robot.dof, len(r0.optimizer.target_joint_names)
+    r1 = RetargetingConfig.load_from_file(path, {"add_dummy_free_joint": True}).build()
+    robot = r1.optimizer.robot
+    assert robot.dof == dof0 + 6
+    assert r1.joint_limits.shape == (act0 + 6, 2)
+    assert all("dummy" in n for n in robot.dof_joint_names[:6])
