@@ -703,7 +703,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 #pragma unroll
       for (int j = 0; j < NP; ++j) Hn[i][j] = wv2{0.f, 0.f};
     // packed views of the two joint slots (NJ2 == 2, joint-space grids): axes / origins, accumulators, per-lane masks
-    constexpr int S1 = (!MIMIC && NJ2 == 2) ? 1 : 0;
+    constexpr int S1 = (MIMIC || NJ2 == 2) ? 1 : 0;  // (MIMIC: family joints 0 and 1 of the lane's variable)
     wv2 jax2[3], jog2[3], jcf2[3], gnew2 = wv2{0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -712,7 +712,12 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       jcf2[i] = wv2{0.f, 0.f};
     }
     const wv2 jm2 = wv2{jopt[0] ? 1.f : 0.f, jopt[NJ2 - 1] ? 1.f : 0.f};  // optimised joints only
-    const wv2 jr2 = wv2{jrev[0] ? 1.f : 0.f, jrev[NJ2 - 1] ? 1.f : 0.f};  // revolute joints
+    // MIMIC: family joints 0 / 1 of this lane's variable -- present?, their bit positions, dq/dx, revolute?
+    const int fk2x = MIMIC ? (famk[0] >= 0 ? famk[0] : 0) : 0, fk2y = MIMIC ? (famk[FAM > 1 ? 1 : 0] >= 0 ? famk[FAM > 1 ? 1 : 0] : 0) : 0;
+    const wv2 fon2 = MIMIC ? wv2{famk[0] >= 0 ? 1.f : 0.f, (fam_max > 1 && famk[FAM > 1 ? 1 : 0] >= 0) ? 1.f : 0.f} : wv2{0.f, 0.f};
+    const wv2 fm2 = MIMIC ? wv2{famm[0], famm[FAM > 1 ? 1 : 0]} : wv2{0.f, 0.f};
+    const wv2 jr2 = MIMIC ? wv2{(float)((revmask >> fk2x) & 1u), (float)((revmask >> fk2y) & 1u)}
+                          : wv2{jrev[0] ? 1.f : 0.f, jrev[NJ2 - 1] ? 1.f : 0.f};  // revolute joints
 
     // (3) terms in sequence: lane l forms the Jacobian columns of its joints (l, l + 16), accumulates their gradient
     // entries and second-order vectors and publishes the term's four weighted Jacobian rows; then every lane adds the
@@ -732,10 +737,37 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       const float4 t3 = *reinterpret_cast<const float4*>(T + 12);
       const uint32_t mt = TMw[t * TMS], mo = TMw[t * TMS + 1];
       if (MIMIC) {
-        // the variable's column is the vmul-weighted sum over its joint family (kinematics_adaptor.py:102-113)
-        float c0 = 0, c1 = 0, c2 = 0;
+        // the variable's column is the vmul-weighted sum over its joint family (kinematics_adaptor.py:102-113).  The
+        // first two family joints (the variable's own joint and its first follower: all of Ability / Inspire, most of
+        // SVH) are formed together in packed float32 arithmetic, like the two joint slots of the joint-space grids; a
+        // third family joint takes the scalar path.
+        float c0, c1, c2;
+        {
+          const wv2 ft = wv2{(float)((mt >> fk2x) & 1u), (float)((mt >> fk2y) & 1u)} * fon2;
+          const wv2 fo = wv2{(float)((mo >> fk2x) & 1u), (float)((mo >> fk2y) & 1u)} * fon2;
+          const wv2 sg = ft - fo;
+          wv2 v[3], d[3];
+          v[0] = ft * t2.x - fo * t3.x - sg * jog2[0];
+          v[1] = ft * t2.y - fo * t3.y - sg * jog2[1];
+          v[2] = ft * t2.z - fo * t3.z - sg * jog2[2];
+          d[0] = jax2[1] * v[2] - jax2[2] * v[1];
+          d[1] = jax2[2] * v[0] - jax2[0] * v[2];
+          d[2] = jax2[0] * v[1] - jax2[1] * v[0];
+          if (any_prismatic) {
+            const wv2 w = (wv2{1.f, 1.f} - jr2) * sg;
 #pragma unroll
-        for (int e = 0; e < FAM; ++e) {
+            for (int i = 0; i < 3; ++i) d[i] = d[i] * jr2 + jax2[i] * w;
+          }
+          jcf2[0] += d[1] * t1.z - d[2] * t1.y;
+          jcf2[1] += d[2] * t1.x - d[0] * t1.z;
+          jcf2[2] += d[0] * t1.y - d[1] * t1.x;
+          const wv2 m0 = fm2 * d[0], m1 = fm2 * d[1], m2 = fm2 * d[2];
+          c0 = m0.x + m0.y;
+          c1 = m1.x + m1.y;
+          c2 = m2.x + m2.y;
+        }
+#pragma unroll
+        for (int e = 2; e < FAM; ++e) {
           if (e < fam_max) {
             const int k = famk[e] >= 0 ? famk[e] : 0;
             const bool on = famk[e] >= 0;
@@ -874,10 +906,12 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     if (!MIMIC && NJ2 == 2) {
       gnew[0] = gnew2.x;
       gnew[NJ2 - 1] = gnew2.y;
+    }
+    if (MIMIC || NJ2 == 2) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        jcf[0][i] = jcf2[i].x;
-        jcf[S1][i] = jcf2[i].y;
+        jcf[0][i] += jcf2[i].x;
+        jcf[S1][i] += jcf2[i].y;
       }
     }
     WPROF_STAGE(3)
