@@ -9,7 +9,7 @@ import sys
 
 S = open(sys.argv[1]).read().split("\n")
 lo = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-hi = int(sys.argv[3]) if len(sys.argv) > 3 else len(S)
+hi = min(int(sys.argv[3]), len(S)) if len(sys.argv) > 3 else len(S)
 minsz = int(sys.argv[4]) if len(sys.argv) > 4 else 25
 blocks = []
 for i in range(lo, hi):
