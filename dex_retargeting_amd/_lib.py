@@ -40,7 +40,7 @@ EXPORTS = ["dexr_last_error", "dexr_version", "dexr_device_count", "dexr_default
            "dexr_model_destroy", "dexr_model_info", "dexr_model_get_tuning", "dexr_model_set_tuning", "dexr_model_kernel",
            "dexr_model_lane_plan",
            "dexr_retarget_dev", "dexr_retarget_seq_dev", "dexr_seq_compose_dev", "dexr_fleet_workspace_bytes",
-           "dexr_retarget_multi_dev", "dexr_retarget", "dexr_retarget_f64",
+           "dexr_retarget_multi_dev", "dexr_retarget_multi", "dexr_retarget", "dexr_retarget_f64",
            "dexr_retarget_kp_dev", "dexr_retarget_kp", "dexr_eval", "dexr_fk", "dexr_mano_keypoints_dev",
            "dexr_mano_keypoints", "dexr_comm_unique_id", "dexr_comm_create", "dexr_comm_destroy", "dexr_comm_info",
            "dexr_allgather", "dexr_comm_max_f64", "dexr_comm_barrier"]
@@ -87,6 +87,7 @@ def load() -> C.CDLL:
     lib.dexr_fleet_workspace_bytes.restype = C.c_size_t
     lib.dexr_retarget_multi_dev.argtypes = [C.POINTER(vp), C.c_int32, i64, vp, vp, vp, C.c_int32, vp, vp, vp, optp, vp,
                                             C.c_size_t, vp]
+    lib.dexr_retarget_multi.argtypes = [C.POINTER(vp), C.c_int32, i64, i32p, f32p, f32p, C.c_int32, u32p, f32p, i32p, optp]
     lib.dexr_retarget.argtypes = [vp, i64, f32p, f32p, f32p, u32p, f32p, i32p, i32p, f32p, optp]
     lib.dexr_retarget_kp_dev.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, optp, vp]
     lib.dexr_retarget_kp.argtypes = [vp, i64, f32p, f32p, f32p, u32p, f32p, i32p, i32p, f32p, optp]
@@ -283,6 +284,30 @@ def retarget_multi_dev(models, B: int, model_id_ptr: int, kp_ptr: int, last_ptr:
                                          state_ptr or None, q_ptr or None, status_ptr or None,
                                          C.byref(opts) if opts is not None else None, ws_ptr or None, ws_bytes,
                                          stream or None))
+
+
+def retarget_multi(models, model_id: np.ndarray, keypoints: np.ndarray, last: np.ndarray, state: Optional[np.ndarray] = None,
+                   qpos_out: Optional[np.ndarray] = None, opts: Optional[SolveOptions] = None, want_status: bool = False):
+    """Mixed-fleet batch on HOST arrays (dexr_retarget_multi): model_id (B,) int32, keypoints (B,21,3) f32, last (B,ld) f32,
+    state (B,) uint32 in/out or None.  Returns qpos (B,ld) f32 [, status (B,) int32]; `qpos_out` (in-out) supplies the
+    values of the rows / columns the call leaves untouched (default zeros)."""
+    mid = np.ascontiguousarray(model_id, dtype=np.int32)
+    kp = np.ascontiguousarray(keypoints, dtype=np.float32)
+    la = np.ascontiguousarray(last, dtype=np.float32)
+    B, ld = la.shape
+    if kp.shape != (B, 21, 3) or mid.shape != (B,):
+        raise ValueError(f"model_id must be ({B},), keypoints ({B}, 21, 3)")
+    q = np.zeros((B, ld), np.float32) if qpos_out is None else np.ascontiguousarray(qpos_out, dtype=np.float32)
+    if q.shape != (B, ld):
+        raise ValueError(f"qpos_out must have shape ({B}, {ld})")
+    if state is not None and (state.dtype != np.uint32 or state.shape != (B,) or not state.flags["C_CONTIGUOUS"]):
+        raise ValueError(f"state must be a C-contiguous uint32 array of shape ({B},)")
+    status = np.zeros(B, np.int32)
+    arr = (C.c_void_p * len(models))(*[m.handle for m in models])
+    check(load().dexr_retarget_multi(arr, len(models), B, _ptr(mid, C.c_int32), _ptr(kp, C.c_float), _ptr(la, C.c_float), ld,
+                                     _ptr(state, C.c_uint32), _ptr(q, C.c_float), _ptr(status, C.c_int32),
+                                     C.byref(opts) if opts is not None else None))
+    return (q, status) if want_status else q
 
 
 def comm_unique_id() -> bytes:

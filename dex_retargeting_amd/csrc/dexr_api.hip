@@ -1355,6 +1355,37 @@ int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, i
   return rc_all;
 }
 
+int dexr_retarget_multi(const dexr_model* const* models, int32_t n_models, int64_t B, const int32_t* model_id,
+                        const float* keypoints, const float* last, int32_t ld, uint32_t* state, float* qpos_out,
+                        int32_t* status_out, const dexr_solve_options* opt) {
+  if (!models || !model_id || !keypoints || !last || !qpos_out) return fail(DEXR_ERR_INVALID, "null argument");
+  if (n_models < 1 || n_models > DEXR_FLEET_MAX_MODELS) return fail(DEXR_ERR_INVALID, "n_models=%d outside 1..%d", n_models, DEXR_FLEET_MAX_MODELS);
+  if (!models[0]) return fail(DEXR_ERR_INVALID, "models[0] is NULL");
+  if (B < 0 || ld < 1) return fail(DEXR_ERR_INVALID, "negative batch or row length");
+  if (B == 0) return DEXR_OK;
+  const size_t nb = (size_t)B;
+  // staged through models[0]'s host context (pinned / device block, the library stream); rows the call leaves untouched
+  // (unknown model ids, columns beyond a model's n_opt) must come back as the caller passed them: qpos_out is in-out
+  std::lock_guard<std::mutex> lock(models[0]->host.mu);
+  dexr::HostCtx& hc = models[0]->host;
+  dexr::Staging sg;
+  const size_t ws_b = dexr_fleet_workspace_bytes(B);
+  const int i_id = sg.add(dexr::Staging::IN, model_id, nullptr, nb * sizeof(int32_t));
+  const int i_kp = sg.add(dexr::Staging::IN, keypoints, nullptr, nb * 21 * 3 * sizeof(float));
+  const int i_last = sg.add(dexr::Staging::IN, last, nullptr, nb * (size_t)ld * sizeof(float));
+  const int i_state = sg.add(dexr::Staging::INOUT, state, state, nb * sizeof(uint32_t));
+  const int i_q = sg.add(dexr::Staging::INOUT, qpos_out, qpos_out, nb * (size_t)ld * sizeof(float));
+  const int i_status = sg.add(dexr::Staging::INOUT, nullptr, status_out, nb * sizeof(int32_t));
+  const int i_ws = sg.add(dexr::Staging::OUT, nullptr, nullptr, ws_b);
+  HIP_TRY(sg.upload(hc));
+  const int rc = dexr_retarget_multi_dev(models, n_models, B, sg.dev<int32_t>(hc, i_id), sg.dev<float>(hc, i_kp),
+                                         sg.dev<float>(hc, i_last), ld, sg.dev<uint32_t>(hc, i_state), sg.dev<float>(hc, i_q),
+                                         status_out ? sg.dev<int32_t>(hc, i_status) : nullptr, opt, sg.dev<void>(hc, i_ws), ws_b, hc.st);
+  if (rc != DEXR_OK) return rc;
+  HIP_TRY(sg.download(hc));
+  return DEXR_OK;
+}
+
 int dexr_mano_keypoints_dev(int64_t B, const float* keypoints, const float* operator2mano, float* joint_pos_out,
                             float* wrist_rot_out, void* stream) {
   if (!keypoints || !operator2mano || !joint_pos_out) return fail(DEXR_ERR_INVALID, "null argument");

@@ -113,6 +113,7 @@ class Staging {
     total_ += (bytes + 15) & ~(size_t)15;
     if (dir == IN) in_end_ = total_;
     if (dir != OUT) h2d_end_ = total_;
+    if (dir != IN && dst && bytes) d2h_end_ = total_;  // trailing scratch segments (no destination) are not copied back
     return n_++;
   }
   size_t total() const { return total_ ? total_ : 16; }
@@ -144,7 +145,7 @@ class Staging {
   hipError_t download(HostCtx& c) {
     hipError_t e = hipSuccess;
     if (pinned_) {
-      if (total_ > in_end_) e = hipMemcpyAsync(c.pin + in_end_, c.dev + in_end_, total_ - in_end_, hipMemcpyDeviceToHost, c.st);
+      if (d2h_end_ > in_end_) e = hipMemcpyAsync(c.pin + in_end_, c.dev + in_end_, d2h_end_ - in_end_, hipMemcpyDeviceToHost, c.st);
       if (e == hipSuccess) e = hipStreamSynchronize(c.st);
       if (e != hipSuccess) return e;
       for (int i = 0; i < n_; ++i) {
@@ -172,7 +173,7 @@ class Staging {
   };
   Seg seg_[MAXSEG];
   int n_ = 0;
-  size_t total_ = 0, in_end_ = 0, h2d_end_ = 0;
+  size_t total_ = 0, in_end_ = 0, h2d_end_ = 0, d2h_end_ = 0;
   bool pinned_ = false;
 };
 

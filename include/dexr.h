@@ -225,6 +225,13 @@ int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, i
                             int32_t* status_out, const dexr_solve_options* opt, void* workspace, size_t workspace_bytes,
                             void* stream);
 
+/* The same with HOST pointers (SURVEY.md section 8b `dexr_retarget_multi`): packs, copies, runs, synchronises like the other
+ * host entry points (staged through models[0]'s context; the workspace is internal).  qpos_out is in-out: rows of frames
+ * with an unknown model id, and the columns beyond a model's n_opt, come back as they were passed. */
+int dexr_retarget_multi(const dexr_model* const* models, int32_t n_models, int64_t B, const int32_t* model_id,
+                        const float* keypoints, const float* last, int32_t ld, uint32_t* state, float* qpos_out,
+                        int32_t* status_out, const dexr_solve_options* opt);
+
 /* ---- multi-GPU: reassembling the qpos tensor (BASELINE.json north_star; SURVEY.md section 8b `dexr_allgather`, 8e) -------
  * One process per GPU.  Frames are independent, so ranks solve contiguous shards with no exchange; the only collective of
  * the path is ONE all-gather of the (B/N, n_opt) result rows.  It runs on RCCL (bound at run time with dlopen: a copy

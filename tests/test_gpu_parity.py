@@ -1207,3 +1207,34 @@ def test_hip_graph_capture_with_caller_fixed_joints():
     torch.cuda.synchronize()
     assert torch.allclose(out, torch.stack(want[1:]), atol=1e-6, rtol=0)
 
+
+
+def test_host_pointer_fleet_entry_point_equals_the_device_one():
+    """dexr_retarget_multi (host arrays) == dexr_retarget_multi_dev on the same batch, incl. the rows
+    it must leave untouched (unknown model ids, columns beyond a model's n_opt) and the DexPilot bits."""
+    torch = pytest.importorskip("torch")
+    from dex_retargeting_amd.fleet import MixedFleet
+
+    rels = ["teleop/allegro_hand_right.yml", "teleop/shadow_hand_right_dexpilot.yml", "teleop/ability_hand_right.yml"]
+    opts = [build(r)[0].optimizer for r in rels]
+    fleet = MixedFleet(opts)
+    for B in (1, 777):
+        rng = np.random.default_rng(B)
+        mid = rng.integers(0, 3, B).astype(np.int32)
+        if B > 10:
+            mid[::50] = 9
+        kp = cases.human_keypoints(B, seed=3)
+        last = np.zeros((B, fleet.n_max), np.float32)
+        for m, o in enumerate(opts):
+            lim = build(rels[m])[1].joint_limits
+            last[mid == m, : o.opt_dof] = lim.mean(1).astype(np.float32)
+        st_h = np.zeros(B, np.uint32)
+        q_h, status = _lib.retarget_multi(fleet.models, mid, kp, last, state=st_h, qpos_out=np.full((B, fleet.n_max), -7.0, np.float32),
+                                          want_status=True)
+        st_d = torch.zeros(B, dtype=torch.int32, device="cuda")
+        out = torch.full((B, fleet.n_max), -7.0, dtype=torch.float32, device="cuda")
+        fleet.retarget(torch.from_numpy(mid).cuda(), torch.from_numpy(kp).cuda(), torch.from_numpy(last).cuda(), st_d, out=out)
+        torch.cuda.synchronize()
+        assert np.array_equal(q_h, out.cpu().numpy())
+        assert np.array_equal(st_h, st_d.cpu().numpy().astype(np.uint32))
+        assert np.all(q_h[mid == 9] == -7.0) and np.all(status <= 1)
