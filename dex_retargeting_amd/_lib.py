@@ -85,9 +85,10 @@ def load() -> C.CDLL:
                                          C.c_double, vp, C.c_int32, vp, vp]
     lib.dexr_fleet_workspace_bytes.argtypes = [i64]
     lib.dexr_fleet_workspace_bytes.restype = C.c_size_t
-    lib.dexr_retarget_multi_dev.argtypes = [C.POINTER(vp), C.c_int32, i64, vp, vp, vp, C.c_int32, vp, vp, vp, optp, vp,
-                                            C.c_size_t, vp]
-    lib.dexr_retarget_multi.argtypes = [C.POINTER(vp), C.c_int32, i64, i32p, f32p, f32p, C.c_int32, u32p, f32p, i32p, optp]
+    lib.dexr_retarget_multi_dev.argtypes = [C.POINTER(vp), C.c_int32, i64, vp, vp, vp, C.c_int32, vp, C.c_int32, vp, vp, vp,
+                                            optp, vp, C.c_size_t, vp]
+    lib.dexr_retarget_multi.argtypes = [C.POINTER(vp), C.c_int32, i64, i32p, f32p, f32p, C.c_int32, f32p, C.c_int32, u32p,
+                                        f32p, i32p, optp]
     lib.dexr_retarget.argtypes = [vp, i64, f32p, f32p, f32p, u32p, f32p, i32p, i32p, f32p, optp]
     lib.dexr_retarget_kp_dev.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, optp, vp]
     lib.dexr_retarget_kp.argtypes = [vp, i64, f32p, f32p, f32p, u32p, f32p, i32p, i32p, f32p, optp]
@@ -277,17 +278,20 @@ def fleet_workspace_bytes(B: int) -> int:
 
 def retarget_multi_dev(models, B: int, model_id_ptr: int, kp_ptr: int, last_ptr: int, ld: int, state_ptr: int,
                        q_ptr: int, status_ptr: int, ws_ptr: int, ws_bytes: int, opts: Optional[SolveOptions] = None,
-                       stream: int = 0):
-    """Mixed-fleet batch (dexr_retarget_multi_dev): `models` is a list of Model handles."""
+                       stream: int = 0, fixed_ptr: int = 0, ld_fixed: int = 0):
+    """Mixed-fleet batch (dexr_retarget_multi_dev): `models` is a list of Model handles; `fixed_ptr` addresses (B, ld_fixed)
+    float32 rows of caller-supplied fixed-joint values (0: no model has any)."""
     arr = (C.c_void_p * len(models))(*[m.handle for m in models])
-    check(load().dexr_retarget_multi_dev(arr, len(models), B, model_id_ptr or None, kp_ptr or None, last_ptr or None, ld,
+    check(load().dexr_retarget_multi_dev(arr, len(models), B, model_id_ptr or None, kp_ptr or None, fixed_ptr or None, ld_fixed,
+                                         last_ptr or None, ld,
                                          state_ptr or None, q_ptr or None, status_ptr or None,
                                          C.byref(opts) if opts is not None else None, ws_ptr or None, ws_bytes,
                                          stream or None))
 
 
 def retarget_multi(models, model_id: np.ndarray, keypoints: np.ndarray, last: np.ndarray, state: Optional[np.ndarray] = None,
-                   qpos_out: Optional[np.ndarray] = None, opts: Optional[SolveOptions] = None, want_status: bool = False):
+                   qpos_out: Optional[np.ndarray] = None, opts: Optional[SolveOptions] = None, want_status: bool = False,
+                   fixed: Optional[np.ndarray] = None):
     """Mixed-fleet batch on HOST arrays (dexr_retarget_multi): model_id (B,) int32, keypoints (B,21,3) f32, last (B,ld) f32,
     state (B,) uint32 in/out or None.  Returns qpos (B,ld) f32 [, status (B,) int32]; `qpos_out` (in-out) supplies the
     values of the rows / columns the call leaves untouched (default zeros)."""
@@ -303,8 +307,10 @@ def retarget_multi(models, model_id: np.ndarray, keypoints: np.ndarray, last: np
     if state is not None and (state.dtype != np.uint32 or state.shape != (B,) or not state.flags["C_CONTIGUOUS"]):
         raise ValueError(f"state must be a C-contiguous uint32 array of shape ({B},)")
     status = np.zeros(B, np.int32)
+    fx = None if fixed is None else np.ascontiguousarray(fixed, dtype=np.float32).reshape(B, -1)
     arr = (C.c_void_p * len(models))(*[m.handle for m in models])
-    check(load().dexr_retarget_multi(arr, len(models), B, _ptr(mid, C.c_int32), _ptr(kp, C.c_float), _ptr(la, C.c_float), ld,
+    check(load().dexr_retarget_multi(arr, len(models), B, _ptr(mid, C.c_int32), _ptr(kp, C.c_float), _ptr(fx, C.c_float),
+                                     0 if fx is None else fx.shape[1], _ptr(la, C.c_float), ld,
                                      _ptr(state, C.c_uint32), _ptr(q, C.c_float), _ptr(status, C.c_int32),
                                      C.byref(opts) if opts is not None else None))
     return (q, status) if want_status else q

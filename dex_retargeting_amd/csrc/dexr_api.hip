@@ -155,6 +155,7 @@ void fill_params(const dexr_model* m, dexr::KernelParams& kp, int64_t B) {
   kp.lds_terms = m->lds_terms;
   kp.n_kp = h.n_keypoints;
   kp.ld = h.n_opt;  // plain batches: rows of last / qout are n_opt long
+  kp.ldf = h.n_fixed;
   for (int i = 0; i < DEXR_MAXT; ++i) {
     kp.h_origin[i] = h.human_origin[i];
     kp.h_task[i] = h.human_task[i];
@@ -1260,9 +1261,9 @@ ForkPool* fork_pool() {
 size_t dexr_fleet_workspace_bytes(int64_t B) { return (dexr_fleet_ws_ints() + (size_t)(B > 0 ? B : 0)) * sizeof(int32_t); }
 
 int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, int64_t B, const int32_t* model_id,
-                            const float* keypoints, const float* last, int32_t ld, uint32_t* state, float* qpos_out,
-                            int32_t* status_out, const dexr_solve_options* opt, void* workspace, size_t workspace_bytes,
-                            void* stream) {
+                            const float* keypoints, const float* fixed, int32_t ld_fixed, const float* last, int32_t ld,
+                            uint32_t* state, float* qpos_out, int32_t* status_out, const dexr_solve_options* opt,
+                            void* workspace, size_t workspace_bytes, void* stream) {
   if (!models || !model_id || !keypoints || !last || !qpos_out || !workspace) return fail(DEXR_ERR_INVALID, "null argument");
   if (n_models < 1 || n_models > DEXR_FLEET_MAX_MODELS) return fail(DEXR_ERR_INVALID, "n_models=%d outside 1..%d", n_models, DEXR_FLEET_MAX_MODELS);
   if (B < 0) return fail(DEXR_ERR_INVALID, "negative batch");
@@ -1274,7 +1275,8 @@ int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, i
     if (!m) return fail(DEXR_ERR_INVALID, "models[%d] is NULL", i);
     if (m->h.kind == DEXR_KIND_FKONLY) return fail(DEXR_ERR_INVALID, "models[%d] is an FK-only table", i);
     if (m->h.n_keypoints <= 0) return fail(DEXR_ERR_INVALID, "models[%d] carries no target_link_human_indices", i);
-    if (m->h.n_fixed > 0) return fail(DEXR_ERR_INVALID, "models[%d] has caller-supplied fixed joints: not supported in fleet batches", i);
+    if (m->h.n_fixed > 0 && (!fixed || m->h.n_fixed > ld_fixed))
+      return fail(DEXR_ERR_INVALID, "models[%d] has %d caller-supplied fixed joints but fixed rows are %d long", i, m->h.n_fixed, fixed ? ld_fixed : 0);
     if (m->h.n_opt > ld) return fail(DEXR_ERR_INVALID, "models[%d] optimises %d joints but rows are %d long", i, m->h.n_opt, ld);
     if (m->h.kind == DEXR_KIND_DEXPILOT && !state) return fail(DEXR_ERR_INVALID, "models[%d] is a DexPilot model but state is NULL", i);
   }
@@ -1330,6 +1332,8 @@ int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, i
       fill_params(m, kp, B);  // B: upper bound of the bucket size (launch geometry); the kernel reads the real count
       apply_options(m, kp, opt);
       kp.kpts = keypoints;
+      kp.fixed = fixed;
+      kp.ldf = ld_fixed;
       kp.last = last;
       kp.state = m->h.kind == DEXR_KIND_DEXPILOT ? state : nullptr;
       kp.qout = qpos_out;
@@ -1356,9 +1360,10 @@ int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, i
 }
 
 int dexr_retarget_multi(const dexr_model* const* models, int32_t n_models, int64_t B, const int32_t* model_id,
-                        const float* keypoints, const float* last, int32_t ld, uint32_t* state, float* qpos_out,
-                        int32_t* status_out, const dexr_solve_options* opt) {
+                        const float* keypoints, const float* fixed, int32_t ld_fixed, const float* last, int32_t ld,
+                        uint32_t* state, float* qpos_out, int32_t* status_out, const dexr_solve_options* opt) {
   if (!models || !model_id || !keypoints || !last || !qpos_out) return fail(DEXR_ERR_INVALID, "null argument");
+  if (ld_fixed < 0 || (fixed && ld_fixed < 1)) return fail(DEXR_ERR_INVALID, "fixed rows of length %d", ld_fixed);
   if (n_models < 1 || n_models > DEXR_FLEET_MAX_MODELS) return fail(DEXR_ERR_INVALID, "n_models=%d outside 1..%d", n_models, DEXR_FLEET_MAX_MODELS);
   if (!models[0]) return fail(DEXR_ERR_INVALID, "models[0] is NULL");
   if (B < 0 || ld < 1) return fail(DEXR_ERR_INVALID, "negative batch or row length");
@@ -1372,6 +1377,7 @@ int dexr_retarget_multi(const dexr_model* const* models, int32_t n_models, int64
   const size_t ws_b = dexr_fleet_workspace_bytes(B);
   const int i_id = sg.add(dexr::Staging::IN, model_id, nullptr, nb * sizeof(int32_t));
   const int i_kp = sg.add(dexr::Staging::IN, keypoints, nullptr, nb * 21 * 3 * sizeof(float));
+  const int i_fix = sg.add(dexr::Staging::IN, fixed, nullptr, fixed ? nb * (size_t)ld_fixed * sizeof(float) : 0);
   const int i_last = sg.add(dexr::Staging::IN, last, nullptr, nb * (size_t)ld * sizeof(float));
   const int i_state = sg.add(dexr::Staging::INOUT, state, state, nb * sizeof(uint32_t));
   const int i_q = sg.add(dexr::Staging::INOUT, qpos_out, qpos_out, nb * (size_t)ld * sizeof(float));
@@ -1379,7 +1385,7 @@ int dexr_retarget_multi(const dexr_model* const* models, int32_t n_models, int64
   const int i_ws = sg.add(dexr::Staging::OUT, nullptr, nullptr, ws_b);
   HIP_TRY(sg.upload(hc));
   const int rc = dexr_retarget_multi_dev(models, n_models, B, sg.dev<int32_t>(hc, i_id), sg.dev<float>(hc, i_kp),
-                                         sg.dev<float>(hc, i_last), ld, sg.dev<uint32_t>(hc, i_state), sg.dev<float>(hc, i_q),
+                                         fixed ? sg.dev<float>(hc, i_fix) : nullptr, ld_fixed, sg.dev<float>(hc, i_last), ld, sg.dev<uint32_t>(hc, i_state), sg.dev<float>(hc, i_q),
                                          status_out ? sg.dev<int32_t>(hc, i_status) : nullptr, opt, sg.dev<void>(hc, i_ws), ws_b, hc.st);
   if (rc != DEXR_OK) return rc;
   HIP_TRY(sg.download(hc));

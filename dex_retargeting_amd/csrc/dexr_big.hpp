@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(64) dexr_big_kernel(const KernelParams kp, con
         const float v = (kp.x0 && !(seq && t_seq > 0)) ? kp.x0[lrow * ld + tb.api[k]] : xl(k);
         x[k] = fminf(fmaxf(v, tb.lo[k]), tb.hi[k]);
       } else if (sk == DEXR_SRC_FIXED) {
-        x[k] = tb.mult[k] * kp.fixed[irow * kp.n_fixed + tb.src_idx[k]] + tb.off[k];
+        x[k] = tb.mult[k] * kp.fixed[irow * kp.ldf + tb.src_idx[k]] + tb.off[k];
       }
     }
   }

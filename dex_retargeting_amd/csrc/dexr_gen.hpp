@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
           double q;
           if (MODE == MODE_FK) q = kp.xin[it * kp.n_q + tb.src_idx[lane]];
           else if (v >= 0) q = l_jmul[lane] * xs[v] + tb.joff[lane];
-          else q = l_jmul[lane] * (double)kp.fixed[it * kp.n_fixed + tb.src_idx[lane]] + tb.joff[lane];
+          else q = l_jmul[lane] * (double)kp.fixed[it * kp.ldf + tb.src_idx[lane]] + tb.joff[lane];
           qj[lane] = q;
         }
         __syncthreads();

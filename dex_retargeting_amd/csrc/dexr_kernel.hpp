@@ -79,6 +79,7 @@ struct KernelParams {
   const int32_t* __restrict__ perm;    // NULL: item i is row i
   const int32_t* __restrict__ bucket;  // NULL: offset 0, B items
   int32_t ld;                          // row length of last / x0 / qout (>= n_opt; rows of a fleet batch are padded)
+  int32_t ldf;                         // row length of fixed (>= n_fixed; = n_fixed outside fleet batches)
   // Frame sequences (SeqRetargeting.retarget semantics, seq_retarget.py:112-134): a work item is a SEQUENCE; the lane
   // (quad) that owns it solves its T frames in order and carries the raw solution, clipped to the joint limits
   // [lo + clip_eps, hi - clip_eps] (tables hold the optimiser's box, widened by clip_eps), as start point and
@@ -676,7 +677,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
           S.xl[k] = l;
           S.x[k] = v;
         } else if (sk == DEXR_SRC_FIXED) {
-          S.x[k] = (real)tb.mult[k] * (real)kp.fixed[it * kp.n_fixed + tb.src_idx[k]] + (real)tb.off[k];
+          S.x[k] = (real)tb.mult[k] * (real)kp.fixed[it * kp.ldf + tb.src_idx[k]] + (real)tb.off[k];
         } else if (sk == DEXR_SRC_DIRECT) {
           S.x[k] = (real)kp.xin[it * kp.n_q + tb.src_idx[k]];
         }

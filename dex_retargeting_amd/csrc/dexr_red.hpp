@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(64, (NV <= 8 ? DEXR_RED_MINW8 : 1)) dexr_red_k
       const int var = tb.var[k];
       double q;
       if (var >= 0) q = (double)tb.vmul[k] * (double)pick_x(var) + (double)tb.off[k];
-      else q = (double)tb.mult[k] * (double)kp.fixed[irow * kp.n_fixed + tb.src_idx[k]] + (double)tb.off[k];
+      else q = (double)tb.mult[k] * (double)kp.fixed[irow * kp.ldf + tb.src_idx[k]] + (double)tb.off[k];
       const bool rev = (revmask >> k) & 1u;
       if (rev) {
         double s, c;

@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         const float v = (kp.x0 && !(seq && t_seq > 0)) ? kp.x0[lrow * ld + tb.api[jsel(s)]] : xlast;
         xj[s] = fminf(fmaxf(v, BOXw[2 * jo_[s]]), BOXw[2 * jo_[s] + 1]);
       } else if (jfix[s]) {
-        xj[s] = tb.mult[jsel(s)] * kp.fixed[irow * kp.n_fixed + tb.src_idx[jsel(s)]] + tb.off[jsel(s)];
+        xj[s] = tb.mult[jsel(s)] * kp.fixed[irow * kp.ldf + tb.src_idx[jsel(s)]] + tb.off[jsel(s)];
       }
       xacc[s] = xj[s];
       if (jin[s]) XLl[jo_[s]] = xlast;
@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       for (int s = 0; s < NFS; ++s)
         if (fsfix[s]) {
           const int k = l + 16 * s;
-          QJl[k] = tb.mult[k] * kp.fixed[irow * kp.n_fixed + tb.src_idx[k]] + tb.off[k];
+          QJl[k] = tb.mult[k] * kp.fixed[irow * kp.ldf + tb.src_idx[k]] + tb.off[k];
         }
     }
     if (dexpilot) {  // projection bits (optimizer.py:466-476)

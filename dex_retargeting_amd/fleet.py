@@ -21,9 +21,8 @@ class MixedFleet:
         self.torch = torch
         self.device = torch.device(device)
         self.optimizers: List[Optimizer] = list(optimizers)
-        for o in self.optimizers:
-            if len(o.idx_pin2fixed):
-                raise ValueError("MixedFleet serves models whose non-target joints are all mimic joints")
+        self.n_fixed = [len(o.idx_pin2fixed) for o in self.optimizers]
+        self.n_fixed_max = max(self.n_fixed)
         self.models = [o.device_model() for o in self.optimizers]
         self.n_opt = [o.opt_dof for o in self.optimizers]
         self.n_max = max(self.n_opt)
@@ -36,9 +35,10 @@ class MixedFleet:
                              "set of options (set them equal, or run the models in separate calls)")
         self._opts = self.optimizers[0]._options()
 
-    def retarget(self, model_id, keypoints, last_qpos, state: Optional["object"] = None, out=None, status=None):
+    def retarget(self, model_id, keypoints, last_qpos, state: Optional["object"] = None, out=None, status=None, fixed=None):
         """model_id (B,) int32, keypoints (B,21,3) f32, last_qpos (B,n_max) f32 (columns >= n_opt[m] ignored),
-        state (B,) int32 DexPilot bits (updated in place) or None  ->  (B, n_max) f32; a frame's row holds its model's
+        state (B,) int32 DexPilot bits (updated in place) or None, fixed (B, n_fixed_max) f32 caller-supplied fixed-joint
+        values (a frame's row holds its model's fixed_qpos; required when a model has fixed joints)  ->  (B, n_max) f32; a frame's row holds its model's
         n_opt joints, the remaining columns are zero (or whatever `out` held).  Enqueues on the current stream."""
         torch = self.torch
         B = int(model_id.shape[0])
@@ -55,6 +55,10 @@ class MixedFleet:
                 raise ValueError(f"{name} must be a contiguous int32 tensor of shape ({B},) on {self.device}")
         if state is None and any(o.retargeting_type == "DEXPILOT" for o in self.optimizers):
             raise ValueError("the fleet contains a DexPilot model: state (B,) int32 is required")
+        if self.n_fixed_max:
+            if fixed is None or fixed.dtype != torch.float32 or not fixed.is_contiguous() or fixed.device != self.device or \
+                    fixed.dim() != 2 or fixed.shape[0] != B or fixed.shape[1] < self.n_fixed_max:
+                raise ValueError(f"fixed must be a contiguous float32 tensor of shape ({B}, >= {self.n_fixed_max}) on {self.device}")
         if out is None:
             out = torch.zeros((B, self.n_max), dtype=torch.float32, device=self.device)
         elif out.dtype != torch.float32 or tuple(out.shape) != (B, self.n_max) or not out.is_contiguous() or out.device != self.device:
@@ -65,5 +69,7 @@ class MixedFleet:
         _lib.retarget_multi_dev(self.models, B, model_id.data_ptr(), keypoints.data_ptr(), last_qpos.data_ptr(), self.n_max,
                                 state.data_ptr() if state is not None else 0, out.data_ptr(),
                                 status.data_ptr() if status is not None else 0, self._ws.data_ptr(), self._ws.numel(),
-                                opts=self._opts, stream=torch.cuda.current_stream(self.device).cuda_stream)
+                                opts=self._opts, stream=torch.cuda.current_stream(self.device).cuda_stream,
+                                fixed_ptr=fixed.data_ptr() if self.n_fixed_max else 0,
+                                ld_fixed=int(fixed.shape[1]) if self.n_fixed_max else 0)
         return out

@@ -210,7 +210,8 @@ int dexr_seq_compose_dev(int64_t B, int32_t T, int32_t n_q, int32_t n_opt, int32
  * solve kernel is enqueued over its index list, reading its bucket's size from device memory and reading / writing
  * the caller's rows in place: no gather / scatter copies and no host synchronisation anywhere.
  *   models     n_models <= DEXR_FLEET_MAX_MODELS handles, each with target_link_human_indices (keypoint input)
- *              and no caller-supplied fixed joints
+ *   fixed      B x ld_fixed float32 rows of caller-supplied fixed-joint values (fixed_qpos, optimizer.py:141-142); a model
+ *              reads its first n_fixed columns; NULL when no model has fixed joints
  *   model_id   B int32 in [0, n_models); frames with another id are left untouched
  *   keypoints  B x 21 x 3 float32: every model forms its own ref_value rows
  *   last, qpos_out  B x ld float32 rows, ld >= max n_opt; a model reads / writes its first n_opt columns
@@ -221,16 +222,16 @@ int dexr_seq_compose_dev(int64_t B, int32_t T, int32_t n_q, int32_t n_opt, int32
 #define DEXR_FLEET_MAX_MODELS 16
 size_t dexr_fleet_workspace_bytes(int64_t B);
 int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, int64_t B, const int32_t* model_id,
-                            const float* keypoints, const float* last, int32_t ld, uint32_t* state, float* qpos_out,
-                            int32_t* status_out, const dexr_solve_options* opt, void* workspace, size_t workspace_bytes,
-                            void* stream);
+                            const float* keypoints, const float* fixed, int32_t ld_fixed, const float* last, int32_t ld,
+                            uint32_t* state, float* qpos_out, int32_t* status_out, const dexr_solve_options* opt,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same with HOST pointers (SURVEY.md section 8b `dexr_retarget_multi`): packs, copies, runs, synchronises like the other
  * host entry points (staged through models[0]'s context; the workspace is internal).  qpos_out is in-out: rows of frames
  * with an unknown model id, and the columns beyond a model's n_opt, come back as they were passed. */
 int dexr_retarget_multi(const dexr_model* const* models, int32_t n_models, int64_t B, const int32_t* model_id,
-                        const float* keypoints, const float* last, int32_t ld, uint32_t* state, float* qpos_out,
-                        int32_t* status_out, const dexr_solve_options* opt);
+                        const float* keypoints, const float* fixed, int32_t ld_fixed, const float* last, int32_t ld,
+                        uint32_t* state, float* qpos_out, int32_t* status_out, const dexr_solve_options* opt);
 
 /* ---- multi-GPU: reassembling the qpos tensor (BASELINE.json north_star; SURVEY.md section 8b `dexr_allgather`, 8e) -------
  * One process per GPU.  Frames are independent, so ranks solve contiguous shards with no exchange; the only collective of

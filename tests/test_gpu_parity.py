@@ -1238,3 +1238,48 @@ def test_host_pointer_fleet_entry_point_equals_the_device_one():
         assert np.array_equal(q_h, out.cpu().numpy())
         assert np.array_equal(st_h, st_d.cpu().numpy().astype(np.uint32))
         assert np.all(q_h[mid == 9] == -7.0) and np.all(status <= 1)
+
+
+def test_fleet_batch_with_caller_fixed_joints():
+    """A fleet whose models take fixed_qpos (target_joint_names = a subset of the joints, optimizer.py:141-142): every
+    frame's row of `fixed` holds its model's fixed-joint values; answers equal the per-model calls."""
+    torch = pytest.importorskip("torch")
+    from dex_retargeting_amd.fleet import MixedFleet
+
+    names = ["joint_0.0", "joint_1.0", "joint_2.0", "joint_3.0", "joint_12.0", "joint_13.0", "joint_14.0", "joint_15.0",
+             "joint_5.0", "joint_9.0"]
+    cfg = dict(type="vector", urdf_path="allegro_hand/allegro_hand_right.urdf", target_joint_names=names,
+               target_origin_link_names=["wrist"] * 4,
+               target_task_link_names=["link_15.0_tip", "link_3.0_tip", "link_7.0_tip", "link_11.0_tip"],
+               target_link_human_indices=np.array([[0, 0, 0, 0], [4, 8, 12, 16]]), scaling_factor=1.6)
+    sub = _custom(cfg).optimizer                                   # 10 variables, 6 fixed joints
+    full = build("teleop/allegro_hand_right.yml")[0].optimizer     # 16 variables, none fixed
+    shadow = build("teleop/shadow_hand_right_dexpilot.yml")[0].optimizer
+    opts = [sub, full, shadow]
+    fleet = MixedFleet(opts)
+    assert fleet.n_fixed == [6, 0, 0] and fleet.n_fixed_max == 6
+    B = 600
+    rng = np.random.default_rng(8)
+    mid = rng.integers(0, 3, B).astype(np.int32)
+    kp = cases.human_keypoints(B, seed=21)
+    fixed = rng.uniform(0.0, 0.3, (B, 6)).astype(np.float32)
+    last = np.zeros((B, fleet.n_max), np.float32)
+    for m, o in enumerate(opts):
+        lim = o.robot.joint_limits[o.idx_pin2target]
+        last[mid == m, : o.opt_dof] = lim.mean(1).astype(np.float32)
+    state = torch.zeros(B, dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError, match="fixed must be"):
+        fleet.retarget(torch.from_numpy(mid).cuda(), torch.from_numpy(kp).cuda(), torch.from_numpy(last).cuda(), state)
+    out = fleet.retarget(torch.from_numpy(mid).cuda(), torch.from_numpy(kp).cuda(), torch.from_numpy(last).cuda(), state,
+                         fixed=torch.from_numpy(fixed).cuda())
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for m, o in enumerate(opts):
+        sel = mid == m
+        st = np.zeros(int(sel.sum()), np.uint32) if o.retargeting_type == "DEXPILOT" else None
+        want = o.retarget_keypoints_batch(kp[sel], fixed[sel] if m == 0 else None, last[sel][:, : o.opt_dof], state=st)
+        assert np.abs(out[sel][:, : o.opt_dof] - want).max() < 2e-6, m
+    # the host-array entry point takes the same rows
+    st_h = np.zeros(B, np.uint32)
+    q_h = _lib.retarget_multi(fleet.models, mid, kp, last, state=st_h, fixed=fixed)
+    assert np.array_equal(q_h, out)
