@@ -523,6 +523,14 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
           }
           pred = gen_wave_sum(pp);
           smax = gen_wave_max(am);
+          if (lam <= (double)kp.lam0 && smax < (double)kp.blind_tol) {
+            // an essentially undamped Newton step of a verified model shorter than blind_tol: its error is ~C s^2, far
+            // below tol -- taken without a further evaluation (the rule of the specialised kernels)
+            if (lane < nv) x[lane] = xt[lane];
+            __syncthreads();
+            status = ST_CONVERGED;
+            break;
+          }
           Ft = eval_at(xt, false) + reg_at(xt);
           accept = (Ft <= F) && (pred > 0);
         }
@@ -534,7 +542,9 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
           F = eval_at(x, true) + reg_at(x);
           add_reg_model();
           const double t3 = 2.0 * rho - 1.0;
-          lam = fmax(lam * fmax(1.0 / 3.0, 1.0 - t3 * t3 * t3), 1e-12);
+          double shrink = fmax(1.0 / 3.0, 1.0 - t3 * t3 * t3);
+          if (kp.lam_fastdec > 0 && rho > 0.9) shrink = (double)kp.lam_fastdec;  // an accurate model: take the damping back fast
+          lam = fmax(lam * shrink, 1e-12);
           nu = 2.0;
           if (small) {
             status = ST_CONVERGED;
