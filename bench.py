@@ -303,7 +303,7 @@ class Workload:
                 if "SQ_INSTS_VALU" in pmc:  # wave64 VALU instruction = 4 issue cycles on a 16-lane SIMD; 1024 SIMDs, 2.4 GHz
                     valu_frac = pmc["SQ_INSTS_VALU"] * 4.0 / (1024 * kernel_ms * 1e-3 * 2.4e9)
         fam, bucket, chain = self.model.kernel()
-        kname = KERNEL_NAMES[fam] + f", bucket {bucket}" + (", serial-chain specialisation" if chain else "")
+        kname = KERNEL_NAMES[fam] + f", bucket {bucket}" + (", serial-chain specialisation" + (" with the tip pass" if chain == 2 else "") if chain else "")
         if precision == "f64":
             kname = f"dexr_kernel<{bucket}, double> (register kernel, float64 arithmetic)"
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,

@@ -133,6 +133,11 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         objs.append(o)
         if force or _stale(o, [inst_s] + HEADERS):
             jobs.append((inst_s, o, NO_SLP + [f"-DDEXR_NMAX={n}", "-DDEXR_F64=0", "-DDEXR_MODE=0", "-DDEXR_CHAIN=1", "-DDEXR_EXT=1"]))
+    for tag, defs in (("tip", []), ("ext_tip", ["-DDEXR_EXT=1"])):  # tip pass of the serial-chain kernel (dexr_tip.hpp)
+        o = os.path.join(BUILD, f"dexr_inst_{tag}_4_0_0.o")
+        objs.append(o)
+        if force or _stale(o, [inst_s, os.path.join(CSRC, "dexr_tip.hpp")] + HEADERS):
+            jobs.append((inst_s, o, NO_SLP + ["-DDEXR_NMAX=4", "-DDEXR_F64=0", "-DDEXR_MODE=0", "-DDEXR_CHAIN=1", "-DDEXR_TIP=1"] + defs))
     for n in CHAIN_BUCKETS:  # serial-chain specialisation, float32 solve only
         o = os.path.join(BUILD, f"dexr_inst_chain_{n}_0_0.o")
         objs.append(o)

@@ -169,7 +169,7 @@ class Model:
         """(family, bucket, chain) of the float32 solve kernel this handle launches."""
         f, b, c = C.c_int32(), C.c_int32(), C.c_int32()
         check(load().dexr_model_kernel(self._h, C.byref(f), C.byref(b), C.byref(c)))
-        return int(f.value), int(b.value), bool(c.value)
+        return int(f.value), int(b.value), int(c.value)  # chain: 0, 1 (serial-chain kernel) or 2 (with its tip pass)
 
     def lane_plan(self, comp: int = 0):
         """(n_chain, depth, chain (16,16) uint8, anc_rev (32,) uint32) of the sixteen-lane kernel for one component."""

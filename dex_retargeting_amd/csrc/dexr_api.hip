@@ -59,6 +59,7 @@ struct dexr_model {
   int lds_frames = 1;  // max n_frame over components
   int lds_terms = 1;   // max n_term over components
   bool chain = false;  // every component is a plain serial chain filling its bucket (CHAIN kernel applies)
+  bool tip = false;    // ... and carries one vector term from a base frame to a frame on its last joint (dexr_tip.hpp)
   bool quad = false;   // dense 9..24-joint components solved four lanes per frame (dexr_quad_kernel)
   bool big = false;    // components of 9+ joints solved by dexr_big_kernel (Hessian in LDS, float64 kinematics)
   bool wide = false;   // dense 9..32-joint components solved sixteen lanes per frame (dexr_wide_kernel)
@@ -507,10 +508,30 @@ int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStr
   }
   const int64_t blocks = (waves + wpb - 1) / wpb;
   if (blocks > 0x7fffffffLL) return fail(DEXR_ERR_INVALID, "batch too large for one launch");
-  dexr::launch_fn fn = dexr::find_launcher(m->bucket, f64, mode, m->chain, ext);
+  dexr::launch_fn fn = dexr::find_launcher(m->bucket, f64, mode, m->chain, ext, m->tip);
   if (!fn) return fail(DEXR_ERR_UNSUPPORTED, "no kernel for bucket %d / f64=%d / mode=%d", m->bucket, f64, mode);
+#ifdef DEXR_SMALL_PROF
+  static double* sprof = nullptr;  // profiling build only: stage cycles of wave 0 (dexr_kernel.hpp SPROF_*)
+  const bool sprof_on = mode == dexr::MODE_SOLVE && m->bucket <= 8;
+  if (sprof_on) {
+    if (!sprof) (void)hipMalloc((void**)&sprof, 12 * sizeof(double));
+    (void)hipMemsetAsync(sprof, 0, 12 * sizeof(double), st);
+    kp.g64out = sprof;
+  }
+#endif
   hipError_t e = fn(kp, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, st);
   if (e != hipSuccess) return fail(DEXR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+#ifdef DEXR_SMALL_PROF
+  if (sprof_on) {
+    double h[12];
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h, sprof, sizeof(h), hipMemcpyDeviceToHost);
+    const char* names[6] = {"hand-out", "step", "fk", "residuals", "accept", "retire"};
+    fprintf(stderr, "[sprof] B=%lld passes(wave 0)=%.0f cycles per pass:", (long long)kp.B, h[11]);
+    for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %.0f |", names[i], h[11] > 0 ? h[i] / h[11] : 0.0);
+    fprintf(stderr, "\n");
+  }
+#endif
   return DEXR_OK;
 }
 
@@ -718,6 +739,15 @@ void select_kernels(dexr_model* m) {
         m->chain = false;
   }
   if (m->bucket != 4) m->chain = false;  // only the 4-joint bucket has a chain instantiation
+  // tip pass (dexr_tip.hpp): VectorOptimizer components with ONE term whose origin frame sits on the base and whose task
+  // frame sits on the last joint -- every finger of the per-finger vector models (dexr_tuning.chain = 2: plain chain kernel)
+  m->tip = m->chain && m->tune.chain == 1 && h.kind == DEXR_KIND_VECTOR;
+  for (size_t ci = 0; ci < m->comps.size() && m->tip; ++ci) {
+    const dexr_comp_table& c = m->comps[ci];
+    if (c.n_term != 1) { m->tip = false; break; }
+    const int ft = c.term_task[0], fo = c.term_origin[0];
+    if (ft < 0 || ft >= c.n_frame || fo < 0 || fo >= c.n_frame || c.frame_joint[ft] != 3 || c.frame_joint[fo] != -1) m->tip = false;
+  }
 }
 
 void apply_options(const dexr_model* m, dexr::KernelParams& kp, const dexr_solve_options* opt) {
@@ -978,7 +1008,7 @@ int dexr_model_kernel(const dexr_model* m, int32_t* family, int32_t* bucket, int
   if (family && m->gen) *family = DEXR_KERNEL_GENERAL;
   else if (family) *family = m->wide ? DEXR_KERNEL_WIDE : m->red ? DEXR_KERNEL_REDUCED : m->quad ? DEXR_KERNEL_QUAD : m->big ? DEXR_KERNEL_LDS : DEXR_KERNEL_REGISTER;
   if (bucket) *bucket = m->bucket;
-  if (chain) *chain = m->chain ? 1 : 0;
+  if (chain) *chain = m->tip ? 2 : m->chain ? 1 : 0;
   return DEXR_OK;
 }
 

@@ -8,6 +8,9 @@
 #ifndef DEXR_CHAIN
 #define DEXR_CHAIN 0
 #endif
+#ifndef DEXR_TIP
+#define DEXR_TIP 0  // serial chains whose single term ends on the last joint: the pass of dexr_tip.hpp (needs DEXR_CHAIN)
+#endif
 #ifndef DEXR_EXT
 #define DEXR_EXT 0  // small-component buckets only: the variant with fleet / sequence addressing (see KernelParams)
 #endif
@@ -22,7 +25,11 @@ typedef float inst_real;
 #define DEXR_CAT_(a, b, c, d) a##b##_##c##_##d
 #define DEXR_CAT(a, b, c, d) DEXR_CAT_(a, b, c, d)
 
-#if DEXR_CHAIN && DEXR_EXT
+#if DEXR_TIP && DEXR_EXT
+#define DEXR_PREFIX launch_ext_tip_
+#elif DEXR_TIP
+#define DEXR_PREFIX launch_tip_
+#elif DEXR_CHAIN && DEXR_EXT
 #define DEXR_PREFIX launch_ext_chain_
 #elif DEXR_CHAIN
 #define DEXR_PREFIX launch_chain_
@@ -34,7 +41,7 @@ typedef float inst_real;
 
 hipError_t DEXR_CAT(DEXR_PREFIX, DEXR_NMAX, DEXR_F64, DEXR_MODE)(const KernelParams& kp, dim3 grid, dim3 block, size_t lds,
                                                               hipStream_t st) {
-  hipLaunchKernelGGL((dexr_kernel<DEXR_NMAX, inst_real, DEXR_MODE, (DEXR_CHAIN != 0), (DEXR_EXT != 0) || (DEXR_NMAX > 8)>), grid, block, lds, st,
+  hipLaunchKernelGGL((dexr_kernel<DEXR_NMAX, inst_real, DEXR_MODE, (DEXR_CHAIN != 0), (DEXR_EXT != 0) || (DEXR_NMAX > 8), (DEXR_TIP != 0)>), grid, block, lds, st,
                      kp, kp.comps);
   return hipGetLastError();
 }

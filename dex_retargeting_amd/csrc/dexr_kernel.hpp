@@ -105,6 +105,28 @@ struct WideTable {
   int32_t pair_max;             // longest per-lane list
 };
 
+// -DDEXR_SMALL_PROF=1 (tools/prof_small_stages.sh; never in the shipped library): wave 0 of the launch accumulates the cycles
+// (s_memtime) of every stage of its passes and adds them to kp.g64out[stage] when its queue is dry.
+#ifdef DEXR_SMALL_PROF
+#define SPROF_DECL long long sp_t0 = 0, sp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define SPROF_START() sp_t0 = clock64()
+#define SPROF_STAGE(i)                    \
+  {                                       \
+    const long long sp_t1 = clock64();    \
+    sp_acc[i] += sp_t1 - sp_t0;           \
+    sp_t0 = sp_t1;                        \
+  }
+#define SPROF_FLUSH()                                                                   \
+  if (wave_global == 0 && lane == 0 && kp.g64out) {                                     \
+    for (int i = 0; i < 12; ++i) atomicAdd(&kp.g64out[i], (double)sp_acc[i]);           \
+  }
+#else
+#define SPROF_DECL
+#define SPROF_START()
+#define SPROF_STAGE(i)
+#define SPROF_FLUSH()
+#endif
+
 enum { MODE_SOLVE = 0, MODE_EVAL = 1, MODE_FK = 2 };
 enum { ST_CONVERGED = 0, ST_MAXITER = 1, ST_FALLBACK = 2 };  // == DEXR_STATUS_* in dexr.h
 
@@ -176,6 +198,9 @@ struct LocalTab {
     }
   }
 };
+}  // namespace dexr
+#include "dexr_tip.hpp"
+namespace dexr {
 template <typename TB> struct TabTraits { static constexpr bool LOCAL = false; };
 template <int N> struct TabTraits<LocalTab<N>> { static constexpr bool LOCAL = true; };
 
@@ -565,8 +590,10 @@ struct LaneSolver {
 // EXT = true adds the extended addressing of KernelParams (fleet buckets, frame sequences).  The small-component
 // kernels are instantiated both ways so that the plain single-model launch keeps its register budget; the large ones
 // always carry it.
-template <int NMAX, typename real, int MODE, bool CHAIN = false, bool EXT = (NMAX > 8)>
+// TIP = true (CHAIN, 4 joints, float32 solve only): every component is a tip component and its pass is dexr_tip.hpp's.
+template <int NMAX, typename real, int MODE, bool CHAIN = false, bool EXT = (NMAX > 8), bool TIP = false>
 __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4) ? DEXR_CHAIN_MINW : 1) dexr_kernel(const KernelParams kp, const dexr_comp_table* __restrict__ comps) {
+  static_assert(!TIP || (CHAIN && NMAX == 4 && sizeof(real) == 4 && MODE == MODE_SOLVE), "tip pass: 4-joint float32 chain solve only");
   extern __shared__ __align__(16) unsigned char lds_raw[];
   using LS = LaneSolver<NMAX, real, CHAIN>;
   using RT = RealTraits<real>;
@@ -800,9 +827,20 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
     // one Cholesky.  The accepted quadratic model (Hs, gs) stays in registers, so a rejected step costs only the
     // re-solve with more damping.
     auto run = [&](const auto& tbl) {
+    // loop-invariant scalars of the pass; the tip kernel pins them in SGPRs (a kernel-argument load + wait each otherwise)
+    auto hot = [](float v) -> float { if constexpr (TIP) return tip_pin(v); else return v; };
+    auto hoti = [](int v) -> int { if constexpr (TIP) return tip_pin(v); else return v; };
+    const real k_lam0 = (real)hot(kp.lam0), k_tol = (real)hot(kp.tol), k_blind_tol = (real)hot(kp.blind_tol);
+    const real k_step_cap = (real)hot(kp.step_cap), k_lam_jump = (real)hot(kp.lam_jump), k_lam_fastdec = (real)hot(kp.lam_fastdec);
+    const real k_lam_recover = (real)hot(kp.lam_recover), k_stall_ratio = (real)hot(kp.stall_ratio), k_stall_cap = (real)hot(kp.stall_cap);
+    const int k_stall_from = hoti(kp.stall_from), k_max_blind = hoti(kp.max_blind), k_max_iter = hoti(kp.max_iter);
+    const real k_delta = (real)hot((float)delta);
+    // (tip kernel) loss constants of the component's single term
+    const float tip_beta = hot(kp.huber_delta), tip_ibeta = hot(1.f / kp.huber_delta), tip_w = hot(kp.inv_norm);
+    const float tip_nw = hot(kp.newton != 0 ? 1.f : 0.f);
     const unsigned QCHUNK = kp.qchunk;
     real Hs[LS::NH], gs[NMAX], xo[NMAX];
-    real F = 0, lam = (real)kp.lam0, nu = 2, sprev = (real)1e30;
+    real F = 0, lam = k_lam0, nu = 2, sprev = (real)1e30;
     int my_iters = 0, blind = 0, nrej = 0;  // nrej: rejected steps of this solve (fast damping recovery only after the first)
     bool has = false, fresh = false;
     int64_t my_item = 0;
@@ -821,8 +859,10 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
       pool_end = in_static ? (unsigned)((tile * 64 + 64 < nB) ? tile * 64 + 64 : nB) : 0u;
     }
     unsigned* queue = kp.queue + comp;
+    SPROF_DECL
 
     for (;;) {
+      SPROF_START();
       // (1) hand new frames to idle lanes
       const unsigned long long want = __ballot(!has);
       if (want != 0ull && !dry) {
@@ -853,7 +893,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
               if ((optmask >> k) & 1u) S.x[k] = fmin(fmax(S.x[k], (real)tbl.lo[k]), (real)tbl.hi[k]);
             has = true;
             fresh = true;
-            lam = (real)kp.lam0;
+            lam = k_lam0;
             nu = 2;
             sprev = (real)1e30;
             my_iters = 0;
@@ -866,6 +906,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
         if (dry) break;
         continue;
       }
+      SPROF_STAGE(0)
 
       // (2) step from the accepted model (lanes holding a fresh frame evaluate their start point instead)
       real smax = 0, pred = 0;
@@ -887,7 +928,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
             const bool fc = (freemask >> cc) & 1u;
             S.H[LS::hidx(rr, cc)] = (fr && fc) ? Hs[LS::hidx(rr, cc)] : (real)0;
           }
-          S.H[LS::hidx(rr, rr)] = fr ? Hs[LS::hidx(rr, rr)] + (real)2 * delta + lam : (real)1;
+          S.H[LS::hidx(rr, rr)] = fr ? Hs[LS::hidx(rr, rr)] + (real)2 * k_delta + lam : (real)1;
         }
         real gm[NMAX];
 #pragma unroll
@@ -895,7 +936,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
         real d[NMAX];
         // modified Cholesky (see chol_solve): `ok` = no pivot had to be modified, i.e. d is the Newton step of the
         // damped model; a modified step is still tried (the decrease test below judges it)
-        ok = S.template chol_solve<true>(d, (real)2 * delta + lam);
+        ok = S.template chol_solve<true>(d, (real)2 * k_delta + lam);
         const bool stepping = has && !fresh;
         // trust radius: scale the step so that no joint moves more than step_cap (alpha in (0, 1])
         real dmax = 0, gd = 0, dd = 0;
@@ -907,7 +948,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
             dd += d[k] * d[k];
           }
         // (a step from a modified factorisation -- negative curvature -- is stretched (up to 8 x) towards the trust radius, see dexr_red.hpp)
-        const real alpha = (kp.step_cap > 0 && (dmax > (real)kp.step_cap || (!ok && dmax > (real)0))) ? fmin((real)kp.step_cap / dmax, (real)8) : (real)1;
+        const real alpha = (k_step_cap > 0 && (dmax > k_step_cap || (!ok && dmax > (real)0))) ? fmin(k_step_cap / dmax, (real)8) : (real)1;
         // predicted decrease of the damped model along alpha*d:  alpha (1 - alpha/2) (-g.d) + alpha^2/2 lam d.d
         pred = alpha * ((real)1 - (real)0.5 * alpha) * gd + (real)0.5 * alpha * alpha * lam * dd;
 #pragma unroll
@@ -924,20 +965,29 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
         // confirm it.  Take it and retire the frame one pass earlier.
         // Beyond 10 tol this is only trusted on the fast (quadratic) tail of a Newton iteration: the step must be at most a
         // tenth of the previous accepted one -- in a nearly flat valley steps shrink slowly and C s^2 is not small.
-        last_step = stepping && ok && smax < (real)kp.blind_tol && lam <= (real)kp.lam0 &&
-                    (smax < (real)10 * (real)kp.tol || smax < (real)0.1 * sprev);
+        last_step = stepping && ok && smax < k_blind_tol && lam <= k_lam0 &&
+                    (smax < (real)10 * k_tol || smax < (real)0.1 * sprev);
       }
 
       // (3) forward kinematics + fused value / gradient / Hessian at S.x
-      S.fk(tb, nj, P, lane);
-      real Ft = S.template residuals<2>(tb, kp, nt, vmask, P, T, W, lane);
-      S.template fold_mimic<true>(tb, nj);
+      SPROF_STAGE(1)
+      real Ft;
+      if constexpr (TIP) {
+        Ft = tip_eval(tbl, S.x, T[lane], T[64 + lane], T[128 + lane], tip_beta, tip_ibeta, tip_w, tip_nw, S.g, S.H);
+        SPROF_STAGE(2)
+      } else {
+        S.fk(tb, nj, P, lane);
+        SPROF_STAGE(2)
+        Ft = S.template residuals<2>(tb, kp, nt, vmask, P, T, W, lane);
+        S.template fold_mimic<true>(tb, nj);
+      }
+      SPROF_STAGE(3)
 #pragma unroll
       for (int k = 0; k < NMAX; ++k) {
         if ((optmask >> k) & 1u) {
           const real dx = S.x[k] - S.xl[k];
-          Ft += delta * dx * dx;
-          S.g[k] += (real)2 * delta * dx;
+          Ft += k_delta * dx * dx;
+          S.g[k] += (real)2 * k_delta * dx;
         } else {
           S.g[k] = 0;
         }
@@ -975,26 +1025,26 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
             const real rho = (F - Ft) / fmax(pred, (real)1e-30);
             const real t = (real)2 * rho - (real)1;
             real shrink = below_floor ? (real)(1.0 / 3.0) : fmax((real)(1.0 / 3.0), (real)1 - t * t * t);
-            if (kp.lam_fastdec > 0 && rho > (real)0.9)
-              shrink = (kp.lam_recover > 0 && nrej <= 2 && lam > (real)10 * (real)kp.lam0) ? (real)kp.lam_recover : (real)kp.lam_fastdec;
+            if (k_lam_fastdec > 0 && rho > (real)0.9)
+              shrink = (k_lam_recover > 0 && nrej <= 2 && lam > (real)10 * k_lam0) ? k_lam_recover : k_lam_fastdec;
             lam = fmax(lam * shrink, (real)1e-9);
             nu = 2;
             F = Ft;
-            const bool stalled = below_floor && blind >= kp.stall_from && smax > (real)kp.stall_ratio * sprev && smax < (real)kp.stall_cap * (real)kp.tol;
+            const bool stalled = below_floor && blind >= k_stall_from && smax > k_stall_ratio * sprev && smax < k_stall_cap * k_tol;
             blind = below_floor ? blind + 1 : 0;
             sprev = smax;
             // a step below tol only means convergence when the damping is not what made it small (see dexr_big.hpp)
-            const real lam_ok = fmax((real)2 * delta, (real)10 * (real)kp.lam0);
-            if ((smax < (real)kp.tol && lam <= lam_ok) || stalled || blind >= kp.max_blind) {
+            const real lam_ok = fmax((real)2 * k_delta, (real)10 * k_lam0);
+            if ((smax < k_tol && lam <= lam_ok) || stalled || blind >= k_max_blind) {
               finished = true;
               status = ST_CONVERGED;
-            } else if (smax < (real)kp.tol) {
+            } else if (smax < k_tol) {
               lam = fmax((real)0.1 * lam, (real)0.5 * lam_ok);
             }
           } else {
             ++nrej;
         lam = fmax(lam, (real)1e-6) * nu;
-            if (kp.lam_jump > 0) {  // go straight to a damping that matters next to the curvature
+            if (k_lam_jump > 0) {  // go straight to a damping that matters next to the curvature
               real ds = 0;
               int dn = 0;
 #pragma unroll
@@ -1003,19 +1053,19 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
                   ds += Hs[LS::hidx(k, k)];
                   ++dn;
                 }
-              lam = fmax(lam, (real)kp.lam_jump * ds / (real)(dn > 0 ? dn : 1));
+              lam = fmax(lam, k_lam_jump * ds / (real)(dn > 0 ? dn : 1));
             }
             nu *= 2;
             if (lam > (real)1e10) {  // no descent direction resolvable any more
               finished = true;
               status = finite ? ST_CONVERGED : ST_FALLBACK;
             }
-            if (finite && smax < (real)kp.tol) {  // rejected step below tol: converged at the rounding floor of F
+            if (finite && smax < k_tol) {  // rejected step below tol: converged at the rounding floor of F
               finished = true;
               status = ST_CONVERGED;
             }
           }
-          if (!finished && my_iters >= kp.max_iter) finished = true;  // status stays ST_MAXITER
+          if (!finished && my_iters >= k_max_iter) finished = true;  // status stays ST_MAXITER
         }
       }
 #pragma unroll
@@ -1027,6 +1077,10 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
       for (int i = 0; i < LS::NH; ++i) Hs[i] = accept ? S.H[i] : Hs[i];
 
       // (5) retire finished frames
+      SPROF_STAGE(4)
+#ifdef DEXR_SMALL_PROF
+      sp_acc[11] += 1;
+#endif
       if (finished) {
         bool bad = (status == ST_FALLBACK);
 #pragma unroll
@@ -1055,7 +1109,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
           for (int k = 0; k < NMAX; ++k)
             if ((optmask >> k) & 1u) S.x[k] = fmin(fmax(S.x[k], (real)tbl.lo[k]), (real)tbl.hi[k]);
           fresh = true;
-          lam = (real)kp.lam0;
+          lam = k_lam0;
           nu = 2;
           sprev = (real)1e30;
           my_iters = 0;
@@ -1066,9 +1120,15 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
           has = false;
         }
       }
+      SPROF_STAGE(5)
     }
+    SPROF_FLUSH()
     };
-    if constexpr (CHAIN) {
+    if constexpr (TIP) {
+      TipTab tt;  // every constant of the pass pinned in SGPRs (dexr_tip.hpp)
+      tt.load(tb, tb.term_task[0], tb.term_origin[0]);
+      run(tt);
+    } else if constexpr (CHAIN) {
       LocalTab<NMAX> lt;  // tables in registers for the whole kernel (see LocalTab)
       lt.load(tb);
       run(lt);

@@ -32,6 +32,9 @@ hipError_t launch_ext_8_0_0(const KernelParams&, dim3, dim3, size_t, hipStream_t
 hipError_t launch_ext_4_1_0(const KernelParams&, dim3, dim3, size_t, hipStream_t);
 hipError_t launch_ext_8_1_0(const KernelParams&, dim3, dim3, size_t, hipStream_t);
 hipError_t launch_ext_chain_4_0_0(const KernelParams&, dim3, dim3, size_t, hipStream_t);
+// tip specialisation of the serial-chain kernel (dexr_tip.hpp): one vector term from a base frame to a frame on the last joint
+hipError_t launch_tip_4_0_0(const KernelParams&, dim3, dim3, size_t, hipStream_t);
+hipError_t launch_ext_tip_4_0_0(const KernelParams&, dim3, dim3, size_t, hipStream_t);
 
 // large-component kernel (dexr_big.hpp): float64 kinematics + float32 Hessian in LDS
 hipError_t launch_big_16(const KernelParams&, dim3, dim3, size_t, hipStream_t);
@@ -79,7 +82,8 @@ struct GenTab;
 hipError_t launch_gen(int mode, const KernelParams& kp, const GenTab& tb, dim3 grid, size_t lds, hipStream_t st);
 size_t gen_lds_bytes(const GenTab& tb);
 
-static inline launch_fn find_launcher(int bucket, int f64, int mode, bool chain = false, bool ext = false) {
+static inline launch_fn find_launcher(int bucket, int f64, int mode, bool chain = false, bool ext = false, bool tip = false) {
+  if (tip && chain && bucket == 4 && !f64 && mode == MODE_SOLVE) return ext ? launch_ext_tip_4_0_0 : launch_tip_4_0_0;
   if (ext && mode == MODE_SOLVE && bucket <= 8) {
     if (chain && bucket == 4 && !f64) return launch_ext_chain_4_0_0;
     if (bucket == 4) return f64 ? launch_ext_4_1_0 : launch_ext_4_0_0;

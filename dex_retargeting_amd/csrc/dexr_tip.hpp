@@ -1,0 +1,212 @@
+// dexr_tip.hpp -- the pass of a "tip" component, written out for the chain kernel (dexr_kernel<4, float, SOLVE, CHAIN, EXT, TIP>).
+//
+// A tip component is what every finger of the per-finger vector models is (teleop Allegro / LEAP, BASELINE.json
+// configs[0] and [1], the headline): an unbranched chain of four revolute optimised joints hanging off the base and ONE
+// residual term -- the vector from a frame on the fixed base to a frame on the last joint (VectorOptimizer with one
+// (origin, task) pair per finger, /root/reference/src/dex_retargeting/optimizer.py:203-306).  The generic pass walks that structure through tables: per joint a scalar load of the placement + wait, a rolled
+// loop over the frames attached to it, frame positions through LDS, a rolled term loop with three dependent scalar loads,
+// ancestor masks tested bit by bit.  Measured (tools/prof_small_stages.sh, s_memtime): ~6 000 cycles per pass for a lone
+// wave at ~550 VALU instructions -- the launch of 65 536 frames is bound by the slowest frame's passes at that latency
+// (4 096 frames: 0.044 ms, 65 536: 0.063 ms).  Here the pass is ONE basic block:
+//   * every constant of the component pinned in SGPRs for the whole kernel (readfirstlane: the compiler cannot turn them
+//     back into loads), laid out as the register PAIRS the packed instructions take;
+//   * forward kinematics in v_pk_fma_f32 form: a rotation is kept as rows (R[i][0], R[i][1]) + R[i][2]; the product with
+//     the next placement yields (column 0, column 1) and (axis component, origin component) pairs, 6 packed FMAs per row;
+//     the joint rotation Rz(q) is two packed operations per row; the last joint's rotation is never formed (the tip offset
+//     is rotated instead);
+//   * Jacobian columns, gradient and Hessian for the joint PAIRS (0,1) and (2,3) at once: packed cross products, a Hessian
+//     row costs 7 packed FMAs per pair of entries;
+//   * sines / cosines of the four joint angles evaluated two at a time (same Cody-Waite reduction and polynomials as
+//     RealTraits<float>::sincos).
+// No LDS traffic except the three target coordinates, no scalar loads, no branches.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dexr_tables.h"
+
+namespace dexr {
+
+typedef float kv2 __attribute__((ext_vector_type(2)));  // a register pair: operands of v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+
+// A wave-uniform value the compiler must KEEP (in an SGPR, or a VGPR lane when those run out): the empty asm makes its source
+// opaque (a vector register of unknown contents), so the readfirstlane can neither be folded back into the kernel-argument /
+// table load the value came from nor be re-loaded inside the pass.
+static __device__ __forceinline__ int tip_pin(int v) {
+  asm volatile("" : "+v"(v));
+  return __builtin_amdgcn_readfirstlane(v);
+}
+static __device__ __forceinline__ float tip_pin(float v) { return __int_as_float(tip_pin(__float_as_int(v))); }
+static __device__ __forceinline__ kv2 tip_splat(float v) { return kv2{v, v}; }
+
+// Wave-uniform constants of one tip component (65 SGPRs).  The origin frame's position is folded into the first joint's
+// placement: every world position below is relative to it, which leaves the residual, the Jacobian and the Hessian unchanged.
+struct TipTab {
+  kv2 A0[3];        // joint 0 (its parent is the base, R = I): (X0[i][0], X0[i][1])
+  float c0[3];      // X0[i][2]: joint 0's axis
+  float p0[3];      // X0's translation - origin frame position
+  kv2 XA[3][3];     // joints 1..3: XA[k-1][j] = (Xk[j][0], Xk[j][1])        (row j of the placement's rotation)
+  kv2 XB[3][3];     //              XB[k-1][j] = (Xk[j][2], Xk's translation[j])
+  float off[3];     // task frame origin in the last joint's frame
+  float lo[4], hi[4];
+  int32_t api[4];   // (not pinned: used once per frame)
+
+  // `ft`: task frame (on joint 3); `fo`: origin frame on the base, or -1
+  __device__ __forceinline__ void load(const dexr_comp_table& tb, int ft, int fo) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      A0[i] = kv2{tip_pin(tb.X[0][3 * i]), tip_pin(tb.X[0][3 * i + 1])};
+      c0[i] = tip_pin(tb.X[0][3 * i + 2]);
+      p0[i] = tip_pin(tb.X[0][9 + i] - (fo >= 0 ? tb.frame_off[fo][i] : 0.f));
+      off[i] = tip_pin(tb.frame_off[ft][i]);
+    }
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        XA[k - 1][j] = kv2{tip_pin(tb.X[k][3 * j]), tip_pin(tb.X[k][3 * j + 1])};
+        XB[k - 1][j] = kv2{tip_pin(tb.X[k][3 * j + 2]), tip_pin(tb.X[k][9 + j])};
+      }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      lo[k] = tip_pin(tb.lo[k]);
+      hi[k] = tip_pin(tb.hi[k]);
+      api[k] = tb.api[k];
+    }
+  }
+};
+
+// sin / cos of two angles at once: the arithmetic of RealTraits<float>::sincos on register pairs (quadrant selection per half)
+static __device__ __forceinline__ void tip_sincos2(kv2 a, kv2* s, kv2* c) {
+  const kv2 t = a * 0.63661977236758134f;
+  const kv2 kf = kv2{rintf(t.x), rintf(t.y)};
+  kv2 r = a - kf * 1.5707962513e+00f;
+  r = r - kf * 7.5497894159e-08f;
+  const kv2 z = r * r;
+  const kv2 sp = r + (r * z) * (tip_splat(-1.6666654611e-1f) + z * (tip_splat(8.3321608736e-3f) + z * -1.9515295891e-4f));
+  const kv2 cp = (tip_splat(1.0f) - z * 0.5f) +
+                 (z * z) * (tip_splat(4.166664568298827e-2f) + z * (tip_splat(-1.388731625493765e-3f) + z * 2.443315711809948e-5f));
+  const int kx = (int)kf.x, ky = (int)kf.y;
+  const float sx = (kx & 1) ? cp.x : sp.x, cx = (kx & 1) ? sp.x : cp.x;
+  const float sy = (ky & 1) ? cp.y : sp.y, cy = (ky & 1) ? sp.y : cp.y;
+  *s = kv2{(kx & 2) ? -sx : sx, (ky & 2) ? -sy : sy};
+  *c = kv2{((kx + 1) & 2) ? -cx : cx, ((ky + 1) & 2) ? -cy : cy};
+}
+
+// One pass at x: returns the data term (reference "huber_distance", no regulariser), writes its gradient g and the lower
+// triangle of its Hessian H (hidx order: 00 | 10 11 | 20 21 22 | 30 31 32 33).  t0..t2: the lane's target (origin folded, see
+// TipTab); w: the 'mean' factor; nw: 1 with the second-order kinematic term (Newton), 0 without.
+static __device__ __forceinline__ float tip_eval(const TipTab& tt, const float (&x)[4], float t0, float t1, float t2,
+                                                 float beta, float ibeta, float w, float nw,
+                                                 float (&g)[4], float (&H)[10]) {
+  kv2 sA, cA, sB, cB;  // joints (0,1) and (2,3)
+  tip_sincos2(kv2{x[0], x[1]}, &sA, &cA);
+  tip_sincos2(kv2{x[2], x[3]}, &sB, &cB);
+  const float sn[4] = {sA.x, sA.y, sB.x, sB.y}, cs[4] = {cA.x, cA.y, cB.x, cB.y};
+
+  // ---- forward kinematics -------------------------------------------------------------------------------------------
+  kv2 rp[3];      // (R[i][0], R[i][1]) of the running rotation
+  float r2[3];    // R[i][2]
+  float p[3];     // running origin
+  kv2 ao[4][3];   // (axis component i, origin component i) of joint k
+  {
+    const kv2 sc = kv2{sn[0], -sn[0]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const kv2 a = tt.A0[i];
+      rp[i] = a * cs[0] + a.yx * sc;
+      r2[i] = tt.c0[i];
+      p[i] = tt.p0[i];
+      ao[0][i] = kv2{tt.c0[i], tt.p0[i]};
+    }
+  }
+  kv2 n01[3];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const kv2 bx = tip_splat(rp[i].x), by = tip_splat(rp[i].y), bz = tip_splat(r2[i]);
+      n01[i] = bx * tt.XA[k - 1][0] + by * tt.XA[k - 1][1] + bz * tt.XA[k - 1][2];
+      kv2 t = bx * tt.XB[k - 1][0] + by * tt.XB[k - 1][1] + bz * tt.XB[k - 1][2];
+      t.y += p[i];
+      ao[k][i] = t;
+    }
+    if (k < 3) {
+      const kv2 sc = kv2{sn[k], -sn[k]};
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        rp[i] = n01[i] * cs[k] + n01[i].yx * sc;
+        r2[i] = ao[k][i].x;
+        p[i] = ao[k][i].y;
+      }
+    }
+  }
+  // task frame: origin_3 + (Rn Rz(q3)) off = origin_3 + Rn (Rz off)
+  const float ox = cs[3] * tt.off[0] - sn[3] * tt.off[1], oy = sn[3] * tt.off[0] + cs[3] * tt.off[1];
+  float pt[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) pt[i] = ao[3][i].y + n01[i].x * ox + n01[i].y * oy + ao[3][i].x * tt.off[2];
+
+  // ---- residual (LaneSolver::residuals' vector-norm branch) -------------------------------------------------------------
+  const float r[3] = {pt[0] - t0, pt[1] - t1, pt[2] - t2};
+  // SmoothL1 of the vector norm (optimizer.py:272-273); 1-ulp v_sqrt / v_rcp
+  const float d2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  const float d = __builtin_amdgcn_sqrtf(d2);
+  const bool quad = d < beta;
+  const float F = w * (quad ? 0.5f * d2 * ibeta : d - 0.5f * beta);
+  const float id = quad ? ibeta : __builtin_amdgcn_rcpf(d);  // d >= beta > 0 in the linear branch
+  const float psi = w * id;
+  const float fvec[3] = {psi * r[0], psi * r[1], psi * r[2]};
+  const float kap = quad ? 0.f : psi * id * id;
+  const float fn[3] = {nw * fvec[0], nw * fvec[1], nw * fvec[2]};
+
+  // ---- Jacobian columns, gradient, Hessian: joint pairs A = (0,1), B = (2,3) ----------------------------------------------
+  kv2 axA[3], ogA[3], axB[3], ogB[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    axA[i] = kv2{ao[0][i].x, ao[1][i].x};
+    ogA[i] = kv2{ao[0][i].y, ao[1][i].y};
+    axB[i] = kv2{ao[2][i].x, ao[3][i].x};
+    ogB[i] = kv2{ao[2][i].y, ao[3][i].y};
+  }
+  kv2 colA[3], colB[3], cfA[3], cfB[3], cwA[3], cwB[3];
+  kv2 gA, gB, uA, uB;
+  auto jac = [&](const kv2 (&axp)[3], const kv2 (&ogp)[3], kv2 (&col)[3], kv2 (&cf)[3], kv2 (&cw)[3], kv2& gp, kv2& up) {
+    kv2 v[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[i] = tip_splat(pt[i]) - ogp[i];
+    col[0] = axp[1] * v[2] - axp[2] * v[1];
+    col[1] = axp[2] * v[0] - axp[0] * v[2];
+    col[2] = axp[0] * v[1] - axp[1] * v[0];
+    gp = col[0] * fvec[0] + col[1] * fvec[1] + col[2] * fvec[2];
+    up = col[0] * r[0] + col[1] * r[1] + col[2] * r[2];
+    // cf = col x f  (second-order term: d2p/dq_c dq_r . f = a_c . (col_r x f), c an ancestor of r or r itself)
+    cf[0] = col[1] * fn[2] - col[2] * fn[1];
+    cf[1] = col[2] * fn[0] - col[0] * fn[2];
+    cf[2] = col[0] * fn[1] - col[1] * fn[0];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cw[i] = col[i] * psi;
+  };
+  jac(axA, ogA, colA, cfA, cwA, gA, uA);
+  jac(axB, ogB, colB, cfB, cwB, gB, uB);
+  const kv2 kuA = uA * kap, kuB = uB * kap;
+  g[0] = gA.x; g[1] = gA.y; g[2] = gB.x; g[3] = gB.y;
+
+  // entries (r, c) and (r, c + 1) of row r against the joint pair Q = (c, c + 1)
+  auto rowpair = [&](float cw0, float cw1, float cw2, float ku, float cf0, float cf1, float cf2, const kv2 (&colQ)[3],
+                     const kv2& uQ, const kv2 (&axQ)[3]) -> kv2 {
+    return colQ[0] * cw0 + colQ[1] * cw1 + colQ[2] * cw2 - uQ * ku + axQ[0] * cf0 + axQ[1] * cf1 + axQ[2] * cf2;
+  };
+  const kv2 q0 = rowpair(cwA[0].x, cwA[1].x, cwA[2].x, kuA.x, cfA[0].x, cfA[1].x, cfA[2].x, colA, uA, axA);
+  const kv2 q1 = rowpair(cwA[0].y, cwA[1].y, cwA[2].y, kuA.y, cfA[0].y, cfA[1].y, cfA[2].y, colA, uA, axA);
+  const kv2 q2a = rowpair(cwB[0].x, cwB[1].x, cwB[2].x, kuB.x, cfB[0].x, cfB[1].x, cfB[2].x, colA, uA, axA);
+  const kv2 q2b = rowpair(cwB[0].x, cwB[1].x, cwB[2].x, kuB.x, cfB[0].x, cfB[1].x, cfB[2].x, colB, uB, axB);
+  const kv2 q3a = rowpair(cwB[0].y, cwB[1].y, cwB[2].y, kuB.y, cfB[0].y, cfB[1].y, cfB[2].y, colA, uA, axA);
+  const kv2 q3b = rowpair(cwB[0].y, cwB[1].y, cwB[2].y, kuB.y, cfB[0].y, cfB[1].y, cfB[2].y, colB, uB, axB);
+  H[0] = q0.x;
+  H[1] = q1.x; H[2] = q1.y;
+  H[3] = q2a.x; H[4] = q2a.y; H[5] = q2b.x;
+  H[6] = q3a.x; H[7] = q3a.y; H[8] = q3b.x; H[9] = q3b.y;
+  return F;
+}
+
+}  // namespace dexr

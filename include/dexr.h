@@ -72,7 +72,8 @@ typedef struct dexr_solve_options {
 typedef struct dexr_tuning {
   uint32_t struct_size; /* sizeof(dexr_tuning) of the caller's header: lets the struct grow compatibly          */
   int32_t kernel;       /* DEXR_KERNEL_*: float32 solve kernel family (AUTO: measured policy, dexr_api.hip)      */
-  int32_t chain;        /* 1: serial-chain specialisation where the tables allow it (default), 0: never          */
+  int32_t chain;        /* 1: serial-chain specialisation (+ its tip pass) where the tables allow it (default), 2: serial-chain
+                           specialisation without the tip pass, 0: never                                           */
   int32_t persist_occ;  /* small components: resident waves per SIMD in queue mode (0: derived from the kernel)  */
   int32_t persist_from; /* small components: queue mode from this many 64-frame tiles per resident wave (8)       */
   int32_t qchunk;       /* frames a wave takes from the queue per atomic (256)                                    */
@@ -120,7 +121,7 @@ int dexr_model_info(const dexr_model* m, dexr_model_header* header_out);
 int dexr_model_get_tuning(const dexr_model* m, dexr_tuning* out);     /* out->struct_size must be set by the caller */
 int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning);  /* re-runs the kernel selection           */
 /* Which float32 solve kernel the handle launches: DEXR_KERNEL_* in *family, joint bucket in *bucket, 1 in *chain
- * when the serial-chain specialisation is active (diagnostics for tools/ and tests). */
+ * when the serial-chain specialisation is active (2: with its tip pass) (diagnostics for tools/ and tests). */
 int dexr_model_kernel(const dexr_model* m, int32_t* family, int32_t* bucket, int32_t* chain);
 /* Diagnostics: the lane plan of component `comp` for the sixteen-lane kernel -- chain_out[16][16]: lane l, step s ->
  * local joint (bit 7 set when that lane publishes the joint's frame, 0xFF: none); anc_rev_out[DEXR_MAXJ]: revolute
