@@ -476,7 +476,9 @@ int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStr
   kp.lam_jump = family_lam_jump(m, FAM_REGISTER);
   if (m->bucket == 32 && mode == dexr::MODE_SOLVE) f64 = 1;  // see find_launcher: bucket 32 is float64 only
   const size_t real_sz = f64 ? 8 : 4;
-  const size_t per_wave = 64 * real_sz * (size_t)(3 * m->lds_frames + 4 * m->lds_terms);
+  // (the tip pass keeps the placements of joints 1..3 in 64 more floats of the wave's LDS, dexr_tip.hpp)
+  const bool tip_kernel = m->tip && m->chain && m->bucket == 4 && !f64 && mode == dexr::MODE_SOLVE;
+  const size_t per_wave = 64 * real_sz * (size_t)(3 * m->lds_frames + 4 * m->lds_terms + (tip_kernel ? 1 : 0));
   int wpb = 4;
   while (wpb > 1 && per_wave * wpb > 48 * 1024) wpb >>= 1;
   if (per_wave > 64 * 1024) return fail(DEXR_ERR_UNSUPPORTED, "component needs %zu B of LDS per wave", per_wave);
@@ -747,6 +749,8 @@ void select_kernels(dexr_model* m) {
     if (c.n_term != 1) { m->tip = false; break; }
     const int ft = c.term_task[0], fo = c.term_origin[0];
     if (ft < 0 || ft >= c.n_frame || fo < 0 || fo >= c.n_frame || c.frame_joint[ft] != 3 || c.frame_joint[fo] != -1) m->tip = false;
+    for (int k = 1; k < 4 && m->tip; ++k)  // the four joints are consecutive columns of last_qpos / qpos_out
+      if (c.api[k] != c.api[0] + k) m->tip = false;
   }
 }
 

@@ -152,12 +152,15 @@ template <> struct RealTraits<float> {
     *c = ((k + 1) & 2) ? -cc : cc;
   }
   static __device__ __forceinline__ float eps() { return 5.9604645e-8f; }
+  // min(max(v, lo), hi) in one instruction (v_med3_f32; fmin / fmax of register operands cost a canonicalising v_max each)
+  static __device__ __forceinline__ float clamp(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 };
 template <> struct RealTraits<double> {
   static __device__ __forceinline__ double rsqrt(double v) { return 1.0 / ::sqrt(v); }
   static __device__ __forceinline__ double sqrt(double v) { return ::sqrt(v); }
   static __device__ __forceinline__ void sincos(double a, double* s, double* c) { ::sincos(a, s, c); }
   static __device__ __forceinline__ double eps() { return 1.1102230246251565e-16; }
+  static __device__ __forceinline__ double clamp(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 };
 
 // Register-resident copy of one component's tables for small serial chains: every field is read with a compile-time
@@ -618,7 +621,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
   const bool valid = item_raw < nB;
   const int64_t item = valid ? item_raw : nB - 1;
 
-  const int per_wave = 64 * (3 * kp.lds_frames + 4 * kp.lds_terms);
+  const int per_wave = 64 * (3 * kp.lds_frames + 4 * kp.lds_terms + (TIP ? 1 : 0));  // (+ the tip pass's broadcast constants)
   real* P = reinterpret_cast<real*>(lds_raw) + (size_t)wave_in_block * per_wave;
   real* T = P + 64 * 3 * kp.lds_frames;
   real* W = T + 64 * 3 * kp.lds_terms;
@@ -672,6 +675,11 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
     }
   };
 
+  // column of last_qpos / qpos_out of local joint k.  A tip component's four joints are consecutive columns (checked when the
+  // kernel is selected): one pinned base index instead of four table loads, and the per-joint addresses share one base
+  const int tip_api0 = TIP ? tip_pin((int)tb.api[0]) : 0;
+  auto api_of = [&](int k) -> int { if constexpr (TIP) return tip_api0 + k; else return tb.api[k]; };
+
   // Loads everything frame `it` needs into this lane: joint values (start point, regularisation target, fixed
   // joints) into registers, per-term targets / DexPilot weights into the lane's LDS column.  Returns the updated
   // DexPilot projection bits.
@@ -691,11 +699,11 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
         const int sk = CHAIN ? DEXR_SRC_OPT : tb.src_kind[k];
         if (sk == DEXR_SRC_OPT) {
           real v;
-          if (MODE == MODE_EVAL) v = (real)kp.xin[it * kp.n_opt + tb.api[k]];
+          if (MODE == MODE_EVAL) v = (real)kp.xin[it * kp.n_opt + api_of(k)];
           else if (carry) v = (real)(float)prev;  // the reference carries the float32 result (optimizer.py:99)
-          else if (kp.x0) v = (real)kp.x0[r0 * ld + tb.api[k]];
-          else v = (real)kp.last[r0 * ld + tb.api[k]];
-          real l = carry ? v : (real)kp.last[r0 * ld + tb.api[k]];
+          else if (!TIP && kp.x0) v = (real)kp.x0[r0 * ld + api_of(k)];  // (float64 polish launches only)
+          else v = (real)kp.last[r0 * ld + api_of(k)];
+          real l = carry ? v : (real)kp.last[r0 * ld + api_of(k)];
           if (seq) {  // seq_retarget.py:118-120: last_qpos clipped to the joint limits before every solve
             const real lo_s = (real)tb.lo[k] + (real)kp.clip_eps, hi_s = (real)tb.hi[k] - (real)kp.clip_eps;
             l = fmin(fmax(l, lo_s), hi_s);
@@ -712,7 +720,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
     }
     if (MODE == MODE_FK) return 0u;
     uint32_t nst = 0;
-    if (kp.kind == DEXR_KIND_DEXPILOT) {
+    if (!TIP && kp.kind == DEXR_KIND_DEXPILOT) {
       // optimizer.py:462-508.  Terms are the model's vectors in order: pairs first, then wrist->finger.
       const int F = kp.num_fingers;
       const int n_pair = F * (F - 1) / 2, len_s1 = F - 1;
@@ -765,7 +773,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
         W[t * 64 + lane] = (real)wt;
       }
     } else {
-      const float sc = (kp.kind == DEXR_KIND_VECTOR) ? kp.scaling : 1.f;
+      const float sc = (TIP || kp.kind == DEXR_KIND_VECTOR) ? kp.scaling : 1.f;
 #pragma clang loop unroll(disable) vectorize(disable)
       for (int t = 0; t < nt; ++t) {
         float rv[3];
@@ -890,7 +898,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
             my_nst = load_item(my_item);
 #pragma unroll
             for (int k = 0; k < NMAX; ++k)
-              if ((optmask >> k) & 1u) S.x[k] = fmin(fmax(S.x[k], (real)tbl.lo[k]), (real)tbl.hi[k]);
+              if ((optmask >> k) & 1u) S.x[k] = RT::clamp(S.x[k], (real)tbl.lo[k], (real)tbl.hi[k]);
             has = true;
             fresh = true;
             lam = k_lam0;
@@ -955,7 +963,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
         for (int k = 0; k < NMAX; ++k) {
           xo[k] = S.x[k];
           if ((optmask >> k) & 1u) {
-            const real xt = fmin(fmax(S.x[k] + alpha * d[k], (real)tbl.lo[k]), (real)tbl.hi[k]);
+            const real xt = RT::clamp(S.x[k] + alpha * d[k], (real)tbl.lo[k], (real)tbl.hi[k]);
             smax = fmax(smax, fabs(xt - S.x[k]));
             if (stepping) S.x[k] = xt;
           }
@@ -1094,8 +1102,8 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
           if ((optmask >> k) & 1u) {
             const real v = bad ? S.xl[k] : S.x[k];
             S.x[k] = v;  // (sequence mode: the value the next frame starts from)
-            kp.qout[orow * ld + tbl.api[k]] = (float)v;
-            if (kp.qout64) kp.qout64[orow * ld + tbl.api[k]] = (double)v;
+            kp.qout[orow * ld + api_of(k)] = (float)v;
+            if (!TIP && kp.qout64) kp.qout64[orow * ld + api_of(k)] = (double)v;  // (float64 launches only)
           }
         }
         if (kp.status) atomicMax(&kp.status[orow], status);
@@ -1107,7 +1115,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
           my_nst = load_item(my_item, my_t, my_nst);
 #pragma unroll
           for (int k = 0; k < NMAX; ++k)
-            if ((optmask >> k) & 1u) S.x[k] = fmin(fmax(S.x[k], (real)tbl.lo[k]), (real)tbl.hi[k]);
+            if ((optmask >> k) & 1u) S.x[k] = RT::clamp(S.x[k], (real)tbl.lo[k], (real)tbl.hi[k]);
           fresh = true;
           lam = k_lam0;
           nu = 2;
@@ -1116,7 +1124,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
           blind = 0;
           nrej = 0;
         } else {
-          if (kp.kind == DEXR_KIND_DEXPILOT && kp.state && comp == 0) kp.state[r0] = my_nst;
+          if (!TIP && kp.kind == DEXR_KIND_DEXPILOT && kp.state && comp == 0) kp.state[r0] = my_nst;
           has = false;
         }
       }
@@ -1126,7 +1134,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
     };
     if constexpr (TIP) {
       TipTab tt;  // every constant of the pass pinned in SGPRs (dexr_tip.hpp)
-      tt.load(tb, tb.term_task[0], tb.term_origin[0]);
+      tt.load(tb, tb.term_task[0], tb.term_origin[0], W + 64 * kp.lds_terms, lane);
       run(tt);
     } else if constexpr (CHAIN) {
       LocalTab<NMAX> lt;  // tables in registers for the whole kernel (see LocalTab)

@@ -8,17 +8,17 @@
 // ancestor masks tested bit by bit.  Measured (tools/prof_small_stages.sh, s_memtime): ~6 000 cycles per pass for a lone
 // wave at ~550 VALU instructions -- the launch of 65 536 frames is bound by the slowest frame's passes at that latency
 // (4 096 frames: 0.044 ms, 65 536: 0.063 ms).  Here the pass is ONE basic block:
-//   * every constant of the component pinned in SGPRs for the whole kernel (readfirstlane: the compiler cannot turn them
-//     back into loads), laid out as the register PAIRS the packed instructions take;
+//   * the constants of the component pinned in SGPRs for the whole kernel (the compiler cannot turn them back into loads) or
+//     broadcast from the wave's LDS, laid out as the register PAIRS the packed instructions take;
 //   * forward kinematics in v_pk_fma_f32 form: a rotation is kept as rows (R[i][0], R[i][1]) + R[i][2]; the product with
 //     the next placement yields (column 0, column 1) and (axis component, origin component) pairs, 6 packed FMAs per row;
 //     the joint rotation Rz(q) is two packed operations per row; the last joint's rotation is never formed (the tip offset
 //     is rotated instead);
 //   * Jacobian columns, gradient and Hessian for the joint PAIRS (0,1) and (2,3) at once: packed cross products, a Hessian
 //     row costs 7 packed FMAs per pair of entries;
-//   * sines / cosines of the four joint angles evaluated two at a time (same Cody-Waite reduction and polynomials as
-//     RealTraits<float>::sincos).
-// No LDS traffic except the three target coordinates, no scalar loads, no branches.
+//   * sines / cosines of the four joint angles evaluated two at a time, reduced by pi instead of pi/2 (one sign flip
+//     instead of a quadrant selection).
+// No scalar loads, no branches; LDS only for the target and the broadcast constants.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -38,20 +38,33 @@ static __device__ __forceinline__ int tip_pin(int v) {
 static __device__ __forceinline__ float tip_pin(float v) { return __int_as_float(tip_pin(__float_as_int(v))); }
 static __device__ __forceinline__ kv2 tip_splat(float v) { return kv2{v, v}; }
 
-// Wave-uniform constants of one tip component (65 SGPRs).  The origin frame's position is folded into the first joint's
-// placement: every world position below is relative to it, which leaves the residual, the Jacobian and the Hessian unchanged.
+// Wave-uniform constants of one tip component.  The origin frame's position is folded into the first joint's placement:
+// every world position below is relative to it, which leaves the residual, the Jacobian and the Hessian unchanged.
+// Joint 0, the tip offset and the box are pinned in SGPRs (23); the placements of joints 1..3 (36 values) would push the
+// kernel's scalar state past the 102 SGPRs a wave has (spilled to VGPR lanes: a v_readlane per use, measured 80 per pass), so
+// they sit in 144 bytes of the wave's LDS, already paired, and are read where they are used (ds_read_b64 of a wave-uniform
+// address: a broadcast, no VALU slot).
 struct TipTab {
   kv2 A0[3];        // joint 0 (its parent is the base, R = I): (X0[i][0], X0[i][1])
   float c0[3];      // X0[i][2]: joint 0's axis
   float p0[3];      // X0's translation - origin frame position
-  kv2 XA[3][3];     // joints 1..3: XA[k-1][j] = (Xk[j][0], Xk[j][1])        (row j of the placement's rotation)
-  kv2 XB[3][3];     //              XB[k-1][j] = (Xk[j][2], Xk's translation[j])
+  const kv2* xl;    // LDS, joints k = 1..3:  xl[6 (k-1) + j]     = (Xk[j][0], Xk[j][1])   (row j of the placement's rotation)
+                    //                        xl[6 (k-1) + 3 + j] = (Xk[j][2], Xk's translation[j])
   float off[3];     // task frame origin in the last joint's frame
   float lo[4], hi[4];
-  int32_t api[4];   // (not pinned: used once per frame)
+  __device__ __forceinline__ kv2 XA(int k1, int j) const { return xl[6 * k1 + j]; }
+  __device__ __forceinline__ kv2 XB(int k1, int j) const { return xl[6 * k1 + 3 + j]; }
 
-  // `ft`: task frame (on joint 3); `fo`: origin frame on the base, or -1
-  __device__ __forceinline__ void load(const dexr_comp_table& tb, int ft, int fo) {
+  // `ft`: task frame (on joint 3); `fo`: origin frame on the base, or -1; `lds`: 36 floats of the wave's LDS
+  __device__ __forceinline__ void load(const dexr_comp_table& tb, int ft, int fo, float* lds, int lane) {
+    if (lane < 36) {
+      const int q = lane >> 1, h = lane & 1, k = q / 6 + 1, jj = q % 6;
+      const int src = jj < 3 ? 3 * jj + h : (h == 0 ? 3 * (jj - 3) + 2 : 9 + (jj - 3));
+      lds[lane] = (&tb.X[0][0])[k * 12 + src];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    xl = reinterpret_cast<const kv2*>(lds);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       A0[i] = kv2{tip_pin(tb.X[0][3 * i]), tip_pin(tb.X[0][3 * i + 1])};
@@ -60,36 +73,33 @@ struct TipTab {
       off[i] = tip_pin(tb.frame_off[ft][i]);
     }
 #pragma unroll
-    for (int k = 1; k < 4; ++k)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        XA[k - 1][j] = kv2{tip_pin(tb.X[k][3 * j]), tip_pin(tb.X[k][3 * j + 1])};
-        XB[k - 1][j] = kv2{tip_pin(tb.X[k][3 * j + 2]), tip_pin(tb.X[k][9 + j])};
-      }
-#pragma unroll
     for (int k = 0; k < 4; ++k) {
       lo[k] = tip_pin(tb.lo[k]);
       hi[k] = tip_pin(tb.hi[k]);
-      api[k] = tb.api[k];
     }
   }
 };
 
-// sin / cos of two angles at once: the arithmetic of RealTraits<float>::sincos on register pairs (quadrant selection per half)
+// sin / cos of two angles at once.  Reduction by pi (k = rint(a / pi), two-constant Cody-Waite: 3.140625 has 9 significant
+// bits, so k * 3.140625 is exact), minimax polynomials of degree 9 / 10 on [-pi/2, pi/2] (fitted in float64; errors
+// 2.5e-8 / 3.3e-9 before rounding, 1.2e-7 / 1.1e-7 in float32 arithmetic over |a| < 7: RealTraits<float>::sincos measures
+// 2.5e-7 on the same angles), and ONE sign for both: sin(a) = (-1)^k sin(r), cos(a) = (-1)^k cos(r) -- the parity bit of k
+// shifted into the sign position and XORed in, instead of the quadrant swap / two conditional negations per angle of the
+// pi/2 reduction (14 selects and compares per angle there, 4 integer operations here).
 static __device__ __forceinline__ void tip_sincos2(kv2 a, kv2* s, kv2* c) {
-  const kv2 t = a * 0.63661977236758134f;
+  const kv2 t = a * 0.318309886183790672f;
   const kv2 kf = kv2{rintf(t.x), rintf(t.y)};
-  kv2 r = a - kf * 1.5707962513e+00f;
-  r = r - kf * 7.5497894159e-08f;
+  kv2 r = a - kf * 3.140625f;
+  r = r - kf * 9.6765358467e-04f;
   const kv2 z = r * r;
-  const kv2 sp = r + (r * z) * (tip_splat(-1.6666654611e-1f) + z * (tip_splat(8.3321608736e-3f) + z * -1.9515295891e-4f));
+  const kv2 sp = r + (r * z) * (tip_splat(-1.6666665961e-01f) +
+                                z * (tip_splat(8.3332417961e-03f) + z * (tip_splat(-1.9822688286e-04f) + z * 2.6345787831e-06f)));
   const kv2 cp = (tip_splat(1.0f) - z * 0.5f) +
-                 (z * z) * (tip_splat(4.166664568298827e-2f) + z * (tip_splat(-1.388731625493765e-3f) + z * 2.443315711809948e-5f));
-  const int kx = (int)kf.x, ky = (int)kf.y;
-  const float sx = (kx & 1) ? cp.x : sp.x, cx = (kx & 1) ? sp.x : cp.x;
-  const float sy = (ky & 1) ? cp.y : sp.y, cy = (ky & 1) ? sp.y : cp.y;
-  *s = kv2{(kx & 2) ? -sx : sx, (ky & 2) ? -sy : sy};
-  *c = kv2{((kx + 1) & 2) ? -cx : cx, ((ky + 1) & 2) ? -cy : cy};
+                 (z * z) * (tip_splat(4.1666666076e-02f) +
+                            z * (tip_splat(-1.3888812242e-03f) + z * (tip_splat(2.4786036849e-05f) + z * -2.6544504746e-07f)));
+  const int sx = (int)kf.x << 31, sy = (int)kf.y << 31;
+  *s = kv2{__int_as_float(__float_as_int(sp.x) ^ sx), __int_as_float(__float_as_int(sp.y) ^ sy)};
+  *c = kv2{__int_as_float(__float_as_int(cp.x) ^ sx), __int_as_float(__float_as_int(cp.y) ^ sy)};
 }
 
 // One pass at x: returns the data term (reference "huber_distance", no regulariser), writes its gradient g and the lower
@@ -125,8 +135,8 @@ static __device__ __forceinline__ float tip_eval(const TipTab& tt, const float (
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const kv2 bx = tip_splat(rp[i].x), by = tip_splat(rp[i].y), bz = tip_splat(r2[i]);
-      n01[i] = bx * tt.XA[k - 1][0] + by * tt.XA[k - 1][1] + bz * tt.XA[k - 1][2];
-      kv2 t = bx * tt.XB[k - 1][0] + by * tt.XB[k - 1][1] + bz * tt.XB[k - 1][2];
+      n01[i] = bx * tt.XA(k - 1, 0) + by * tt.XA(k - 1, 1) + bz * tt.XA(k - 1, 2);
+      kv2 t = bx * tt.XB(k - 1, 0) + by * tt.XB(k - 1, 1) + bz * tt.XB(k - 1, 2);
       t.y += p[i];
       ao[k][i] = t;
     }
