@@ -1283,3 +1283,51 @@ def test_fleet_batch_with_caller_fixed_joints():
     st_h = np.zeros(B, np.uint32)
     q_h = _lib.retarget_multi(fleet.models, mid, kp, last, state=st_h, fixed=fixed)
     assert np.array_equal(q_h, out)
+
+
+# ---- round 3: the tip pass of the serial-chain kernel (csrc/dexr_tip.hpp) -----------------------------------------------
+@pytest.mark.parametrize("rel", ["teleop/allegro_hand_right.yml", "teleop/leap_hand_left.yml"])
+def test_tip_pass_agrees_with_the_table_driven_kernels(rel):
+    """The per-finger vector models run the hand-written pass (packed straight-line FK / Jacobian / Hessian, sin / cos
+    reduced by pi); dexr_tuning.chain = 2 selects the table-driven serial-chain kernel, chain = 0 the generic register
+    kernel.  Same objective, same damping rules, different rounding: same minimisers to float32 solve accuracy, same
+    iteration counts on all but a few frames, and each variant deterministic."""
+    seq, prob = build(rel)
+    model = seq.optimizer.device_model()
+    B = 8192
+    kp = np.ascontiguousarray(cases.human_keypoints(B + 1, seed=cases.SEED))
+    mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
+    res = {}
+    try:
+        model.tune(chain=1)
+        assert model.kernel() == (_lib.KERNEL_REGISTER, 4, 2)
+        last = model.retarget(kp[:-1], None, mid, keypoints=True)
+        for chain in (1, 2, 0):
+            model.tune(chain=chain)
+            assert model.kernel()[2] == {1: 2, 2: 1, 0: 0}[chain]
+            q, info = model.retarget(kp[1:], None, last, keypoints=True, want_info=True)
+            q2 = model.retarget(kp[1:], None, last, keypoints=True)
+            assert np.array_equal(q, q2)
+            assert (info["status"] == 0).all()
+            res[chain] = (q.astype(np.float64), info["iters"])
+    finally:
+        model.tune(chain=1)
+    q64 = model.retarget_f64(cases.ref_from_keypoints(prob, kp[1:]), None, last)
+    for chain in (2, 0):
+        dq = np.abs(res[1][0] - res[chain][0]).max(1)
+        assert np.percentile(dq, 99) < 2e-5 and (dq > 1e-4).mean() < 2e-3, (chain, np.percentile(dq, [50, 99, 100]))
+        assert (res[1][1] != res[chain][1]).mean() < 0.05
+    # and it is no further from the float64 kernel's answers than the table-driven float32 kernel is
+    e_tip = np.abs(res[1][0] - q64).max(1)
+    e_tab = np.abs(res[2][0] - q64).max(1)
+    assert np.percentile(e_tip, 99) < 2e-5 and np.percentile(e_tip, 99) < 2 * np.percentile(e_tab, 99) + 1e-6
+
+
+def test_tip_pass_needs_its_pattern():
+    """A position model of the same robot (dense 22-joint component) and a DexPilot model never take the tip pass; the
+    per-finger vector models of both hands do."""
+    for rel, want in (("teleop/allegro_hand_left.yml", 2), ("teleop/leap_hand_right.yml", 2),
+                      ("teleop/allegro_hand_right_dexpilot.yml", 0), ("offline/allegro_hand_right.yml", 0),
+                      ("teleop/panda_gripper.yml", 0)):
+        seq, _ = build(rel)
+        assert seq.optimizer.device_model().kernel()[2] == want, rel
