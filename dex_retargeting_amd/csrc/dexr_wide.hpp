@@ -165,9 +165,9 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63;
-  const int l = lane & 15;        // lane within the frame's row
+  int l = lane & 15;        // lane within the frame's row
   const int slot = lane >> 4;     // frame slot of the wave
-  const int a = l >> 2, b = l & 3;  // row / column class of the Hessian grid
+  int a = l >> 2, b = l & 3;  // row / column class of the Hessian grid
   const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int waves_per_block = blockDim.x >> 6;
   const int64_t wave_global = (int64_t)blockIdx.x * waves_per_block + wave_in_block;
@@ -1127,6 +1127,10 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   };
   float screen_acc = 0.f;  // screening launch: sum of F(x0) over the frames of this wave (lane 0 of each row)
   for (;;) {
+    // the lane's grid coordinates, made opaque once per pass: predicates on them (a == 2, b <= a, ...) are then recomputed
+    // where they are used (one v_cmp) instead of being hoisted out of the loop as 64-bit lane masks -- dozens of SGPR pairs
+    // that do not fit and come back from VGPR lanes with two v_readlane + a hazard nop each
+    asm volatile("" : "+v"(l), "+v"(a), "+v"(b));
     WPROF_START();
     // (0) hand frames to idle rows
     const unsigned long long want = __ballot(!active);
