@@ -341,8 +341,21 @@ def test_full_size_batches_of_the_persistent_kernels(rel):
     m = 4096
     q64 = model.retarget_f64(d["ref"][:m], d["fixed"][:m], d["last"][:m], state=st(m))
     dq = np.abs(q1[:m].astype(np.float64) - q64).max(1)
-    # far starts on human targets: several minima, a few per cent of the frames end in different ones
-    assert np.median(dq) < 1e-5 and (dq < 1e-4).mean() > 0.85, (np.percentile(dq, [50, 90, 99]), (dq < 1e-4).mean())
+    # Far starts on human targets: the objective has several minima and a few per cent of the frames end in different ones
+    # under float32 and float64 arithmetic (measured, tools/probe_basins.py: 4.4 % Shadow DexPilot, 0.5 % LEAP position,
+    # 3.7 % Inspire position; the float32 answer has the LOWER objective on 32-54 % of those frames, i.e. neither
+    # arithmetic is systematically in the better basin).  Gate: >= 90 % of the frames agree to 1e-4 rad, and where they do
+    # not, the float32 answer is itself a certified stationary point of the same box-constrained objective (projected
+    # gradient of the float64 objective evaluation at the float32 answer below 1e-6; the float64 kernel's own is ~1e-11).
+    far = dq >= 1e-4
+    assert np.median(dq) < 1e-5 and (~far).mean() > 0.90, (np.percentile(dq, [50, 90, 99]), (~far).mean())
+    if far.any():
+        _, g = model.eval(d["ref"][:m][far], d["fixed"][:m][far], d["last"][:m][far], q1[:m][far].astype(np.float64), state=st(int(far.sum())))
+        qf = q1[:m][far].astype(np.float64)
+        g = g.copy()
+        g[(qf <= lo + 1e-6) & (g > 0)] = 0
+        g[(qf >= hi - 1e-6) & (g < 0)] = 0
+        assert np.abs(g).max() < 1e-6, np.abs(g).max()
 
 
 @pytest.mark.parametrize("rel", ["teleop/allegro_hand_right.yml", "teleop/ability_hand_right.yml",
