@@ -1344,3 +1344,23 @@ def test_tip_pass_needs_its_pattern():
                       ("teleop/panda_gripper.yml", 0)):
         seq, _ = build(rel)
         assert seq.optimizer.device_model().kernel()[2] == want, rel
+
+
+@pytest.mark.parametrize("rel", ["teleop/allegro_hand_right.yml", "teleop/inspire_hand_right.yml",
+                                 "teleop/shadow_hand_right.yml"])
+def test_gauss_newton_option_reaches_the_same_minima(rel):
+    """dexr_solve_options.newton = 0 drops the second-order kinematic term from the model Hessian (tip pass: the cf = col x f
+    products are scaled by 0; the other families skip them).  The minimiser of the objective does not depend on which
+    model the iteration uses: in the unique-minimum regime (reachable targets: small residuals, where Gauss-Newton
+    converges as fast as Newton) both settings return the oracle's answer."""
+    seq, prob = build(rel)
+    model = seq.optimizer.device_model()
+    B = 512
+    d = cases.reachable_set(prob, B, 0.05)
+    want = solvers.solve_lm_batched(prob, d["ref"], d["fixed"], d["last"], newton=True, max_iter=100)
+    qn, inn = model.retarget(d["ref"], d["fixed"], d["last"], want_info=True)
+    qg, ing = model.retarget(d["ref"], d["fixed"], d["last"], want_info=True, opts=_lib.default_options(newton=0, max_iter=200))
+    for q, info in ((qn, inn), (qg, ing)):
+        assert (info["status"] == 0).mean() > 0.99
+        assert (np.abs(q.astype(np.float64) - want).max(1) < 1e-4).mean() >= 0.99
+    assert not np.array_equal(qn, qg)  # (the option reaches the kernel: different models, different rounding)
