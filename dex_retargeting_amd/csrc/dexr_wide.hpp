@@ -383,27 +383,38 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         }
     }
     if (dexpilot) {  // projection bits (optimizer.py:466-476)
+      // One lane per pair vector (n_pair <= 10 of the row's 16 lanes): its length from ONE round of keypoint loads, the
+      // thumb-finger bits (S1, hysteresis on the incoming state) gathered with a row ballot, then the finger-finger bits
+      // (S2 = both S1 bits and a short vector).  A loop over the rows in every lane, as the other kernels have it, waits
+      // for ten dependent load round trips each time a row takes a new frame: tools/prof_wide_stages.sh showed 5 k of a
+      // pass's 39 k cycles going to this hand-out at 65 536 frames.
       const uint32_t st = (seq && t_seq > 0) ? nst : (kp.state ? kp.state[lrow] : 0u);
-      nst = 0;
-      for (int i = 0; i < len_s1; ++i) {
+      float dist = 0.f;
+      if (l < n_pair) {
         float rv[3];
-        ref_row(i, rv);
-        const float dist = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
-        bool bb = (st >> i) & 1u;
+        ref_row(l, rv);
+        dist = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+      }
+      bool bb = false;
+      if (l < len_s1) {
+        bb = (st >> l) & 1u;
         if (dist < kp.project_dist) bb = true;
         if (dist > kp.escape_dist) bb = false;
-        nst |= (bb ? 1u : 0u) << i;
       }
-      int idx = len_s1;
-      for (int aa = 0; aa < F_ - 2; ++aa)
-        for (int b2 = aa + 1; b2 < F_ - 1; ++b2) {
-          float rv[3];
-          ref_row(idx, rv);
-          const float dist = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
-          const bool bb = ((nst >> b2) & 1u) && ((nst >> aa) & 1u) && (dist <= 0.03f);
-          nst |= (bb ? 1u : 0u) << idx;
-          ++idx;
+      const uint32_t s1 = (uint32_t)(__ballot(bb) >> (16 * slot)) & 0xFFFFu;
+      bool b2b = false;
+      if (l >= len_s1 && l < n_pair) {
+        int aa = 0, b2 = 1;  // pair l - len_s1 of the enumeration aa < b2 < F - 1, aa-major (optimizer.py:442-447)
+        for (int i = len_s1; i < l; ++i) {
+          ++b2;
+          if (b2 >= F_ - 1) {
+            ++aa;
+            b2 = aa + 1;
+          }
         }
+        b2b = ((s1 >> b2) & 1u) && ((s1 >> aa) & 1u) && (dist <= 0.03f);
+      }
+      nst = s1 | ((uint32_t)(__ballot(b2b) >> (16 * slot)) & 0xFFFFu);
     }
     FS32[1] = (int32_t)nst;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
