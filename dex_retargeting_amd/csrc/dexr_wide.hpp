@@ -348,6 +348,12 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       v = lastp[tb.api[jsel(s)]];
     return seq ? fminf(fmaxf(v, BOXw[2 * jo_[s]] + kp.clip_eps), BOXw[2 * jo_[s] + 1] - kp.clip_eps) : v;
   };
+  // Target vector and weight of the lane's own term (lane t evaluates term t in every pass): constant while the row's frame
+  // is being solved, so they are formed ONCE when the frame is taken and kept in four registers of that lane -- re-reading
+  // the keypoints in every pass put a global-load round trip into each pass and was the 1.5 x between the kernel's HBM
+  // traffic and its algorithmic bytes.  (Not at n = 32, where the Hessian grid already spills.)
+  constexpr bool TGREG = NMAX <= 24;
+  float tgt[4] = {0.f, 0.f, 0.f, 1.f};
   auto load_frame = [&](int64_t it, int t) {
     const int t_seq = t;
     const int64_t lrow = row_of(it);
@@ -444,6 +450,15 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       const float sc = (kp.kind == DEXR_KIND_VECTOR) ? kp.scaling : 1.f;
 #pragma unroll
       for (int i = 0; i < 3; ++i) tv[i] = rv[i] * sc;
+    }
+  };
+
+  // (called by every lane of a row right after load_frame)
+  auto load_target = [&]() {
+    if (TGREG && l < nt) {
+      float tv[3], wgt;
+      term_target(tb.term_ref[l], tv, wgt);
+      tgt[0] = tv[0]; tgt[1] = tv[1]; tgt[2] = tv[2]; tgt[3] = wgt;
     }
   };
 
@@ -636,7 +651,11 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       const int ft = tb.term_task[l], fo = tb.term_origin[l];
       double rd[3];
       float tv[3], wgt;
-      term_target(tb.term_ref[l], tv, wgt);
+      if (TGREG) {
+        tv[0] = tgt[0]; tv[1] = tgt[1]; tv[2] = tgt[2]; wgt = tgt[3];
+      } else {
+        term_target(tb.term_ref[l], tv, wgt);
+      }
       float ptf[3], pof[3] = {0, 0, 0};
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
@@ -1167,6 +1186,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         pool_next += (unsigned)__popcll(__ballot(got)) >> 4;
         if (got) {
           load_frame((int64_t)cand, 0);
+          load_target();
           active = true;
           reset_state();
         }
@@ -1343,6 +1363,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       if (seq && t_seq + 1 < kp.T) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the next frame's start point is the row just written
         load_frame(FS64[2], t_seq + 1);
+        load_target();
         reset_state();
       } else {
         if (l == 0 && dexpilot && kp.state && comp == 0) kp.state[f_lrow()] = f_nst();
