@@ -354,6 +354,10 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   // traffic and its algorithmic bytes.  (Not at n = 32, where the Hessian grid already spills.)
   constexpr bool TGREG = NMAX <= 24;
   float tgt[4] = {0.f, 0.f, 0.f, 1.f};
+  // frames of the lane's own term (table reads indexed by the lane: taken once, here, where the lane index is still a
+  // loop-invariant the compiler may use -- inside the pass loop it is opaque, see the top of the loop)
+  const int my_ft = l < nt ? tb.term_task[l] : 0, my_fo = l < nt ? tb.term_origin[l] : -1;
+  const int my_ref = l < nt ? tb.term_ref[l] : 0;
   auto load_frame = [&](int64_t it, int t) {
     const int t_seq = t;
     const int64_t lrow = row_of(it);
@@ -457,7 +461,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   auto load_target = [&]() {
     if (TGREG && l < nt) {
       float tv[3], wgt;
-      term_target(tb.term_ref[l], tv, wgt);
+      term_target(my_ref, tv, wgt);
       tgt[0] = tv[0]; tgt[1] = tv[1]; tgt[2] = tv[2]; tgt[3] = wgt;
     }
   };
@@ -648,13 +652,13 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   auto terms = [&]() -> double {
     double Fv = 0;
     if (l < nt) {
-      const int ft = tb.term_task[l], fo = tb.term_origin[l];
+      const int ft = my_ft, fo = my_fo;
       double rd[3];
       float tv[3], wgt;
       if (TGREG) {
         tv[0] = tgt[0]; tv[1] = tgt[1]; tv[2] = tgt[2]; wgt = tgt[3];
       } else {
-        term_target(tb.term_ref[l], tv, wgt);
+        term_target(my_ref, tv, wgt);
       }
       float ptf[3], pof[3] = {0, 0, 0};
 #pragma unroll
