@@ -1299,7 +1299,41 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     WPROF_STAGE(5)
-    const bool okf = factor_and_solve(freemask, lam);
+    // A failed factorisation (the damped model is indefinite) used to cost a whole pass: the garbage "step" was applied, the
+    // kinematics and the assembly ran at that point, and only then did the rejection raise lambda -- 20-33 % of the passes
+    // of the frames that need 16+ passes (diagnostic build counting rejections), i.e. of the tail
+    // that bounds a launch.  The rejection needs nothing from that evaluation, so it is taken here: the same lambda / nu /
+    // iteration-count updates as the reject branch above, then the factorisation again, inside the pass (16 % of a pass
+    // instead of 100 %).  Same sequence of damping values and trial points, hence the same answers.  (One call site in a
+    // rolled loop: the unrolled factorisation is the largest block of the kernel.)
+    bool okf = true;
+#pragma clang loop unroll(disable)
+    for (int attempt = 0;; ++attempt) {
+      okf = factor_and_solve(freemask, lam);
+      // (not at n = 32: the loop around the 32 x 32 factorisation costs 60 more spilled registers, +16 % per launch)
+      const bool retry = !MODCHOL && NMAX <= 24 && attempt < 3 && !done && !okf;  // (uniform over the row's 16 lanes)
+      if (!__any(retry)) break;
+      if (retry) {
+        float gdl = 0.f, ddl = 0.f;
+#pragma unroll
+        for (int s = 0; s < NJ2; ++s)
+          if (jin[s] && ((freemask >> jo_[s]) & 1u)) {
+            gdl -= GVl[jo_[s]] * dstep[s];
+            ddl += dstep[s] * dstep[s];
+          }
+        const float gd = row_sum(gdl), dd = row_sum(ddl);
+        keff = gd / fmaxf(dd, 1e-30f);
+        ++my_iters;
+        lam = fmaxf(lam, 1e-6f) * nu;
+        if (kp.lam_jump > 0) lam = fmaxf(lam, kp.lam_jump * keff);
+        nu *= 2.f;
+        if (lam > 1e10f) {
+          done = true;
+          status = ST_CONVERGED;
+        }
+        if (!done && my_iters >= kp.max_iter) done = true;
+      }
+    }
     WPROF_STAGE(6)
     const bool stepping = !done;
     if (stepping) {
