@@ -83,6 +83,14 @@ static __device__ __forceinline__ float wquad_bcast(float v) {
 
 // -DDEXR_WIDE_PROF=1 (tools/prof_wide_stages.sh; never in the shipped library): wave 0 of block 0 accumulates the cycles
 // (s_memtime) of every stage of its passes and adds them to kp.g64out[stage] when it retires.
+// -DDEXR_WIDE_DIAG=1 (tools/pass_composition.sh; never in the shipped library): the per-frame iteration count written to
+// kp.iters carries, in its upper bytes, how many of the frame's passes were rejected steps, steps cut by the trust radius
+// and failed factorisations.
+#ifdef DEXR_WIDE_DIAG
+#define WDIAG(x) x
+#else
+#define WDIAG(x)
+#endif
 #ifdef DEXR_WIDE_PROF
 #define WPROF_DECL long long wp_t0 = 0, wp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define WPROF_START() wp_t0 = clock64()
@@ -1135,6 +1143,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 
   // ---- projected Levenberg-Marquardt / Newton ------------------------------------------------------------------------
   float lam = kp.lam0, nu = 2.f, sprev = 1e30f, keff = 0.f;
+  WDIAG(int d_nrej = 0; int d_ncap = 0; int d_nfail = 0;)
   bool done = true, pending = false;
   int status = ST_MAXITER, my_iters = 0, blind = 0;
   double F = 0;
@@ -1151,6 +1160,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     nu = 2.f;
     sprev = 1e30f;
     keff = 0.f;
+    WDIAG(d_nrej = 0; d_ncap = 0; d_nfail = 0;)
     status = ST_MAXITER;
     my_iters = 0;
     blind = 0;
@@ -1250,6 +1260,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
             lam = fmaxf(0.1f * lam, 0.5f * lam_ok);
           }
         } else {
+          WDIAG(++d_nrej; if (!ok) ++d_nfail;)
           lam = fmaxf(lam, 1e-6f) * nu;
           if (kp.lam_jump > 0) lam = fmaxf(lam, kp.lam_jump * (MODCHOL ? hdmean : keff));
           nu *= 2.f;
@@ -1301,7 +1312,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     WPROF_STAGE(5)
     // A failed factorisation (the damped model is indefinite) used to cost a whole pass: the garbage "step" was applied, the
     // kinematics and the assembly ran at that point, and only then did the rejection raise lambda -- 20-33 % of the passes
-    // of the frames that need 16+ passes (diagnostic build counting rejections), i.e. of the tail
+    // of the frames that need 16+ passes (tools/pass_composition.sh, profiles/r03_wide_pass_composition.txt), i.e. of the tail
     // that bounds a launch.  The rejection needs nothing from that evaluation, so it is taken here: the same lambda / nu /
     // iteration-count updates as the reject branch above, then the factorisation again, inside the pass (16 % of a pass
     // instead of 100 %).  Same sequence of damping values and trial points, hence the same answers.  (One call site in a
@@ -1324,6 +1335,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         const float gd = row_sum(gdl), dd = row_sum(ddl);
         keff = gd / fmaxf(dd, 1e-30f);
         ++my_iters;
+        WDIAG(++d_nrej; ++d_nfail;)
         lam = fmaxf(lam, 1e-6f) * nu;
         if (kp.lam_jump > 0) lam = fmaxf(lam, kp.lam_jump * keff);
         nu *= 2.f;
@@ -1350,6 +1362,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       // (MODCHOL: a step from a modified factorisation is stretched towards the trust radius, at most 8 x)
       const float alpha = (kp.step_cap > 0 && (dmax > kp.step_cap || (MODCHOL && !okf && dmax > 0.f)))
                               ? fminf(kp.step_cap / dmax, MODCHOL ? 8.f : 1e30f) : 1.f;
+      WDIAG(if (alpha < 1.f) ++d_ncap;)
       pred = alpha * (1.f - 0.5f * alpha) * gd + 0.5f * alpha * alpha * lam * dd;
       keff = gd / fmaxf(dd, 1e-30f);
       float sl = 0.f;
@@ -1394,7 +1407,11 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       if (l == 0) {
         const int64_t irow = f_irow();
         if (kp.status) atomicMax(&kp.status[irow], status);
+#ifdef DEXR_WIDE_DIAG
+        if (kp.iters) atomicMax(&kp.iters[irow], my_iters | (d_nrej << 8) | (d_ncap << 16) | (d_nfail << 24));
+#else
         if (kp.iters) atomicMax(&kp.iters[irow], my_iters);
+#endif
         if (kp.fval) atomicAdd(&kp.fval[irow], (float)F);
       }
       const int t_seq = seq ? FS32[0] : 0;
