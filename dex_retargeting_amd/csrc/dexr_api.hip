@@ -562,6 +562,8 @@ void default_tuning(dexr_model* m) {
   t.step_cap = 0.3f;
   // small components: a verified, undamped Newton step below 100 tol (2e-4 rad) leaves an error of ~C s^2 < 1e-6 rad
   // (tools/lm_lab.py: max 8.6e-7 over 1 863 frames) and saves the confirming pass: mean 4.3 -> 3.9 passes per frame
+  // (larger components: 10 tol.  Measured with tools/all_configs.py + DEXR_TOOL_KNOBS: 30 tol is 2-3 % faster per launch, but a
+  // far-start LEAP DexPilot frame then stops 2e-3 rad short of its stationary point -- tests/test_gpu_all_configs.py)
   t.blind_tol_scale = m->bucket <= 8 ? 100.f : 10.f;
   t.pivot_rule = -1;
   t.longest_first = -1;

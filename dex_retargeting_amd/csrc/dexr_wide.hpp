@@ -1376,7 +1376,9 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         }
       smax = row_max(sl);
       pending = true;
-      if (okf && smax < kp.blind_tol && lam <= kp.lam0) {  // see dexr_quad.hpp: verified undamped model, tiny Newton step
+      // (see dexr_quad.hpp: verified undamped model, tiny Newton step; beyond 10 tol only on the quadratic tail of the
+      // iteration -- the step must be at most a tenth of the previous accepted one, as in the small-component kernel)
+      if (okf && smax < kp.blind_tol && lam <= kp.lam0 && (smax < 10.f * kp.tol || smax < 0.1f * sprev)) {
         ++my_iters;
         pending = false;
         done = true;

@@ -12,6 +12,7 @@ import numpy as np
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tools"))
 import torch  # noqa: E402
 
 from dex_retargeting_amd.constants import DEFAULT_URDF_DIR  # noqa: E402
@@ -40,6 +41,9 @@ for path in sorted(glob.glob(os.path.join(cases.CONFIG_DIR, "*", "*.yml"))):
         from dex_retargeting_amd import _lib
         model.tune(kernel={"register": _lib.KERNEL_REGISTER, "quad": _lib.KERNEL_QUAD, "lds": _lib.KERNEL_LDS,
                            "reduced": _lib.KERNEL_REDUCED, "wide": _lib.KERNEL_WIDE}[KERNEL])
+    if os.environ.get("DEXR_TOOL_KNOBS"):  # e.g. DEXR_TOOL_KNOBS="blind_tol_scale=100,step_cap=0.2": developer knobs (tools/_tune.py)
+        import _tune
+        _tune.apply(model, dict(kv.split("=") for kv in os.environ["DEXR_TOOL_KNOBS"].split(",")))
     dex = prob.kind == "dexpilot"
     mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
     st = (lambda: np.zeros(B, np.uint32)) if dex else (lambda: None)
