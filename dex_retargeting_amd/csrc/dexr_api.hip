@@ -992,6 +992,7 @@ int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning) {
   t.struct_size = (uint32_t)sizeof(dexr_tuning);
   if (t.kernel < DEXR_KERNEL_AUTO || t.kernel > DEXR_KERNEL_WIDE) return fail(DEXR_ERR_INVALID, "unknown kernel family %d", t.kernel);
   if (t.pivot_rule < -1 || t.pivot_rule > 1) return fail(DEXR_ERR_INVALID, "unknown pivot rule %d", t.pivot_rule);
+  if (t.chain < 0 || t.chain > 2) return fail(DEXR_ERR_INVALID, "chain must be 0 (never), 1 (serial-chain kernel + tip pass) or 2 (serial-chain kernel)");
   if (t.longest_first < -1 || t.longest_first > 1) return fail(DEXR_ERR_INVALID, "longest_first must be -1, 0 or 1");
   if (t.fork_streams < -1 || t.fork_streams > 1) return fail(DEXR_ERR_INVALID, "fork_streams must be -1, 0 or 1");
   if (t.persist_from < 0 || t.qchunk < 0 || t.persist_occ < 0 || t.resident_waves < 0 || t.max_blind < 0)

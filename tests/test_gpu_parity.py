@@ -1050,7 +1050,7 @@ def test_launches_on_two_streams_do_not_interfere(rel):
 def test_tuning_rejects_unknown_values():
     seq, _ = build("teleop/shadow_hand_right_dexpilot.yml")
     model = seq.optimizer.device_model()
-    for bad in (dict(kernel=7), dict(pivot_rule=3), dict(longest_first=2), dict(lam_jump=-1.0)):
+    for bad in (dict(kernel=7), dict(pivot_rule=3), dict(longest_first=2), dict(lam_jump=-1.0), dict(chain=3)):
         with pytest.raises(_lib.DexrError):
             model.tune(**bad)
     model.tune(kernel=_lib.KERNEL_AUTO)
