@@ -178,3 +178,40 @@ def test_unique_id_is_created_without_a_gpu_and_has_the_abi_size():
     assert len(a) == _lib.UNIQUE_ID_BYTES == 128 and a != b
     with pytest.raises(ValueError):
         _lib.Comm(b"short", 0, 1)
+
+
+def test_committed_bench_lines_follow_the_driver_contract():
+    """The JSON lines committed under profiles/ (copies of what `python bench.py` printed on the GPU box) carry every
+    field the driver parses, the roofline and cpu_baseline objects, and self-consistent numbers."""
+    import json
+
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(REPO, "profiles")
+    lines = {}
+    for name in ("r03_bench_default.json", "r03_bench_mixed_fleet.json", "r03_bench_1rank_native_rccl.json"):
+        with open(os.path.join(prof, name)) as f:
+            lines[name] = json.loads([ln for ln in f if ln.startswith("{")][-1])
+    base = json.load(open(os.path.join(REPO, "BASELINE.json")))
+    for name, d in lines.items():
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config"):
+            assert k in d, (name, k)
+        assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+        assert d["dtype"] == "f32" and "synthetic" in d["data"] and "workload" in d["config"]
+        assert d["unit"] == "frames/s"
+        if name != "r03_bench_mixed_fleet.json":
+            assert d["metric"] == base["metric"], (d["metric"], base["metric"])
+        r = d["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in r, (name, k)
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        assert 0 < r["frac"] < 1 and r["peak"] == 8000.0
+        # throughput and step time describe the same run
+        frames = d["config"].get("batch_per_gpu", d["config"].get("frames_per_gpu", None))
+        if frames:
+            assert abs(d["value"] - d["n_gpus"] * frames / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.02
+    c = lines["r03_bench_default.json"]["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    assert lines["r03_bench_1rank_native_rccl.json"]["config"].get("rccl_world_size") == 1
