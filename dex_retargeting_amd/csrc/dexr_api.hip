@@ -96,6 +96,7 @@ struct dexr_model {
   bool gen = false;       // generic table (dexr_tables.h): served by the general kernel (dexr_gen.hpp), every mode, float64
   dexr::GenTab gen_tab;   // device pointers into d_gen
   void* d_gen = nullptr;
+  float lam_fastdec_user = -1.f;  // >= 0: the caller overrode dexr_tuning.lam_fastdec (same rule as lam_jump below)
   float lam_jump_user = -1.f;  // >= 0: the caller overrode dexr_tuning.lam_jump; otherwise every launch uses the default
                                // of the kernel family it actually dispatches (family_lam_jump)
   mutable dexr::HostCtx host;  // private stream + persistent pinned / device staging of the host-pointer entry points
@@ -119,6 +120,20 @@ float family_lam_jump(const dexr_model* m, Family fam) {
   if (fam == FAM_QUAD || (fam == FAM_WIDE && !m->wide_modchol)) return 1.0f;
   return m->bucket <= 8 ? 3.0f : 0.3f;
 }
+// Default of dexr_tuning.lam_fastdec (lambda x this after a step the model predicted to 90 %, instead of x 1/3) per family.
+// After a rejection lambda jumps to the curvature scale; at 1/3 per accepted step the sixteen-lane kernel then spent ~10
+// over-damped passes coming back.  Measured on it (65 536 frames, tools/all_configs.py with DEXR_TOOL_KNOBS=lam_fastdec=...):
+// 0.1 for joint-space models, for the first 6 rejections of a solve (KernelParams::fastdec_max_rej: unbounded it is 5-11 %
+// faster still, but a handful of LEAP DexPilot frames then cycle until max_iter) -- same box, Shadow + free joints -7 %,
+// LEAP DexPilot -7 %, LEAP / Allegro position -3 %, Shadow vector -4 %, Shadow DexPilot -0.5 %, Allegro DexPilot +4 %;
+// models with mimic joints lose 2-6 % with it (Inspire) and keep the 1/3 rule.  The other large-component kernels
+// (float64 validation / polish launches run the register kernel) keep 0: with 0.1 a Shadow DexPilot frame of
+// tests/test_gpu_parity.py::test_solve_matches_oracle_tracking stops 0.02 rad short of its minimum.
+float family_lam_fastdec(const dexr_model* m, Family fam) {
+  if (m->lam_fastdec_user >= 0.f) return m->lam_fastdec_user;
+  if (fam == FAM_WIDE && !m->has_mimic) return 0.1f;
+  return m->bucket <= 8 ? 0.1f : 0.f;
+}
 Family selected_family(const dexr_model* m) {
   return m->red ? FAM_RED : m->wide ? FAM_WIDE : m->quad ? FAM_QUAD : m->big ? FAM_BIG : FAM_REGISTER;
 }
@@ -133,8 +148,10 @@ void fill_params(const dexr_model* m, dexr::KernelParams& kp, int64_t B) {
   // curvature instead of creeping up by x2, x4, ...; small components also drop it by 10x (not 3x) after a step the
   // model predicted well.  Allegro vector, 65 536 frames: 0.143 -> 0.119 ms; Shadow DexPilot: 19.4 -> 15.4 ms.
   kp.lam_jump = family_lam_jump(m, FAM_REGISTER);  // launch() sets the dispatched family's value
-  kp.lam_fastdec = m->tune.lam_fastdec;
+  kp.lam_fastdec = family_lam_fastdec(m, FAM_REGISTER);  // (likewise)
   kp.lam_recover = m->tune.lam_recover;
+  kp.fastdec_max_rej = 6;  // (3 / 6 / 12 / unbounded compared in one box: 6 is the largest bound under which every frame of
+                           // the 39 configs still converges within max_iter; profiles/r03_wide_ab_fastdec_same_box.txt)
   kp.floor_scale = m->tune.floor_scale;
   kp.step_cap = m->tune.step_cap;
   kp.blind_tol = 0.f;  // set from the tolerance in apply_options
@@ -470,6 +487,7 @@ int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStr
   if (mode == dexr::MODE_SOLVE && !f64 && selected_family(m) != FAM_REGISTER) {
     const Family fam = selected_family(m);
     kp.lam_jump = family_lam_jump(m, fam);
+    kp.lam_fastdec = family_lam_fastdec(m, fam);
     return fam == FAM_RED ? launch_red(m, kp, st) : fam == FAM_WIDE ? launch_wide(m, kp, st)
          : fam == FAM_QUAD ? launch_quad(m, kp, st) : launch_big(m, kp, st);
   }
@@ -556,7 +574,7 @@ void default_tuning(dexr_model* m) {
   t.stall_ratio = 0.9f;
   t.stall_cap = 20.f;
   t.lam_jump = m->bucket <= 8 ? 3.0f : 0.3f;
-  t.lam_fastdec = m->bucket <= 8 ? 0.1f : 0.f;
+  t.lam_fastdec = m->bucket <= 8 ? 0.1f : 0.f;  // (the sixteen-lane kernel has its own default: family_lam_fastdec)
   t.lam_recover = 0.f;
   t.floor_scale = 1e-12f;
   t.step_cap = 0.3f;
@@ -926,6 +944,7 @@ int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out) {
   m->wide_ok = build_wide_tables(m);
   select_kernels(m);
   m->tune.lam_jump = family_lam_jump(m, selected_family(m));  // reported value; launches derive it per family
+  m->tune.lam_fastdec = family_lam_fastdec(m, selected_family(m));
   if (m->bucket < 0) {
     delete m;
     return fail(DEXR_ERR_UNSUPPORTED, "component with %d joints exceeds the largest kernel bucket", maxj);
@@ -1003,10 +1022,13 @@ int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning) {
   // otherwise each launch keeps using the default of the family it dispatches (which select_kernels may change now)
   if (tuning->struct_size >= offsetof(dexr_tuning, lam_jump) + sizeof(float) && t.lam_jump != m->tune.lam_jump)
     m->lam_jump_user = t.lam_jump;
+  if (tuning->struct_size >= offsetof(dexr_tuning, lam_fastdec) + sizeof(float) && t.lam_fastdec != m->tune.lam_fastdec)
+    m->lam_fastdec_user = t.lam_fastdec;
   m->tune = t;
   if (m->gen) return DEXR_OK;  // one kernel serves a generic model
   select_kernels(m);
   m->tune.lam_jump = family_lam_jump(m, selected_family(m));
+  m->tune.lam_fastdec = family_lam_fastdec(m, selected_family(m));
   return DEXR_OK;
 }
 

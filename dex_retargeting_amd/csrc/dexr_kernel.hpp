@@ -58,6 +58,7 @@ struct KernelParams {
   float step_cap;                 // trust radius: a step whose largest component exceeds it is scaled down to it (0: off)
   float lam_jump;                 // on a rejected step lambda becomes at least lam_jump x mean diag(H) (0: plain x nu)
   float lam_fastdec;              // on an accepted step with rho > 0.9 lambda shrinks by this factor (0: Nielsen's 1/3)
+  int32_t fastdec_max_rej;        // sixteen-lane kernel: ... only while the solve has had at most this many rejections
   float lam_recover;              // ... and by this factor while lambda is still above 10 lam0, i.e. while the damping
                                   // that a rejection raised is being taken back (0: lam_fastdec there too)
   float floor_scale;              // mixed-precision kernels: value differences below floor_scale x |F| are unverifiable

@@ -1145,7 +1145,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   float lam = kp.lam0, nu = 2.f, sprev = 1e30f, keff = 0.f;
   WDIAG(int d_nrej = 0; int d_ncap = 0; int d_nfail = 0;)
   bool done = true, pending = false;
-  int status = ST_MAXITER, my_iters = 0, blind = 0;
+  int status = ST_MAXITER, my_iters = 0, blind = 0, nrej = 0;  // nrej: rejections of this solve (bounds the fast damping decay)
   double F = 0;
   float smax = 0, pred = 0;
   bool ok = true;
@@ -1160,6 +1160,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     nu = 2.f;
     sprev = 1e30f;
     keff = 0.f;
+    nrej = 0;
     WDIAG(d_nrej = 0; d_ncap = 0; d_nfail = 0;)
     status = ST_MAXITER;
     my_iters = 0;
@@ -1244,7 +1245,9 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
           const float rho = (float)((F - Fe) / fmax((double)pred, 1e-30));
           const float tt = 2.f * rho - 1.f;
           float shrink = below_floor ? (1.f / 3.f) : fmaxf(1.f / 3.f, 1.f - tt * tt * tt);
-          if (kp.lam_fastdec > 0 && rho > 0.9f) shrink = kp.lam_fastdec;
+          // (fast decay: the quick way back after a damping jump -- but only for the first few rejections of a solve: a frame
+          // that keeps being rejected is cycling between a too small and a too large lambda, and the 1/3 rule damps that)
+          if (kp.lam_fastdec > 0 && rho > 0.9f && nrej <= kp.fastdec_max_rej) shrink = kp.lam_fastdec;
           lam = fmaxf(lam * shrink, 1e-9f);
           nu = 2.f;
           F = Fe;
@@ -1261,6 +1264,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
           }
         } else {
           WDIAG(++d_nrej; if (!ok) ++d_nfail;)
+          ++nrej;
           lam = fmaxf(lam, 1e-6f) * nu;
           if (kp.lam_jump > 0) lam = fmaxf(lam, kp.lam_jump * (MODCHOL ? hdmean : keff));
           nu *= 2.f;
@@ -1336,6 +1340,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         keff = gd / fmaxf(dd, 1e-30f);
         ++my_iters;
         WDIAG(++d_nrej; ++d_nfail;)
+        ++nrej;
         lam = fmaxf(lam, 1e-6f) * nu;
         if (kp.lam_jump > 0) lam = fmaxf(lam, kp.lam_jump * keff);
         nu *= 2.f;

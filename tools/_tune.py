@@ -6,7 +6,7 @@ names."""
 from dex_retargeting_amd import _lib
 
 _TUNE = {"persist_from": int, "persist_occ": int, "qchunk": int, "resident_waves": int, "max_blind": int,
-         "stall_from": int, "stall_ratio": float, "stall_cap": float, "lam_jump": float, "lam_fastdec": float,
+         "stall_from": int, "stall_ratio": float, "stall_cap": float, "lam_jump": float, "lam_fastdec": float, "lam_recover": float,
          "floor_scale": float, "step_cap": float, "blind_tol_scale": float, "chain": int, "pivot_rule": int, "longest_first": int}
 _KERNEL = {"auto": _lib.KERNEL_AUTO, "register": _lib.KERNEL_REGISTER, "quad": _lib.KERNEL_QUAD, "lds": _lib.KERNEL_LDS,
            "reduced": _lib.KERNEL_REDUCED, "wide": _lib.KERNEL_WIDE}
