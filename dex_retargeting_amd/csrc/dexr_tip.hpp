@@ -3,9 +3,9 @@
 // A tip component is what every finger of the per-finger vector models is (teleop Allegro / LEAP, BASELINE.json
 // configs[0] and [1], the headline): an unbranched chain of four revolute optimised joints hanging off the base and ONE
 // residual term -- the vector from a frame on the fixed base to a frame on the last joint (VectorOptimizer with one
-// (origin, task) pair per finger, /root/reference/src/dex_retargeting/optimizer.py:203-306).  The generic pass walks that structure through tables: per joint a scalar load of the placement + wait, a rolled
-// loop over the frames attached to it, frame positions through LDS, a rolled term loop with three dependent scalar loads,
-// ancestor masks tested bit by bit.  Measured (tools/prof_small_stages.sh, s_memtime): ~6 000 cycles per pass for a lone
+// (origin, task) pair per finger, /root/reference/src/dex_retargeting/optimizer.py:203-306).  The generic pass walks that
+// structure through tables: per joint a scalar load of the placement + wait, a rolled loop over the frames attached to it,
+// frame positions through LDS, a rolled term loop with three dependent scalar loads, ancestor masks tested bit by bit.  Measured (tools/prof_small_stages.sh, s_memtime): ~6 000 cycles per pass for a lone
 // wave at ~550 VALU instructions -- the launch of 65 536 frames is bound by the slowest frame's passes at that latency
 // (4 096 frames: 0.044 ms, 65 536: 0.063 ms).  Here the pass is ONE basic block:
 //   * the constants of the component pinned in SGPRs for the whole kernel (the compiler cannot turn them back into loads) or
@@ -97,7 +97,7 @@ static __device__ __forceinline__ void tip_sincos2(kv2 a, kv2* s, kv2* c) {
   const kv2 cp = (tip_splat(1.0f) - z * 0.5f) +
                  (z * z) * (tip_splat(4.1666666076e-02f) +
                             z * (tip_splat(-1.3888812242e-03f) + z * (tip_splat(2.4786036849e-05f) + z * -2.6544504746e-07f)));
-  const int sx = (int)kf.x << 31, sy = (int)kf.y << 31;
+  const int sx = (int)((unsigned)(int)kf.x << 31), sy = (int)((unsigned)(int)kf.y << 31);  // parity of k -> sign bit
   *s = kv2{__int_as_float(__float_as_int(sp.x) ^ sx), __int_as_float(__float_as_int(sp.y) ^ sy)};
   *c = kv2{__int_as_float(__float_as_int(cp.x) ^ sx), __int_as_float(__float_as_int(cp.y) ^ sy)};
 }
