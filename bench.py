@@ -184,6 +184,7 @@ class Workload:
             step()
         if pipe is not None:
             pipe.finish()
+        n[0] = 0  # the timed steps start a fresh group of a k-step gather (the batches keep rotating)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         if comm is not None:
             comm.barrier(self.stream.cuda_stream)
@@ -296,18 +297,28 @@ class Workload:
         # the summary, committed under profiles/): 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction per
         # MI355X_MICROARCH.md.  Only attached to the line it was measured for (same batch, f32, keypoint input).
         pmc_path = os.path.join(REPO, "profiles", f"pmc_{self.name}.json")
+        pmc_note = None
         if os.path.exists(pmc_path) and precision == "f32" and batch_kind == "kp" and world == 1:
+            from dex_retargeting_amd._build import source_hash
+
             pmc = json.load(open(pmc_path))
-            if pmc.get("batch") == self.B:
+            if pmc.get("batch") != self.B:
+                pmc_note = "committed PMC summary is for another batch size"
+            elif pmc.get("source_sha16") != source_hash(self.name):
+                pmc_note = "committed PMC summary was taken on other kernel sources (source_sha16 mismatch): counters withheld"
+            else:
                 traffic = pmc.get("hbm_bytes_per_launch")
-                if "SQ_INSTS_VALU" in pmc:  # wave64 VALU instruction = 4 issue cycles on a 16-lane SIMD; 1024 SIMDs, 2.4 GHz
-                    valu_frac = pmc["SQ_INSTS_VALU"] * 4.0 / (1024 * kernel_ms * 1e-3 * 2.4e9)
+                if "SQ_INSTS_VALU" in pmc:
+                    # a wave64 VALU instruction issues over 2 cycles on a SIMD-32 (MI355X_MICROARCH.md, "Wave scheduling":
+                    # 32 lanes/cycle x 2; 157.3 TF = 64 FLOP/clk/SIMD); 1024 SIMDs at 2.4 GHz.  A lower bound on the busy
+                    # share: packed-f32 and f64 instructions take 4 (round 3 charged 4 to every instruction: 2x too high)
+                    valu_frac = pmc["SQ_INSTS_VALU"] * 2.0 / (1024 * kernel_ms * 1e-3 * 2.4e9)
         fam, bucket, chain = self.model.kernel()
         kname = KERNEL_NAMES[fam] + f", bucket {bucket}" + (", serial-chain specialisation" + (" with the tip pass" if chain == 2 else "") if chain else "")
         if precision == "f64":
             kname = f"dexr_kernel<{bucket}, double> (register kernel, float64 arithmetic)"
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic, "valu_issue_frac": valu_frac,
+                "traffic": traffic, "valu_issue_frac": valu_frac, "pmc_note": pmc_note,
                 "valu": {"achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf,
                          "algorithmic_flops_per_frame": flops_frame},
                 "kernel": kname, "kernel_ms": kernel_ms, "algorithmic_bytes_per_frame": bpf}
@@ -536,43 +547,121 @@ def job_env(args):
     return rank, local_rank, world, os.environ.get("RANK") is not None
 
 
-def gather_records(timed_fn, comm, B, n_cols, dev, steps, warmup, world, graph_fn=None):
+class Watchdog:
+    """Deadline for the optional N > 1 measurements.  A collective that misbehaves across ranks (a graph capture RCCL does
+    not support, a rank that died) HANGS rather than raises; the headline has been measured by then.  Every rank arms the
+    same deadlines at the same points; when one passes, rank 0 prints the line it already has (plus what timed out) and
+    every rank leaves with os._exit, so the launcher sees a finished job instead of its own timeout."""
+
+    def __init__(self, rank, seconds):
+        import threading
+
+        self.rank, self.seconds, self.line, self.stage, self.deadline = rank, seconds, None, None, None
+        self.done = {}
+        self._lock = threading.Lock()
+        t = threading.Thread(target=self._run, daemon=True)
+        t.start()
+
+    def arm(self, stage):
+        with self._lock:
+            self.stage, self.deadline = stage, time.time() + self.seconds
+
+    def disarm(self):
+        with self._lock:
+            self.stage, self.deadline = None, None
+
+    def _run(self):
+        while True:
+            time.sleep(0.25)
+            with self._lock:
+                late = self.deadline is not None and time.time() > self.deadline
+                stage = self.stage
+            if late:
+                if self.rank == 0 and self.line is not None:
+                    line = dict(self.line)
+                    line["multi_gpu"] = dict(self.done, watchdog=f"'{stage}' did not finish within {self.seconds:g} s; the "
+                                                                 f"figures measured before it are reported, the job was ended")
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+
+
+def rccl_env():
+    """What the RCCL tuner was told (nothing = its own choice per message size; SURVEY.md section 8e asks for it to be
+    stated).  bench.py --nccl-algo / --nccl-proto set these before the communicator exists."""
+    keys = ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "NCCL_P2P_LEVEL", "RCCL_MSCCL_ENABLE",
+            "RCCL_MSCCLPP_ENABLE", "HSA_ENABLE_IPC_MODE_LEGACY")
+    return {k: os.environ.get(k, "unset (RCCL default)") for k in keys}
+
+
+def gather_records(timed_fn, comm, B, n_cols, dev, steps, warmup, world, graph_fn=None, rank=0, on_headline=None,
+                   strong_fn=None):
     """The N > 1 figures (also taken with ONE rank when launched by torch.distributed.run, so that the RCCL side runs on a
-    1-GPU box): one dexr_allgather per step.  Returns (elapsed, kernel_ms, record dict).
+    1-GPU box): dexr_allgather of the (B, n_cols) f32 result rows.  Returns
+    (elapsed, kernel_ms, record dict).
 
-    headline  = the collective on a second HIP stream, ordered after the solve by an event: the next step's solve
-                overlaps it; every gather has completed when the timed region ends;
-    secondary = the collective on the solve stream itself (strictly serial: what one captured graph of
-                [solve, all-gather] per step does)."""
-    from dex_retargeting_amd.distributed import NativeGather
+    headline       = one collective per step on a second HIP stream, ordered after the solve by an event: the next step's
+                     solve overlaps it; every gather has completed when the timed region ends;
+    no_gather      = the same steps, same barrier bracket, no collective (SURVEY 8e: "with and without the all-gather");
+    on solve stream= the collective on the solve stream itself (strictly serial);
+    every k steps  = ONE collective per k steps (k from distributed.steps_per_gather_for: the gathers must keep up with the
+                     solves at <= 60 % of the xGMI ingest), on the second stream;
+    graph replay   = [solve -> all-gather] x 4 captured into one HIP graph;
+    strong scaling = the metric's 65 536 frames over the whole node (B / N per GPU) with the per-step gather.
+    Everything after the headline runs under a watchdog."""
+    from dex_retargeting_amd.distributed import NativeGather, steps_per_gather_for
 
+    wd = Watchdog(rank, float(os.environ.get("DEXR_BENCH_WATCHDOG_S", "120")))
     depth = min(8, steps + warmup + 1)
     elapsed, kernel_ms = timed_fn(NativeGather(comm, B, n_cols, dev, depth=depth, overlap=True))
-    e2, _ = timed_fn(NativeGather(comm, B, n_cols, dev, depth=depth, overlap=False))
     shard_mb = B * n_cols * 4 / 1e6
-    graph = None
-    if graph_fn is not None and world > 1:
-        # verified with one rank only (all a 1-GPU box holds); a capture that misbehaves across ranks would hang the whole
-        # job rather than raise, so multi-rank runs do not attempt it
-        graph = {"skipped": "graph replay of [solve -> all-gather] is measured with one rank only"}
-    elif graph_fn is not None:
+    rec = wd.done
+    rec.update({
+        "collective": "dexr_allgather (C-ABI of libdexr.so -> RCCL ncclAllGather, bound with dlopen), one per step, "
+                      "enqueued on a second HIP stream behind an event recorded after the solve; all gathers "
+                      "complete inside the timed region",
+        "rccl_world_size": world, "rccl_version": comm.rccl_version(), "rccl_env": rccl_env(),
+        "xgmi": {"shard_MB_per_rank_per_step": shard_mb, "received_MB_per_gpu_per_step": shard_mb * (world - 1),
+                 "note": "every GPU receives (N-1) shards per step over its 7 xGMI links (~76.8 GB/s per link and "
+                         "direction, 537 GB/s aggregate ingest at best): the all-gather lower bound per step is "
+                         f"{shard_mb * (world - 1) / 537.0 * 1e3:.1f} us at N={world} if all links carry it, "
+                         f"{shard_mb * (world - 1) / 76.8 * 1e3:.1f} us on a single ring direction"}})
+    if on_headline is not None:
+        wd.line = on_headline(elapsed, kernel_ms)
+
+    def fig(e, note, frames=None):
+        return {"value": (world * B if frames is None else frames) * steps / e, "unit": "frames/s", "ms_per_step": e / steps * 1e3, "note": note}
+
+    wd.arm("no_gather")
+    e0, _ = timed_fn(None)
+    rec["no_gather"] = fig(e0, "same steps and barrier bracket with NO collective: what the shards alone sustain")
+    wd.arm("gather_on_solve_stream")
+    e2, _ = timed_fn(NativeGather(comm, B, n_cols, dev, depth=depth, overlap=False))
+    rec["gather_on_solve_stream"] = fig(e2, "same steps with the all-gather enqueued on the solve stream (serial)")
+    # e0 is the maximum over ranks (comm.max_f64): every rank derives the same k
+    k = steps_per_gather_for(e0 / steps * 1e3, B * n_cols * 4, world)
+    if world == 1:
+        k = 4  # one rank: nothing to hide, but the code path is exercised and timed
+    while steps % k:
+        k -= 1  # whole groups inside the timed region
+    wd.arm("gather_every_k_steps")
+    ek, _ = timed_fn(NativeGather(comm, B, n_cols, dev, depth=2, overlap=True, steps_per_gather=k))
+    rec["gather_every_k_steps"] = dict(fig(ek, f"ONE all-gather per {k} steps ({k} x {shard_mb:.2f} MB per rank) on the second "
+                                               f"stream: same bytes, 1/{k} of the collectives; results reach the other ranks up "
+                                               f"to {k - 1} steps later"), k=k,
+                                       policy="smallest k for which a gather at 60 % of 537 GB/s ingest + 30 us of collective "
+                                              "overhead fits into k solve steps (distributed.steps_per_gather_for); 16 when one "
+                                              "step's wire time already exceeds the step")
+    if strong_fn is not None and world > 1:
+        wd.arm("strong_scaling")
+        rec["strong_scaling"] = strong_fn()
+    if graph_fn is not None:
+        wd.arm("graph_replay")
         try:
-            graph = graph_fn()
+            rec["graph_replay"] = graph_fn()
         except Exception as e:  # capture support varies with the RCCL build: never lose the line to it
-            graph = {"error": repr(e)}
-    rec = {"collective": "dexr_allgather (C-ABI of libdexr.so -> RCCL ncclAllGather, bound with dlopen), one per step, "
-                         "enqueued on a second HIP stream behind an event recorded after the solve; all gathers "
-                         "complete inside the timed region",
-           "rccl_world_size": world, "rccl_version": comm.rccl_version(),
-           "gather_on_solve_stream": {"value": world * B * steps / e2, "unit": "frames/s", "ms_per_step": e2 / steps * 1e3,
-                                      "note": "same steps with the all-gather enqueued on the solve stream (serial)"},
-           "graph_replay": graph,
-           "xgmi": {"shard_MB_per_rank_per_step": shard_mb, "received_MB_per_gpu_per_step": shard_mb * (world - 1),
-                    "note": "every GPU receives (N-1) shards per step over its 7 xGMI links (~76.8 GB/s per link and "
-                            "direction, 537 GB/s aggregate ingest at best): the all-gather lower bound per step is "
-                            f"{shard_mb * (world - 1) / 537.0 * 1e3:.1f} us at N={world} if all links carry it, "
-                            f"{shard_mb * (world - 1) / 76.8 * 1e3:.1f} us on a single ring direction"}}
-    return elapsed, kernel_ms, rec
+            rec["graph_replay"] = {"error": repr(e)}
+    wd.disarm()
+    return elapsed, kernel_ms, dict(rec)
 
 
 def run_single(args):
@@ -596,16 +685,54 @@ def run_single(args):
     diag = wl.diagnostics(wl.tracking)
 
     # ---- headline: float32 tracking -----------------------------------------------------------------------------
+    def contract_line(elapsed, kernel_ms, coll=None):
+        frames = world * B * args.steps
+        return {
+            "metric": json.load(open(os.path.join(REPO, "BASELINE.json")))["metric"],
+            "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{wl.title}, {B} frames/GPU, human-keypoint refs (fixture frame b mod 621 + 2 mm noise), "
+                                   f"warm start = previous frame's solution; {N_BATCHES} staged batches rotated over the steps",
+                       "config_file": wl.rel, "batch_per_gpu": B, "n_opt": wl.n_opt, "n_ref": wl.n_ref,
+                       "collective": "none" if comm is None else "dexr_allgather (RCCL ncclAllGather), one per step, second stream",
+                       "rccl_world_size": None if comm is None else world},
+            "solver": dict(diag, tol_rad=2e-6, newton=1),
+            "roofline": dict(wl.roofline(kernel_ms, diag["iters_mean"], world=world),
+                             traffic_note="bytes per launch from the rocprofv3 --pmc passes in profiles/ (same command, same "
+                                          "batch, same kernel sources); null when no matching profile is committed",
+                             note="path is FP32 VALU/latency bound (n_dof <= 24 per lane, no dense contraction); the HBM "
+                                  "fraction is reported as north_star asks, see DESIGN.md section 4"),
+        }
+
+    def strong_scaling():
+        """The metric read as STRONG scaling: its 65 536 frames over the whole node, B / N frames per GPU, per-step gather
+        on the second stream (each GPU then holds a fraction of a wave per SIMD: the step sits on the launch-latency floor
+        of profiles/r03_small_latency_tip.txt, and the all-gather moves 1 / N as much)."""
+        from dex_retargeting_amd.distributed import NativeGather
+
+        Bs = max(64, B // world)
+        ws = Workload(args.workload, rank, Bs, dev, torch)
+        es, ks = ws.timed(ws.tracking, args.steps, args.warmup, comm=comm,
+                          pipe=NativeGather(comm, Bs, ws.n_opt, dev, depth=min(8, args.steps + args.warmup + 1), overlap=True))
+        e0s, _ = ws.timed(ws.tracking, args.steps, args.warmup, comm=comm)
+        return {"total_frames_per_step": world * Bs, "frames_per_gpu": Bs, "value": world * Bs * args.steps / es,
+                "unit": "frames/s", "ms_per_step": es / args.steps * 1e3, "solve_kernel_ms": ks,
+                "no_gather": {"value": world * Bs * args.steps / e0s, "ms_per_step": e0s / args.steps * 1e3},
+                "scaling": "strong", "note": f"{world * Bs} frames per step over {world} GPUs"}
+
     coll = None
     if comm is not None:
         elapsed, kernel_ms, coll = gather_records(
             lambda pipe: wl.timed(wl.tracking, args.steps, args.warmup, pipe=pipe, comm=comm),
-            comm, B, wl.n_opt, dev, args.steps, args.warmup, world,
-            graph_fn=lambda: wl.timed_graph(wl.tracking, args.steps, comm))
+            comm, B, wl.n_opt, dev, args.steps, args.warmup, world, rank=rank,
+            graph_fn=lambda: wl.timed_graph(wl.tracking, args.steps, comm),
+            on_headline=(lambda e, k: contract_line(e, k)) if rank == 0 else None,
+            strong_fn=strong_scaling)
     else:
         elapsed, kernel_ms = wl.timed(wl.tracking, args.steps, args.warmup)
     # per-step answers of the last timed step's batch for the parity check
-    last_batch = wl.tracking[(args.steps + args.warmup - 1) % N_BATCHES]
+    last_batch = wl.tracking[(args.steps - 1) % N_BATCHES]
     wl.launch(last_batch, wl.t_q)
     torch.cuda.synchronize()
     q_head = wl.t_q.cpu().numpy()
@@ -663,7 +790,7 @@ def run_single(args):
                 ts2 = w2.timed_two_streams(w2.tracking, args.steps, args.warmup)
             except Exception as e:
                 ts2 = {"error": repr(e)}
-            b2 = w2.tracking[(args.steps + args.warmup - 1) % N_BATCHES]
+            b2 = w2.tracking[(args.steps - 1) % N_BATCHES]
             w2.launch(b2, w2.t_q)
             torch.cuda.synchronize()
             also[name] = (w2, b2, w2.t_q.cpu().numpy(),
@@ -675,24 +802,7 @@ def run_single(args):
         comm.close()
         return
 
-    frames = world * B * args.steps
-    out = {
-        "metric": json.load(open(os.path.join(REPO, "BASELINE.json")))["metric"],
-        "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{wl.title}, {B} frames/GPU, human-keypoint refs (fixture frame b mod 621 + 2 mm noise), "
-                               f"warm start = previous frame's solution; {N_BATCHES} staged batches rotated over the steps",
-                   "config_file": wl.rel, "batch_per_gpu": B, "n_opt": wl.n_opt, "n_ref": wl.n_ref,
-                   "collective": "none" if coll is None else coll["collective"],
-                   "rccl_world_size": None if coll is None else coll["rccl_world_size"]},
-        "solver": dict(diag, tol_rad=2e-6, newton=1),
-        "roofline": dict(wl.roofline(kernel_ms, diag["iters_mean"], world=world),
-                         traffic_note="bytes per launch from the rocprofv3 --pmc passes in profiles/ (same command, same "
-                                      "batch); null when no matching profile is committed",
-                         note="path is FP32 VALU/latency bound (n_dof <= 24 per lane, no dense contraction); the HBM "
-                              "fraction is reported as north_star asks, see DESIGN.md section 4"),
-    }
+    out = contract_line(elapsed, kernel_ms)
     if coll is not None:
         out["multi_gpu"] = coll
     out.update(sub)
@@ -768,14 +878,15 @@ def run_single(args):
         if procs > 1:
             from oracle import cases, cpu_worker
 
-            per_proc = max(8, int(out["cpu_baseline"]["value"] * 6.0))  # ~6 s of work per process
+            per_proc = max(8, int(out["cpu_baseline"]["value"] * 4.0))  # ~4 s of work per process
             full_ref = cases.ref_from_keypoints(prob, last_batch["host_in"]).astype(np.float32)
             res = cpu_worker.run_all_cores(wl.rel, full_ref, last_batch["host_last"], procs, per_proc)
             if res is not None:
                 out["cpu_baseline_all_cores"] = {
-                    "value": res[0] / res[1], "unit": "frames/s", "cores": procs, "kind": "port",
-                    "sample": f"first {res[0]} frames, {procs} processes x {per_proc} frames started together, same "
-                              f"solver as cpu_baseline; {avail} CPUs available to the process"}
+                    "value": res[0] / res[1], "unit": "frames/s", "cores": res[2], "kind": "port",
+                    "sample": f"{res[0]} frames = {res[2]} processes x {per_proc} frames of the same workload (frame i mod "
+                              f"{B} once the batch is exhausted), started together, same solver as cpu_baseline; "
+                              f"{avail} CPUs available to the process"}
     print(json.dumps(out))
     if comm is not None:
         comm.close()
@@ -830,9 +941,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every host-CPU solve (baseline and SLSQP distance)")
     ap.add_argument("--headline-only", action="store_true", help="skip the f64 / cold-start / other-config sub-records")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="frames of the workload timed on the host CPU")
+    ap.add_argument("--nccl-algo", default=None, help="sets NCCL_ALGO before the RCCL communicator exists (e.g. Ring, Tree, Direct)")
+    ap.add_argument("--nccl-proto", default=None, help="sets NCCL_PROTO (e.g. Simple, LL, LL128)")
     ap.add_argument("--dry-run-launch", action="store_true",
                     help="launch + rendezvous plumbing only (no GPU work): used by the CPU tests of the N > 1 launcher")
     args = ap.parse_args()
+    if args.nccl_algo:
+        os.environ["NCCL_ALGO"] = args.nccl_algo
+    if args.nccl_proto:
+        os.environ["NCCL_PROTO"] = args.nccl_proto
     if args.gpus > 1 and os.environ.get("RANK") is None:
         return relaunch(args)  # does not return
     if args.dry_run_launch:

@@ -82,6 +82,7 @@ def run(args):
             step()
         if pipe is not None:
             pipe.finish()
+        n[0] = 0
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         if comm is not None:
             comm.barrier(stream.cuda_stream)
@@ -103,7 +104,7 @@ def run(args):
 
     coll = None
     if comm is not None:
-        elapsed, step_ms, coll = gather_records(timed, comm, B, fleet.n_max, dev, args.steps, args.warmup, world)
+        elapsed, step_ms, coll = gather_records(timed, comm, B, fleet.n_max, dev, args.steps, args.warmup, world, rank=rank)
     else:
         elapsed, step_ms = timed(None)
     if rank != 0:

@@ -34,6 +34,30 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", 
 NO_SLP = ["-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-fgpu-flush-denormals-to-zero"]
 
 
+# Which sources decide the code a bench workload's dominant kernel runs (used to key the committed rocprofv3 PMC
+# summaries, profiles/pmc_<workload>.json: bench.py attaches their counters to a line only while this hash is unchanged).
+_COMMON_SOURCES = ["dexr_api.hip", "dexr_launch.hpp", "../../include/dexr.h", "../../include/dexr_tables.h"]
+KERNEL_SOURCES = {
+    "allegro_vector": ["dexr_kernel.hpp", "dexr_tip.hpp", "dexr_inst.hip"],
+    "shadow_dexpilot": ["dexr_wide.hpp", "dexr_wide_inst.hip", "dexr_big.hpp"],
+    "leap_position": ["dexr_wide.hpp", "dexr_wide_inst.hip", "dexr_big.hpp"],
+}
+
+
+def source_hash(workload: str) -> str:
+    """sha256[:16] over the sources (names + contents) and compiler flags that produce `workload`'s dominant kernel."""
+    import hashlib
+
+    names = sorted(set(KERNEL_SOURCES.get(workload) or [f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]) | set(_COMMON_SOURCES))
+    h = hashlib.sha256()
+    for n in names:
+        h.update(os.path.basename(n).encode())
+        with open(os.path.normpath(os.path.join(CSRC, n)), "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS[:4] + NO_SLP).encode())
+    return h.hexdigest()[:16]
+
+
 def _hipcc() -> str:
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):

@@ -188,10 +188,30 @@ def exchange_bytes(store, rank: int, key: str, make) -> bytes:
     return bytes(store.get(key))
 
 
-def native_comm(rank: int, world: int, store=None, key: str = "dexr/unique_id"):
-    """An RCCL communicator over all ranks, bound to the CURRENT HIP device (call torch.cuda.set_device first)."""
+_comm_generation = [0]
+
+
+def comm_key(base: str = "dexr/unique_id") -> str:
+    """Store key of the NEXT communicator this process creates: `base`/r<restart>/c<count>.  Every rank of a job creates
+    its communicators in the same order, so the count agrees across ranks without another exchange; the elastic restart
+    count (TORCHELASTIC_RESTART_COUNT) separates attempts.  A fixed key would hand the id of an earlier communicator --
+    or of the attempt before a restart -- to the non-zero ranks the moment they ask (the agent's store outlives both),
+    and ncclCommInitRank then hangs on mismatched ids."""
+    import os
+
+    k = f"{base}/r{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}/c{_comm_generation[0]}"
+    _comm_generation[0] += 1
+    return k
+
+
+def native_comm(rank: int, world: int, store=None, key: str = None):
+    """An RCCL communicator over all ranks, bound to the CURRENT HIP device (call torch.cuda.set_device first).  `key`
+    (optional) names the store entry the unique id travels under; by default every communicator gets its own
+    (:func:`comm_key`)."""
     from . import _lib
 
+    if key is None:
+        key = comm_key()
     if world == 1:
         return _lib.Comm(_lib.comm_unique_id(), 0, 1)
     if store is None:
@@ -201,40 +221,67 @@ def native_comm(rank: int, world: int, store=None, key: str = "dexr/unique_id"):
 
 
 class NativeGather:
-    """Per-step all-gather of this rank's (per, n) float32 result rows through ``dexr_allgather``.
+    """All-gather of this rank's (per, n) float32 result rows through ``dexr_allgather``, one collective per
+    ``steps_per_gather`` steps.
 
-    ``depth`` (shard, full) buffer pairs rotate.  Per step k::
+    ``depth`` (shard, full) buffer pairs rotate; a pair holds ``steps_per_gather`` = G consecutive steps.  Per step k::
 
-        out = ng.shard(k)    # this rank's rows of step k; the solve stream first waits for the gather that last read
-                             # this pair (an event, no host wait)
+        out = ng.shard(k)    # this rank's rows of step k; when step k opens a buffer pair the solve stream first waits
+                             # for the gather that last read that pair (an event, no host wait)
         ... enqueue the solve that writes `out` on the current stream ...
-        ng.gather(k)         # overlap=True: the collective runs on a second stream ordered after the solve by an event, so
-                             # the next step's solve overlaps it;  overlap=False: on the solve stream itself (strictly
-                             # serial, what a single captured hipGraph of [solve, all-gather] does)
+        ng.gather(k)         # after the G-th step of a group: ONE collective of G shards.
+                             # overlap=True: it runs on a second stream ordered after the solve by an event, so the
+                             # following solves overlap it;  overlap=False: on the solve stream itself (strictly serial,
+                             # what a single captured hipGraph of [solve, all-gather] does)
 
-    ``finish()`` makes the current stream wait for every gather in flight and returns the last full (world, per, n)
-    tensor.  Nothing here blocks the host."""
+    G > 1 is for steps shorter than their gather (Allegro vector at 8 GPUs: 47 us of solve against >= 55 us of xGMI
+    ingest): the same bytes travel, in 1/G as many collectives, so the per-collective launch /
+    synchronisation cost of RCCL (tens of us) is paid once per G steps and the copy engines see G x larger messages;
+    results reach the other ranks up to G - 1 steps later.  ``finish()`` gathers a partly filled last group, makes the
+    current stream wait for every gather in flight and returns the last full tensor, shaped (world, G, per, n)
+    ((world, per, n) when G = 1).  Nothing here blocks the host."""
 
-    def __init__(self, comm, per: int, n: int, device, depth: int = 4, overlap: bool = True):
+    def __init__(self, comm, per: int, n: int, device, depth: int = 4, overlap: bool = True, steps_per_gather: int = 1):
         import torch
 
-        self.torch, self.comm, self.depth, self.overlap = torch, comm, depth, overlap
-        self.bytes_per_rank = per * n * 4
-        self._shard = [torch.zeros((per, n), dtype=torch.float32, device=device) for _ in range(depth)]
-        self._full = [torch.empty((comm.world, per, n), dtype=torch.float32, device=device) for _ in range(depth)]
+        if depth < 1 or steps_per_gather < 1:
+            raise ValueError("depth and steps_per_gather must be >= 1")
+        self.torch, self.comm, self.depth, self.G = torch, comm, depth, steps_per_gather
+        # host tensors (the world-size-2 CPU tests, with a gloo-backed stand-in for the communicator): no streams, every
+        # collective completes before gather() returns
+        self._gpu = torch.device(device).type == "cuda"
+        self.overlap = overlap and self._gpu
+        self.bytes_per_rank = per * n * 4  # of ONE step
+        G = self.G
+        self._shard = [torch.zeros((G, per, n) if G > 1 else (per, n), dtype=torch.float32, device=device) for _ in range(depth)]
+        self._full = [torch.empty((comm.world, G, per, n) if G > 1 else (comm.world, per, n), dtype=torch.float32, device=device)
+                      for _ in range(depth)]
         self._done = [None] * depth
-        self._comm_stream = torch.cuda.Stream(device=device) if overlap else None
+        self._comm_stream = torch.cuda.Stream(device=device) if self.overlap else None
         self._last = None
+        self._filled = 0  # steps written into the open group
+        self._open_slot = 0
+        self.collectives = 0
+
+    def _slot(self, k: int) -> int:
+        return (k // self.G) % self.depth
 
     def shard(self, k: int):
-        slot = k % self.depth
-        if self._done[slot] is not None:
+        slot, g = self._slot(k), k % self.G
+        if g == 0 and self._done[slot] is not None:
             self.torch.cuda.current_stream().wait_event(self._done[slot])
-        return self._shard[slot]
+        return self._shard[slot][g] if self.G > 1 else self._shard[slot]
 
-    def gather(self, k: int):
+    def _issue(self, slot: int):
         torch = self.torch
-        slot = k % self.depth
+        # a partly filled last group sends the whole block: the receive layout (world, G, per, n) needs equal counts
+        nbytes = self.bytes_per_rank * self.G
+        self.collectives += 1
+        self._last = slot
+        self._filled = 0
+        if not self._gpu:
+            self.comm.allgather(self._shard[slot].data_ptr(), self._full[slot].data_ptr(), nbytes, 0)
+            return
         cur = torch.cuda.current_stream()
         if self.overlap:
             ready = torch.cuda.Event()
@@ -243,15 +290,44 @@ class NativeGather:
             st = self._comm_stream
         else:
             st = cur
-        self.comm.allgather(self._shard[slot].data_ptr(), self._full[slot].data_ptr(), self.bytes_per_rank, st.cuda_stream)
+        self.comm.allgather(self._shard[slot].data_ptr(), self._full[slot].data_ptr(), nbytes, st.cuda_stream)
         done = torch.cuda.Event()
         done.record(st)
         self._done[slot] = done
-        self._last = slot
+
+    def gather(self, k: int):
+        self._filled += 1
+        self._open_slot = self._slot(k)
+        if k % self.G == self.G - 1:
+            self._issue(self._open_slot)
 
     def finish(self):
-        cur = self.torch.cuda.current_stream()
-        for ev in self._done:
-            if ev is not None:
-                cur.wait_event(ev)
+        if self._filled:
+            self._issue(self._open_slot)
+        if self._gpu:
+            cur = self.torch.cuda.current_stream()
+            for ev in self._done:
+                if ev is not None:
+                    cur.wait_event(ev)
         return None if self._last is None else self._full[self._last]
+
+
+def steps_per_gather_for(step_ms: float, shard_bytes: int, world: int, ingest_GBps: float = 537.0, target: float = 0.6,
+                         collective_overhead_us: float = 30.0, max_steps: int = 16) -> int:
+    """How many steps should share one all-gather so that the collectives keep up with the solves.
+
+    A gather of G steps moves (world - 1) * G * shard_bytes into every GPU: at `target` of the xGMI ingest that takes
+    t_wire(G) = G * (world - 1) * shard_bytes / (target * ingest) and costs one `collective_overhead_us` of launch /
+    rendezvous.  The gather stream keeps up when  t_wire(G) + overhead <= G * step_ms, i.e.
+    G >= overhead / (step - wire_per_step); when the wire time of ONE step already exceeds the step (the job is
+    gather-bound whatever G is) the answer is `max_steps`: fewer, larger collectives are then simply the cheaper way to
+    move the same bytes."""
+    if world <= 1 or shard_bytes <= 0:
+        return 1
+    wire_us = (world - 1) * shard_bytes / (target * ingest_GBps * 1e9) * 1e6
+    slack_us = step_ms * 1e3 - wire_us
+    if slack_us <= 0:
+        return max_steps
+    import math
+
+    return int(min(max_steps, max(1, math.ceil(collective_overhead_us / slack_us))))

@@ -61,23 +61,36 @@ def main(argv):
     print(ref.shape[0], time.perf_counter() - t0, flush=True)
 
 
+def plan_workers(n_available: int, procs: int, frames_per_proc: int):
+    """Frame index ranges of the all-cores leg: exactly `procs` workers, `frames_per_proc` frames each, taken from the
+    workload's frames in order and wrapping around when procs x frames_per_proc exceeds what one batch holds (round 3
+    capped the total at the batch size but kept the per-worker count, which started 7 workers where 64 were reported).
+    Returns a list of (start, count) into the wrapped index sequence  i -> i mod n_available."""
+    procs = max(1, int(procs))
+    per = max(1, int(frames_per_proc))
+    return [(w * per, per) for w in range(procs)] if n_available > 0 else []
+
+
 def run_all_cores(rel: str, ref: np.ndarray, last: np.ndarray, procs: int, frames_per_proc: int, deadline_s: float = 120.0):
-    """Returns (frames, wall seconds between 'go' and the last worker finishing) or None on any failure/timeout."""
-    n = min(procs * frames_per_proc, ref.shape[0])
-    starts = list(range(0, n, frames_per_proc))
+    """Returns (frames, wall seconds between 'go' and the last worker finishing, workers started) or None on any
+    failure/timeout."""
+    plan = plan_workers(ref.shape[0], procs, frames_per_proc)
+    if not plan:
+        return None
+    n = plan[-1][0] + plan[-1][1]
+    idx = np.arange(n) % ref.shape[0]
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     t_end = time.time() + deadline_s
     workers = []
     with tempfile.TemporaryDirectory() as sync:
         npz = os.path.join(sync, "inputs.npz")
-        np.savez(npz, ref=ref[:n], last=last[:n])
+        np.savez(npz, ref=ref[idx], last=last[idx])
         try:
-            for s in starts:
-                workers.append(subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", rel, npz, str(s),
-                                                 str(min(frames_per_proc, n - s)), sync], cwd=repo, env=env,
-                                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
-            while sum(os.path.exists(os.path.join(sync, f"ready.{s}")) for s in starts) < len(starts):
+            for s, c in plan:
+                workers.append(subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", rel, npz, str(s), str(c), sync],
+                                                cwd=repo, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+            while sum(os.path.exists(os.path.join(sync, f"ready.{s}")) for s, _ in plan) < len(plan):
                 if time.time() > t_end or any(w.poll() not in (None, 0) for w in workers):
                     raise TimeoutError("workers did not come up")
                 time.sleep(0.01)
@@ -87,7 +100,7 @@ def run_all_cores(rel: str, ref: np.ndarray, last: np.ndarray, procs: int, frame
             for w in workers:
                 out, _ = w.communicate(timeout=max(1.0, t_end - time.time()))
                 frames += int(out.split()[0])
-            return frames, time.perf_counter() - t0
+            return frames, time.perf_counter() - t0, len(workers)
         except Exception:
             return None
         finally:

@@ -149,6 +149,102 @@ def test_pipelined_all_gather_two_ranks_gloo(tmp_path, G):
             assert torch.equal(t, want), (rank, k)
 
 
+class _GlooComm:
+    """Stand-in for _lib.Comm on host memory: the same pointer-level allgather(send, recv, bytes_per_rank, stream)
+    contract as dexr_allgather, carried by a gloo all_gather."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def allgather(self, send_ptr, recv_ptr, bytes_per_rank, stream=0):
+        import ctypes
+
+        import torch
+        import torch.distributed as dist
+
+        n = bytes_per_rank // 4
+        send = torch.from_numpy(np.ctypeslib.as_array((ctypes.c_float * n).from_address(send_ptr)))
+        recv = torch.from_numpy(np.ctypeslib.as_array((ctypes.c_float * (n * self.world)).from_address(recv_ptr)))
+        dist.all_gather_into_tensor(recv, send)
+
+
+def _native_gather_worker(rank, world, port, out_dir, G):
+    import torch
+    import torch.distributed as dist
+
+    from dex_retargeting_amd.distributed import NativeGather
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per, n, steps, depth = 5, 3, 11, 2
+    ng = NativeGather(_GlooComm(rank, world), per, n, "cpu", depth=depth, overlap=True, steps_per_gather=G)
+    seen = {}
+    for k in range(steps):
+        out = ng.shard(k)
+        out.copy_(torch.full((per, n), float(100 * k + rank)))  # the "solve" of step k on this rank
+        before = ng.collectives
+        ng.gather(k)
+        if ng.collectives > before:  # a group went out: its G steps are complete on every rank
+            full = ng._full[ng._last]
+            for g in range(G):
+                seen[k - (G - 1) + g] = (full[:, g] if G > 1 else full).clone()
+    full = ng.finish()
+    tail = steps % G
+    for g in range(tail):
+        seen[steps - tail + g] = full[:, g].clone()
+    assert ng.collectives == -(-steps // G)
+    torch.save({"seen": seen}, os.path.join(out_dir, f"n{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("G", [1, 4])
+def test_native_gather_k_step_mode_two_ranks_gloo(tmp_path, G):
+    """NativeGather's group / buffer-rotation logic with world size 2 (the communicator replaced by a gloo stand-in with
+    the C-ABI's pointer contract): with steps_per_gather = 4, four steps share one collective, eleven steps need three
+    (the last one partly filled), and every rank sees every rank's rows of every step in order."""
+    import torch
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_native_gather_worker, args=(2, port, str(tmp_path), G), nprocs=2, join=True)
+    for rank in range(2):
+        d = torch.load(os.path.join(str(tmp_path), f"n{rank}.pt"))
+        assert sorted(d["seen"]) == list(range(11))
+        for k, t in d["seen"].items():
+            want = torch.stack([torch.full((5, 3), float(100 * k + r)) for r in range(2)])
+            assert torch.equal(t, want), (rank, k)
+
+
+def test_every_communicator_gets_its_own_store_key(monkeypatch):
+    """a fixed key hands a stale unique id to the non-zero ranks of a second communicator / a restarted
+    attempt.  Keys are distinct per communicator and per elastic restart, and identical across ranks (no exchange)."""
+    from dex_retargeting_amd import distributed
+
+    monkeypatch.setattr(distributed, "_comm_generation", [0])
+    monkeypatch.delenv("TORCHELASTIC_RESTART_COUNT", raising=False)
+    a, b = distributed.comm_key(), distributed.comm_key()
+    assert a != b and a == "dexr/unique_id/r0/c0" and b == "dexr/unique_id/r0/c1"
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "2")
+    monkeypatch.setattr(distributed, "_comm_generation", [0])
+    assert distributed.comm_key() == "dexr/unique_id/r2/c0"
+
+
+def test_steps_per_gather_policy():
+    from dex_retargeting_amd.distributed import steps_per_gather_for
+
+    shard = 65536 * 16 * 4
+    assert steps_per_gather_for(0.047, shard, 1) == 1                      # one GPU: nothing to gather
+    assert steps_per_gather_for(0.047, shard, 8) == 16                     # Allegro at 8 GPUs: wire time > step -> max
+    k = steps_per_gather_for(1.34, 65536 * 24 * 4, 8)                      # Shadow DexPilot: the solve hides the gather
+    assert k == 1
+    k2 = steps_per_gather_for(0.047, shard, 2)                             # 2 GPUs: 13 us of wire per 47 us step
+    assert 1 <= k2 <= 2
+
+
 def test_bench_gpus_n_starts_n_ranks_by_itself():
     """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE in the environment must start two ranks (the way
     the driver invokes the N = 1 run).  --dry-run-launch keeps the GPU out of it: every rank joins the job's store,

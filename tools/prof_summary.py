@@ -26,6 +26,13 @@ def q(path, sql):
 
 
 summary = {"workload": w}
+try:  # key of the sources this profile was taken on (bench.py only attaches the counters while it still matches)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from dex_retargeting_amd._build import source_hash
+
+    summary["source_sha16"] = source_hash(w)
+except Exception as e:
+    print("# no source hash:", e)
 try:
     line = open(os.path.join(out, f"prof_{w}_bench.json")).read().strip().splitlines()[-1]
     b = json.loads(line)
