@@ -487,6 +487,75 @@ def online_record(no_cpu=False):
     return out
 
 
+OFFLINE_ROBOTS = ["offline/allegro_hand_right.yml", "offline/shadow_hand_right.yml", "offline/leap_hand_right.yml",
+                  "offline/ability_hand_right.yml"]
+
+
+def offline_multi_robot_measure(torch, dev, tracks=8192, T=20):
+    """Sub-record `offline_multi_robot`: the reference's offline viewer loop
+    (/root/reference/example/position_retargeting/hand_robot_viewer.py:134-181) for K = 4 position configs with dummy free
+    joints and `tracks` human hand tracks in lock-step: warm_start once, then per frame ONE fleet batch of K x tracks rows
+    (MultiRobotSeqRetargeting).  Timed: T frames after the first (HIP events on the launch stream).  Returns (record,
+    checker context); touches nothing under oracle/."""
+    import bench_data
+    from dex_retargeting_amd.constants import HandType
+    from dex_retargeting_amd.multi_robot import MultiRobotSeqRetargeting
+    from dex_retargeting_amd.retargeting_config import RetargetingConfig
+
+    rets = [RetargetingConfig.load_from_file(os.path.join(bench_data.CONFIG_DIR, rel)).build() for rel in OFFLINE_ROBOTS]
+    K = len(rets)
+    multi = MultiRobotSeqRetargeting(rets, tracks, device=str(dev))
+    kp, wrist_pos, wrist_quat = bench_data.world_tracks(tracks, T + 2)
+    t_kp = torch.from_numpy(kp).to(dev)
+    multi.warm_start(wrist_pos, wrist_quat, hand_type=HandType.right, is_mano_convention=True)
+    multi.retarget(t_kp[0])  # frame 0: from the warm start (untimed: the solver's cold frame)
+    stream = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for t in range(1, T + 1):
+        multi.retarget(t_kp[t])
+    e1.record(stream)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms = float(e0.elapsed_time(e1))
+    start = multi.last_qpos.clone()
+    multi.retarget(t_kp[T + 1])  # one more frame, kept for the checker: start point, keypoints, answers
+    q = multi.last_qpos.cpu().numpy()
+    rec = {"robots": OFFLINE_ROBOTS, "tracks": tracks, "frames_timed": T, "rows_per_frame": K * tracks,
+           "ms_per_frame": ms / T, "robot_frames_per_s": K * tracks * T / (ms * 1e-3), "wall_ms_per_frame": wall / T * 1e3,
+           "unit": "robot-frames/s",
+           "protocol": "hand_robot_viewer.py:134-181: warm_start(wrist_pos, wrist_quat, right, is_mano_convention=True) once per "
+                       "robot, then per frame ref_value = joint[target_link_human_indices] -> retarget() for every robot; here "
+                       "all K robots x all tracks of a frame are one dexr_retarget_multi_dev batch, last_qpos carried on the device"}
+    return rec, dict(start=start.cpu().numpy(), q=q, kp=kp[T + 1], tracks=tracks)
+
+
+def offline_multi_robot_check(rec, ctx, n_par=1024):
+    """Checker: the last frame of the first n_par tracks of every robot against the float64 oracle from the same start."""
+    from oracle import cases, jobs
+
+    B = ctx["tracks"]
+    n_par = min(n_par, B)
+    rec["parity"] = {}
+    with jobs.host_pool() as pool:
+        for k, rel in enumerate(OFFLINE_ROBOTS):
+            prob = cases.problem_from_config(rel)
+            n = prob.n_opt
+            lo, hi = prob.joint_limits[:, 0], prob.joint_limits[:, 1]
+            rows = slice(k * B, k * B + n_par)
+            last = np.clip(ctx["start"][rows, :n].astype(np.float64), lo, hi).astype(np.float32)
+            ref = np.ascontiguousarray(cases.ref_from_keypoints(prob, ctx["kp"][:n_par]), dtype=np.float32)
+            got = ctx["q"][rows, :n].astype(np.float64)
+            o = jobs.pooled_oracle_solve(rel, ref, last, None, got, pool=pool)
+            dq = np.abs(got - o["want"]).max(1)
+            far = dq >= 1e-4
+            rec["parity"][rel] = {"subset": n_par, "max_abs_dq_rad": float(dq.max()), "frac_within_1e-4": float((~far).mean()),
+                                  "other_minimum": {"frames": int(far.sum()), "worse": int((o["F_gpu"][far] > o["F_want"][far] + 1e-9).sum())}}
+    return rec
+
+
 def parity_block(wl, batch, q_gpu, n_par, n_slsqp):
     """Checker (oracle) section: max |dq| against the float64 oracle minimiser of F on the first n_par frames of
     `batch`, and the distance to the reference-as-configured SLSQP answers on the first n_slsqp."""
@@ -508,19 +577,27 @@ def parity_block(wl, batch, q_gpu, n_par, n_slsqp):
         return dict(weights=w, dexpilot_ref=rv)
 
     kw = kw_for(slice(0, n_par))
-    want = solvers.solve_lm_batched(prob, ref, None, last, newton=True, max_iter=100, **kw)
     got = q_gpu[:n_par].astype(np.float64)
-    dq = np.abs(got - want).max(1)
     last64 = last.astype(np.float64)
-    F_got = prob.total(got, ref, None, last64, **kw)
-    F_want = prob.total(want, ref, None, last64, **kw)
+    if n_par >= 1024:  # thousands of frames: the oracle phase is fanned over the host cores (spawned processes)
+        from oracle import jobs
+
+        st_in = None if not wl.dexpilot else (batch["host_state"][:n_par] if batch["host_state"] is not None else np.zeros(n_par, np.uint32))
+        o = jobs.pooled_oracle_solve(wl.rel, np.ascontiguousarray(ref), np.ascontiguousarray(last), st_in, got)
+        want, F_got, F_want = o["want"], o["F_gpu"], o["F_want"]
+    else:
+        want = solvers.solve_lm_batched(prob, ref, None, last, newton=True, max_iter=100, **kw)
+        F_got = prob.total(got, ref, None, last64, **kw)
+        F_want = prob.total(want, ref, None, last64, **kw)
+    dq = np.abs(got - want).max(1)
     other = dq >= 1e-4
     out = {"subset": n_par, "max_abs_dq_rad": float(dq.max()), "p99_abs_dq_rad": float(np.percentile(dq, 99)),
            "frac_within_1e-4": float((dq < 1e-4).mean()),
            "other_minimum": {"frames": int(other.sum()),
-                             "gpu_objective_lower_or_equal": int((F_got[other] <= F_want[other] + 1e-9).sum())},
+                             "gpu_objective_lower_or_equal": int((F_got[other] <= F_want[other] + 1e-9).sum()),
+                             "worse": int((F_got[other] > F_want[other] + 1e-9).sum())},
            "max_abs_dq_rad_same_minimum": float(dq[~other].max()) if (~other).any() else None,
-           "oracle": "float64 projected LM/Newton on F (oracle/solvers.py)"}
+           "oracle": "float64 projected LM/Newton on F, positive-definite damped models only (oracle/solvers.py)"}
     if n_slsqp:
         sl = slice(0, n_slsqp)
         q_ref, _ = solvers.solve_ref_as_configured(prob, ref[sl], None, last[sl], **kw_for(sl))
@@ -798,6 +875,19 @@ def run_single(args):
                            "unit": "frames/s", "n_gpus": 1, "ms_per_step": e2 / args.steps * 1e3, "solver": d2,
                            "roofline": w2.roofline(k2, d2["iters_mean"]), "two_streams": ts2})
 
+    fleet_m, offline_m = None, None
+    if rank == 0 and not args.headline_only and args.workload == "allegro_vector":
+        try:  # BASELINE configs[4], the per-GPU slice: 1 048 576 / 8 frames of four robots in one batch
+            import bench_fleet
+
+            fleet_m = bench_fleet.fleet_measure(args, batch=131072, standalone=False)
+        except Exception as e:
+            fleet_m = repr(e)
+        try:
+            offline_m = offline_multi_robot_measure(torch, dev)
+        except Exception as e:
+            offline_m = repr(e)
+
     if rank != 0:
         comm.close()
         return
@@ -808,7 +898,7 @@ def run_single(args):
     out.update(sub)
 
     # ---- checker sections (oracle = checker only; nothing above this line touches oracle/) -------------------------
-    n_par = 4096 if args.workload == "allegro_vector" else 512  # 4 096-item subset on the headline
+    n_par = 4096  # 4 096-item subset (the oracle phase runs in a host process pool)
     par, prob, ref_now, last_now, kw_for = parity_block(wl, last_batch, q_head, min(n_par, B), 0 if args.no_cpu_baseline else min(128, B))
     out["parity"] = par
     if "cold_start" in sub:
@@ -827,8 +917,21 @@ def run_single(args):
                                        "note": "far starts are multi-modal: frames that end in another minimum than the "
                                                "oracle's are counted, with the objective comparison"}
     for name, (w2, b2, q2, rec) in also.items():
-        rec["parity"] = parity_block(w2, b2, q2, min(256, B), 0 if args.no_cpu_baseline else min(64, B))[0]
+        rec["parity"] = parity_block(w2, b2, q2, min(4096, B), 0 if args.no_cpu_baseline else min(64, B))[0]
         out.setdefault("also", {})[name] = rec
+
+    if fleet_m is not None:
+        import bench_fleet
+
+        try:
+            out.setdefault("also", {})["mixed_fleet"] = fleet_m if isinstance(fleet_m, str) else bench_fleet.fleet_check(*fleet_m, args)
+        except Exception as e:
+            out.setdefault("also", {})["mixed_fleet"] = {"error": repr(e)}
+    if offline_m is not None:
+        try:
+            out["offline_multi_robot"] = {"error": offline_m} if isinstance(offline_m, str) else offline_multi_robot_check(*offline_m)
+        except Exception as e:
+            out["offline_multi_robot"] = {"error": repr(e)}
 
     # ---- CPU baseline: the reference path as configured, on the host cores (oracle = checker code only) -------------
     if world == 1 and not args.no_cpu_baseline:

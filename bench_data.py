@@ -47,3 +47,31 @@ def reachable_batch(seq, B: int, sigma: float, seed: int = SEED):
         ref = (pos[:, opt.task_link_indices] - pos[:, opt.origin_link_indices]) / float(opt.scaling)
     return (np.ascontiguousarray(ref, dtype=np.float32),
             np.ascontiguousarray(start[:, opt.idx_pin2target], dtype=np.float32))
+
+
+def world_tracks(B: int, T: int, seed: int = 5):
+    """B hand tracks x T frames of (21, 3) WORLD-frame keypoints, the way the reference's offline viewer feeds its position
+    configs (/root/reference/example/position_retargeting/hand_robot_viewer.py:143-176: MANO joints in the camera frame),
+    + the wrist pose of frame 0 as that viewer hands it to warm_start (wrist_pos = joint[0], wrist_quat = the MANO global
+    orientation R_q).  Track b plays the human fixture from a random phase; its (MANO-convention) wrist frame sits in the
+    world at rotation R_q @ OPERATOR2MANO[right]^T (seq_retarget.py:70-75) and translation p0_b + t v_b (|v| <= 2 mm/frame).
+    Returns kp (T, B, 21, 3) f32, wrist_pos (B, 3) f64, wrist_quat (B, 4) f64 (w, x, y, z)."""
+    from dex_retargeting_amd.constants import OPERATOR2MANO, HandType
+
+    rng = np.random.default_rng(seed)
+    fixture = np.load(HUMAN_FIXTURE).astype(np.float64)
+    op = np.asarray(OPERATOR2MANO[HandType.right], dtype=np.float64)
+    q = rng.standard_normal((B, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    Rq = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], -1),
+                   np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
+                   np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], -2)
+    Rw = Rq @ op.T                                     # (B, 3, 3)
+    p0 = rng.uniform(-0.3, 0.3, (B, 3))
+    vel = rng.uniform(-2e-3, 2e-3, (B, 3))
+    phase = rng.integers(0, fixture.shape[0], B)
+    idx = (phase[None, :] + np.arange(T)[:, None]) % fixture.shape[0]          # (T, B)
+    hand = fixture[idx]                                                        # (T, B, 21, 3)
+    kp = np.einsum("tbkj,bij->tbki", hand, Rw) + (p0[None] + vel[None] * np.arange(T)[:, None, None])[:, :, None, :]
+    return kp.astype(np.float32), p0, q

@@ -20,6 +20,15 @@ from bench import FLEET, HBM_PEAK_GBPS, N_BATCHES, WORKLOADS  # noqa: E402
 
 
 def run(args):
+    m = fleet_measure(args)
+    if m is not None:
+        print(json.dumps(fleet_check(*m, args)))
+
+
+def fleet_measure(args, batch=None, standalone=True):
+    """Timed part of the mixed-fleet line: (record dict, checker context) on rank 0, None on the other ranks.  Touches
+    nothing under oracle/.  standalone=False: called from bench.py's default command for the sub-record also.mixed_fleet
+    (one GPU, no communicator: BASELINE configs[4]'s per-GPU slice)."""
     import torch
 
     import bench_data
@@ -27,13 +36,13 @@ def run(args):
     from dex_retargeting_amd.fleet import MixedFleet
     from dex_retargeting_amd.retargeting_config import RetargetingConfig
 
-    from bench import gather_records, job_env
+    from bench import gather_records, job_env  # noqa: F401
 
-    rank, local_rank, world, launched = job_env(args)
+    rank, local_rank, world, launched = job_env(args) if standalone else (0, int(os.environ.get("LOCAL_RANK", "0")), 1, False)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     comm = None
-    if world > 1 or (launched and os.environ.get("DEXR_BENCH_DIST", "1") != "0"):
+    if standalone and (world > 1 or (launched and os.environ.get("DEXR_BENCH_DIST", "1") != "0")):
         from dex_retargeting_amd.distributed import native_comm
 
         comm = native_comm(rank, world)
@@ -41,7 +50,7 @@ def run(args):
     RetargetingConfig.set_default_urdf_dir(str(DEFAULT_URDF_DIR))
     seqs = [RetargetingConfig.load_from_file(os.path.join(bench_data.CONFIG_DIR, r)).build() for r in FLEET]
     fleet = MixedFleet([q.optimizer for q in seqs], device=str(dev))
-    B = args.batch
+    B = batch or args.batch
     seed = bench_data.SEED + 1000 * rank
     batches = []
     for j in range(N_BATCHES):
@@ -109,7 +118,7 @@ def run(args):
         elapsed, step_ms = timed(None)
     if rank != 0:
         comm.close()
-        return
+        return None
     last_b = last_b[0]
     # answers of the last step's batch (re-issued into a plain buffer) for the checker
     t_state.copy_(last_b["t_state0"])
@@ -135,31 +144,43 @@ def run(args):
                      "kernel": "dexr_retarget_multi_dev: device-side bucketing (3 small kernels) + one solve launch per model "
                                "over its index list, in-place rows"},
     }
-    # ---- checker (oracle) and CPU baseline: only from here on ----------------------------------------------------
-    from oracle import cases, solvers
+    if comm is not None:
+        comm.close()
+    return out_json, dict(q=q, last=last, st_in=st_in, mid=mid, kp=kp, world=world, standalone=standalone, coll=coll)
+
+
+def fleet_check(out_json, ctx, args):
+    """Checker part (oracle/): 4 096 frames of each model against the float64 oracle, fanned over the host cores; the CPU
+    port timed on a small sample of each model (standalone N = 1 runs only)."""
+    from oracle import cases
+
+    q, last, st_in, mid, kp, world, standalone, coll = (ctx[k] for k in ("q", "last", "st_in", "mid", "kp", "world", "standalone", "coll"))
+    from oracle import jobs
 
     probs = [cases.problem_from_config(r) for r in FLEET]
     parity, cpu_t, cpu_n = {}, 0.0, 0
-    for m, (rel, pr) in enumerate(zip(FLEET, probs)):
-        idx = np.nonzero(mid == m)[0][:128]
-        ref = cases.ref_from_keypoints(pr, kp[idx]).astype(np.float32)
-        kw = {}
-        if pr.kind == "dexpilot":
-            proj = ((st_in[idx, None] >> np.arange(pr.n_pair, dtype=np.uint32)) & 1).astype(bool)
-            w, rv, _ = pr.dexpilot_preamble(ref, proj)
-            kw = dict(weights=w, dexpilot_ref=rv)
-        la = last[idx][:, : pr.n_opt]
-        want = solvers.solve_lm_batched(pr, ref, None, la, newton=True, max_iter=100, **kw)
-        dq = np.abs(q[idx][:, : pr.n_opt].astype(np.float64) - want).max(1)
-        parity[rel] = {"subset": len(idx), "max_abs_dq_rad": float(dq.max()), "frac_within_1e-4": float((dq < 1e-4).mean())}
-        if not args.no_cpu_baseline and world == 1:
-            from oracle import cport
+    n_par = 4096  # frames of each model compared with the oracle (fanned over the host cores)
+    with jobs.host_pool() as pool:
+        for m, (rel, pr) in enumerate(zip(FLEET, probs)):
+            idx = np.nonzero(mid == m)[0][:n_par]
+            ref = np.ascontiguousarray(cases.ref_from_keypoints(pr, kp[idx]), dtype=np.float32)
+            la = np.ascontiguousarray(last[idx][:, : pr.n_opt])
+            got = q[idx][:, : pr.n_opt].astype(np.float64)
+            o = jobs.pooled_oracle_solve(rel, ref, la, st_in[idx] if pr.kind == "dexpilot" else None, got, pool=pool)
+            dq = np.abs(got - o["want"]).max(1)
+            far = dq >= 1e-4
+            parity[rel] = {"subset": len(idx), "max_abs_dq_rad": float(dq.max()), "frac_within_1e-4": float((~far).mean()),
+                           "other_minimum": {"frames": int(far.sum()), "worse": int((o["F_gpu"][far] > o["F_want"][far] + 1e-9).sum())},
+                           "max_abs_dq_rad_same_minimum": float(dq[~far].max()) if (~far).any() else None}
+            if not args.no_cpu_baseline and world == 1 and standalone:
+                from oracle import cport
 
-            cp = cport.CProblem(pr)
-            t1 = time.perf_counter()
-            cport.solve_ref_as_configured_c(cp, ref, None, la, **kw)
-            cpu_t += time.perf_counter() - t1
-            cpu_n += len(idx)
+                kw = jobs._kw(pr, ref[:128], st_in[idx][:128]) if pr.kind == "dexpilot" else {}
+                cp = cport.CProblem(pr)
+                t1 = time.perf_counter()
+                cport.solve_ref_as_configured_c(cp, ref[:128], None, la[:128], **kw)
+                cpu_t += time.perf_counter() - t1
+                cpu_n += min(128, len(idx))
     out_json["parity"] = parity
     if cpu_n:
         out_json["cpu_baseline"] = {"value": cpu_n / cpu_t, "unit": "frames/s", "cores": 1, "kind": "port",
@@ -167,6 +188,4 @@ def run(args):
                                               "oracle's plain-C closure + scipy's compiled SLSQP (see bench.py cpu_baseline)"}
     if coll is not None:
         out_json["multi_gpu"] = coll
-    print(json.dumps(out_json))
-    if comm is not None:
-        comm.close()
+    return out_json

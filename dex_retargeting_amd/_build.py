@@ -19,7 +19,8 @@ VARIANTS = ((0, 0), (1, 0), (1, 1), (1, 2))  # (float64?, mode): f32 solve, f64 
 BIG_HEADER = os.path.join(CSRC, "dexr_big.hpp")
 QUAD_HEADER = os.path.join(CSRC, "dexr_quad.hpp")
 QUAD_BUCKETS = (16, 24)
-HEADERS = [os.path.join(CSRC, "dexr_kernel.hpp"), os.path.join(CSRC, "dexr_launch.hpp"),
+HEADERS = [os.path.join(CSRC, "dexr_kernel.hpp"), os.path.join(CSRC, "dexr_launch.hpp"), os.path.join(CSRC, "dexr_tip.hpp"),
+           os.path.join(CSRC, "dexr_math.hpp"),
            os.path.join(INCLUDE, "dexr.h"), os.path.join(INCLUDE, "dexr_tables.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}"] + \
     os.environ.get("DEXR_EXTRA_FLAGS", "").split()
@@ -38,9 +39,9 @@ NO_SLP = ["-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "
 # summaries, profiles/pmc_<workload>.json: bench.py attaches their counters to a line only while this hash is unchanged).
 _COMMON_SOURCES = ["dexr_api.hip", "dexr_launch.hpp", "../../include/dexr.h", "../../include/dexr_tables.h"]
 KERNEL_SOURCES = {
-    "allegro_vector": ["dexr_kernel.hpp", "dexr_tip.hpp", "dexr_inst.hip"],
-    "shadow_dexpilot": ["dexr_wide.hpp", "dexr_wide_inst.hip", "dexr_big.hpp"],
-    "leap_position": ["dexr_wide.hpp", "dexr_wide_inst.hip", "dexr_big.hpp"],
+    "allegro_vector": ["dexr_kernel.hpp", "dexr_tip.hpp", "dexr_math.hpp", "dexr_inst.hip"],
+    "shadow_dexpilot": ["dexr_wide.hpp", "dexr_wide_inst.hip", "dexr_big.hpp", "dexr_math.hpp"],
+    "leap_position": ["dexr_wide.hpp", "dexr_wide_inst.hip", "dexr_big.hpp", "dexr_math.hpp"],
 }
 
 
@@ -157,11 +158,12 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         objs.append(o)
         if force or _stale(o, [inst_s] + HEADERS):
             jobs.append((inst_s, o, NO_SLP + [f"-DDEXR_NMAX={n}", "-DDEXR_F64=0", "-DDEXR_MODE=0", "-DDEXR_CHAIN=1", "-DDEXR_EXT=1"]))
-    for tag, defs in (("tip", []), ("ext_tip", ["-DDEXR_EXT=1"])):  # tip pass of the serial-chain kernel (dexr_tip.hpp)
-        o = os.path.join(BUILD, f"dexr_inst_{tag}_4_0_0.o")
-        objs.append(o)
-        if force or _stale(o, [inst_s, os.path.join(CSRC, "dexr_tip.hpp")] + HEADERS):
-            jobs.append((inst_s, o, NO_SLP + ["-DDEXR_NMAX=4", "-DDEXR_F64=0", "-DDEXR_MODE=0", "-DDEXR_CHAIN=1", "-DDEXR_TIP=1"] + defs))
+    for f64 in (0, 1):  # tip pass of the serial-chain kernel (dexr_tip.hpp): float32, and float64 (the reference's arithmetic)
+        for tag, defs in (("tip", []), ("ext_tip", ["-DDEXR_EXT=1"])):
+            o = os.path.join(BUILD, f"dexr_inst_{tag}_4_{f64}_0.o")
+            objs.append(o)
+            if force or _stale(o, [inst_s] + HEADERS):
+                jobs.append((inst_s, o, NO_SLP + ["-DDEXR_NMAX=4", f"-DDEXR_F64={f64}", "-DDEXR_MODE=0", "-DDEXR_CHAIN=1", "-DDEXR_TIP=1"] + defs))
     for n in CHAIN_BUCKETS:  # serial-chain specialisation, float32 solve only
         o = os.path.join(BUILD, f"dexr_inst_chain_{n}_0_0.o")
         objs.append(o)

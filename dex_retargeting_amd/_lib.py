@@ -31,7 +31,11 @@ class Tuning(C.Structure):
                 ("stall_cap", C.c_float), ("lam_jump", C.c_float), ("lam_fastdec", C.c_float),
                 ("floor_scale", C.c_float), ("step_cap", C.c_float), ("blind_tol_scale", C.c_float),
                 ("pivot_rule", C.c_int32), ("longest_first", C.c_int32), ("lam_recover", C.c_float),
-                ("fork_streams", C.c_int32)]
+                ("fork_streams", C.c_int32), ("user_mask", C.c_uint32)]
+
+
+TUNE_LAM_JUMP, TUNE_LAM_FASTDEC = 1, 2
+_TUNE_BITS = {"lam_jump": TUNE_LAM_JUMP, "lam_fastdec": TUNE_LAM_FASTDEC}
 
 
 KERNEL_AUTO, KERNEL_REGISTER, KERNEL_QUAD, KERNEL_LDS, KERNEL_REDUCED, KERNEL_WIDE, KERNEL_GENERAL = -1, 0, 1, 2, 3, 4, 5
@@ -156,11 +160,17 @@ class Model:
         return t
 
     def tune(self, **kw) -> Tuning:
-        """Change fields of the handle's dexr_tuning, e.g. ``model.tune(kernel=KERNEL_REGISTER, persist_from=0)``."""
+        """Change fields of the handle's dexr_tuning, e.g. ``model.tune(kernel=KERNEL_REGISTER, persist_from=0)``.
+        ``lam_jump`` / ``lam_fastdec``: a number is a caller override (holds for every kernel family), ``None`` drops it."""
         t = self.get_tuning()
         for k, v in kw.items():
             if k not in dict(Tuning._fields_):
                 raise AttributeError(f"dexr_tuning has no field {k}")
+            if k in _TUNE_BITS:  # family-dependent defaults: a value is an explicit override, None returns to the default
+                if v is None:
+                    t.user_mask &= ~_TUNE_BITS[k]
+                    continue
+                t.user_mask |= _TUNE_BITS[k]
             setattr(t, k, v)
         check(load().dexr_model_set_tuning(self._h, C.byref(t)))
         return t

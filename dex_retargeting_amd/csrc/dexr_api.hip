@@ -495,7 +495,7 @@ int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStr
   if (m->bucket == 32 && mode == dexr::MODE_SOLVE) f64 = 1;  // see find_launcher: bucket 32 is float64 only
   const size_t real_sz = f64 ? 8 : 4;
   // (the tip pass keeps the placements of joints 1..3 in 64 more floats of the wave's LDS, dexr_tip.hpp)
-  const bool tip_kernel = m->tip && m->chain && m->bucket == 4 && !f64 && mode == dexr::MODE_SOLVE;
+  const bool tip_kernel = m->tip && m->chain && m->bucket == 4 && mode == dexr::MODE_SOLVE;
   const size_t per_wave = 64 * real_sz * (size_t)(3 * m->lds_frames + 4 * m->lds_terms + (tip_kernel ? 1 : 0));
   int wpb = 4;
   while (wpb > 1 && per_wave * wpb > 48 * 1024) wpb >>= 1;
@@ -505,6 +505,7 @@ int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStr
   if (mode == dexr::MODE_SOLVE && m->bucket <= 8) {
     // persistent lanes (small components): a resident set of waves pulls frames from per-component queues
     int occ = m->chain ? 4 : (m->bucket <= 4 ? 3 : 2);  // waves per SIMD the kernels' register budgets allow
+    if (f64) occ = tip_kernel ? 2 : 1;                  // (float64: the tip pass is built for two, the generic kernels hold one)
     if (m->tune.persist_occ > 0) occ = m->tune.persist_occ;
     const int64_t resident = (int64_t)m->n_cu * 4 * occ;
     const int64_t per_comp = (resident + kp.n_comp - 1) / kp.n_comp;
@@ -539,8 +540,35 @@ int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStr
     kp.g64out = sprof;
   }
 #endif
+#ifdef DEXR_WAVE_TRACE
+  // profiling build only (tools/wave_trace.sh): 24 doubles per wave, dumped to /tmp/dexr_wave_trace.bin after every launch
+  static double* wtrace = nullptr;
+  static size_t wtrace_cap = 0;
+  const bool wtrace_on = mode == dexr::MODE_SOLVE && m->bucket <= 8;
+  const size_t wtrace_n = (size_t)blocks * wpb * 24;
+  if (wtrace_on) {
+    if (wtrace_n > wtrace_cap) {
+      if (wtrace) (void)hipFree(wtrace);
+      (void)hipMalloc((void**)&wtrace, wtrace_n * sizeof(double));
+      wtrace_cap = wtrace_n;
+    }
+    (void)hipMemsetAsync(wtrace, 0, wtrace_n * sizeof(double), st);
+    kp.g64out = wtrace;
+  }
+#endif
   hipError_t e = fn(kp, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, st);
   if (e != hipSuccess) return fail(DEXR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+#ifdef DEXR_WAVE_TRACE
+  if (wtrace_on) {
+    std::vector<double> h(wtrace_n);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h.data(), wtrace, wtrace_n * sizeof(double), hipMemcpyDeviceToHost);
+    if (FILE* f = fopen("/tmp/dexr_wave_trace.bin", "wb")) {
+      fwrite(h.data(), sizeof(double), wtrace_n, f);
+      fclose(f);
+    }
+  }
+#endif
 #ifdef DEXR_SMALL_PROF
   if (sprof_on) {
     double h[12];
@@ -945,6 +973,7 @@ int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out) {
   select_kernels(m);
   m->tune.lam_jump = family_lam_jump(m, selected_family(m));  // reported value; launches derive it per family
   m->tune.lam_fastdec = family_lam_fastdec(m, selected_family(m));
+  m->tune.user_mask = 0u;
   if (m->bucket < 0) {
     delete m;
     return fail(DEXR_ERR_UNSUPPORTED, "component with %d joints exceeds the largest kernel bucket", maxj);
@@ -1018,12 +1047,14 @@ int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning) {
     return fail(DEXR_ERR_INVALID, "negative launch parameter");
   if (!(t.step_cap >= 0) || !(t.lam_jump >= 0) || !(t.lam_fastdec >= 0) || !(t.floor_scale >= 0) || !(t.blind_tol_scale >= 0) || !(t.lam_recover >= 0))
     return fail(DEXR_ERR_INVALID, "negative or non-finite damping parameter");
-  // lam_jump: a value that differs from what get_tuning reports is a caller override and then holds for every family;
-  // otherwise each launch keeps using the default of the family it dispatches (which select_kernels may change now)
-  if (tuning->struct_size >= offsetof(dexr_tuning, lam_jump) + sizeof(float) && t.lam_jump != m->tune.lam_jump)
-    m->lam_jump_user = t.lam_jump;
-  if (tuning->struct_size >= offsetof(dexr_tuning, lam_fastdec) + sizeof(float) && t.lam_fastdec != m->tune.lam_fastdec)
-    m->lam_fastdec_user = t.lam_fastdec;
+  // lam_jump / lam_fastdec are caller overrides -- holding for every family -- exactly when the caller says so
+  // (user_mask); otherwise each launch uses the default of the family it dispatches (which select_kernels may change now)
+  if (tuning->struct_size >= offsetof(dexr_tuning, user_mask) + sizeof(uint32_t)) {
+    if (t.user_mask & ~(DEXR_TUNE_LAM_JUMP | DEXR_TUNE_LAM_FASTDEC)) return fail(DEXR_ERR_INVALID, "unknown bits in dexr_tuning.user_mask");
+    m->lam_jump_user = (t.user_mask & DEXR_TUNE_LAM_JUMP) ? t.lam_jump : -1.f;
+    m->lam_fastdec_user = (t.user_mask & DEXR_TUNE_LAM_FASTDEC) ? t.lam_fastdec : -1.f;
+  }
+  t.user_mask = (m->lam_jump_user >= 0.f ? DEXR_TUNE_LAM_JUMP : 0u) | (m->lam_fastdec_user >= 0.f ? DEXR_TUNE_LAM_FASTDEC : 0u);
   m->tune = t;
   if (m->gen) return DEXR_OK;  // one kernel serves a generic model
   select_kernels(m);
@@ -1054,12 +1085,17 @@ int dexr_model_lane_plan(const dexr_model* m, int32_t comp, int32_t* n_chain, in
   return DEXR_OK;
 }
 
+// Raw-keypoint input needs the rows' keypoint map: target_link_human_indices in the fixed tables, and -- for a model in
+// the generic table format -- the validated per-row map (create_generic checks row_ho / row_ht only when has_keypoint_map
+// is set: a blob with n_keypoints > 0 but no map would make dexr_gen_kernel index the keypoints with unvalidated rows).
+static bool takes_keypoints(const dexr_model* m) { return m->h.n_keypoints > 0 && (!m->gen || m->gen_tab.has_kp); }
+
 static int retarget_dev_impl(const dexr_model* m, int64_t B, const float* ref, bool ref_is_keypoints, const float* fixed,
                              const float* last, uint32_t* state, float* qpos_out, int32_t* status_out,
                              int32_t* iters_out, float* fval_out, const dexr_solve_options* opt, void* stream) {
   if (!m || !ref || !last || !qpos_out) return fail(DEXR_ERR_INVALID, "null argument");
   if (m->h.kind == DEXR_KIND_FKONLY) return fail(DEXR_ERR_INVALID, "model is an FK-only table");
-  if (ref_is_keypoints && (m->h.n_keypoints <= 0 || (m->gen && !m->gen_tab.has_kp)))
+  if (ref_is_keypoints && !takes_keypoints(m))
     return fail(DEXR_ERR_INVALID, "model carries no target_link_human_indices: keypoint input not available");
   if (m->h.n_fixed > 0 && !fixed) return fail(DEXR_ERR_INVALID, "model has %d fixed joints but fixed_qpos is NULL", m->h.n_fixed);
   if (B < 0) return fail(DEXR_ERR_INVALID, "negative batch");
@@ -1105,7 +1141,7 @@ static int retarget_host(const dexr_model* m, int64_t B, const float* ref, const
                          bool verify_every_step = false) {
   if (!m || !ref || !last || (!q32 && !q64)) return fail(DEXR_ERR_INVALID, "null argument");
   if (m->h.kind == DEXR_KIND_FKONLY) return fail(DEXR_ERR_INVALID, "model is an FK-only table");
-  if (ref_is_keypoints && m->h.n_keypoints <= 0)
+  if (ref_is_keypoints && !takes_keypoints(m))
     return fail(DEXR_ERR_INVALID, "model carries no target_link_human_indices: keypoint input not available");
   if (m->h.n_fixed > 0 && !fixed) return fail(DEXR_ERR_INVALID, "model has %d fixed joints but fixed_qpos is NULL", m->h.n_fixed);
   if (B < 0) return fail(DEXR_ERR_INVALID, "negative batch");
@@ -1238,7 +1274,7 @@ int dexr_retarget_seq_dev(const dexr_model* m, int64_t B, int32_t T, const float
                           int32_t* status_out, float joint_limit_eps, const dexr_solve_options* opt, void* stream) {
   if (!m || !inputs || !last_inout || !qpos_raw_out) return fail(DEXR_ERR_INVALID, "null argument");
   if (m->h.kind == DEXR_KIND_FKONLY) return fail(DEXR_ERR_INVALID, "model is an FK-only table");
-  if (inputs_are_keypoints && m->h.n_keypoints <= 0)
+  if (inputs_are_keypoints && !takes_keypoints(m))
     return fail(DEXR_ERR_INVALID, "model carries no target_link_human_indices: keypoint input not available");
   if (m->h.n_fixed > 0 && !fixed) return fail(DEXR_ERR_INVALID, "model has %d fixed joints but fixed_qpos is NULL", m->h.n_fixed);
   if (B < 0 || T < 0) return fail(DEXR_ERR_INVALID, "negative batch or sequence length");
@@ -1333,7 +1369,7 @@ int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, i
     const dexr_model* m = models[i];
     if (!m) return fail(DEXR_ERR_INVALID, "models[%d] is NULL", i);
     if (m->h.kind == DEXR_KIND_FKONLY) return fail(DEXR_ERR_INVALID, "models[%d] is an FK-only table", i);
-    if (m->h.n_keypoints <= 0) return fail(DEXR_ERR_INVALID, "models[%d] carries no target_link_human_indices", i);
+    if (!takes_keypoints(m)) return fail(DEXR_ERR_INVALID, "models[%d] carries no target_link_human_indices", i);
     if (m->h.n_fixed > 0 && (!fixed || m->h.n_fixed > ld_fixed))
       return fail(DEXR_ERR_INVALID, "models[%d] has %d caller-supplied fixed joints but fixed rows are %d long", i, m->h.n_fixed, fixed ? ld_fixed : 0);
     if (m->h.n_opt > ld) return fail(DEXR_ERR_INVALID, "models[%d] optimises %d joints but rows are %d long", i, m->h.n_opt, ld);
@@ -1359,7 +1395,14 @@ int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, i
   std::unique_lock<std::mutex> lock;
   if (fp) {
     lock = std::unique_lock<std::mutex>(fp->mu);
+    // every stream and event the fork may need exists BEFORE the fork event is recorded: an allocation failure returns
+    // here, with nothing forked (an early return after work has been enqueued on an internal stream would leave the
+    // caller's stream un-joined -- buffers in use, an unjoined fork inside a stream capture)
     if (!fp->fork) HIP_TRY(hipEventCreateWithFlags(&fp->fork, hipEventDisableTiming));
+    for (int sl = 0; sl < DEXR_FLEET_MAX_MODELS; ++sl) {
+      if (!fp->aux[sl]) HIP_TRY(hipStreamCreateWithFlags(&fp->aux[sl], hipStreamNonBlocking));
+      if (!fp->join[sl]) HIP_TRY(hipEventCreateWithFlags(&fp->join[sl], hipEventDisableTiming));
+    }
     HIP_TRY(hipEventRecord(fp->fork, st));
   }
   int rc_all = DEXR_OK;
@@ -1381,10 +1424,14 @@ int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, i
       }
       if (heavy) first_heavy_placed = true;
       if (slot >= 0) {
-        if (!fp->aux[slot]) HIP_TRY(hipStreamCreateWithFlags(&fp->aux[slot], hipStreamNonBlocking));
-        if (!fp->join[slot]) HIP_TRY(hipEventCreateWithFlags(&fp->join[slot], hipEventDisableTiming));
         si = fp->aux[slot];
-        if (!forked[slot]) HIP_TRY(hipStreamWaitEvent(si, fp->fork, 0));
+        if (!forked[slot]) {
+          const hipError_t we = hipStreamWaitEvent(si, fp->fork, 0);
+          if (we != hipSuccess) {  // join what has been forked so far, then report
+            rc_all = fail(DEXR_ERR_HIP, "hipStreamWaitEvent(fork) failed: %s", hipGetErrorString(we));
+            break;
+          }
+        }
         forked[slot] = true;
       }
       dexr::KernelParams kp;
@@ -1409,10 +1456,14 @@ int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, i
     }
   }
   std::string err = g_err;
-  for (int sl = 0; sl < DEXR_FLEET_MAX_MODELS; ++sl) {
+  for (int sl = 0; sl < DEXR_FLEET_MAX_MODELS; ++sl) {  // every forked stream is joined, whatever failed before
     if (!forked[sl]) continue;
-    HIP_TRY(hipEventRecord(fp->join[sl], fp->aux[sl]));
-    HIP_TRY(hipStreamWaitEvent(st, fp->join[sl], 0));
+    hipError_t je = hipEventRecord(fp->join[sl], fp->aux[sl]);
+    if (je == hipSuccess) je = hipStreamWaitEvent(st, fp->join[sl], 0);
+    if (je != hipSuccess && rc_all == DEXR_OK) {
+      rc_all = fail(DEXR_ERR_HIP, "joining internal stream %d failed: %s", sl, hipGetErrorString(je));
+      err = g_err;
+    }
   }
   if (rc_all != DEXR_OK) g_err = err;
   return rc_all;

@@ -7,13 +7,9 @@ namespace dexr {
 size_t gen_lds_bytes(const GenTab& tb) { return gen_lds_doubles(tb.nj, tb.nf, tb.nt, tb.nv, tb.nfam) * sizeof(double); }
 
 template <int MODE> static hipError_t launch_gen_mode(const KernelParams& kp, const GenTab& tb, dim3 grid, size_t lds, hipStream_t st) {
-  static size_t configured = 0;  // dynamic LDS above 64 KB has to be requested once per kernel
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dexr_gen_kernel<MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    configured = lds;
-  }
+  static DynLds dyn;
+  hipError_t e = dyn.ensure(reinterpret_cast<const void*>(&dexr_gen_kernel<MODE>), lds);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL((dexr_gen_kernel<MODE>), grid, dim3(64), lds, st, kp, tb);
   return hipGetLastError();
 }

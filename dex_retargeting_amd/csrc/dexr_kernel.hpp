@@ -20,6 +20,9 @@
 
 #include "dexr_tables.h"
 
+#ifndef DEXR_TIP64_MINW
+#define DEXR_TIP64_MINW 2  // float64 tip kernel: waves per SIMD requested (256 VGPRs)
+#endif
 #ifndef DEXR_CHAIN_MINW
 #define DEXR_CHAIN_MINW 4  // minimum waves per SIMD requested for the serial-chain kernel (caps its VGPR budget at 128)
 #endif
@@ -126,6 +129,29 @@ struct WideTable {
 #define SPROF_START()
 #define SPROF_STAGE(i)
 #define SPROF_FLUSH()
+#endif
+
+// -DDEXR_WAVE_TRACE=1 (tools/wave_trace.sh; never in the shipped library): every wave of a small-component solve launch
+// records, on the 100 MHz wall clock (s_memrealtime: one time base for all XCDs), when it started, when its first frames
+// were loaded, the end of each of its first 16 passes, when it retired, how many passes it ran and where it ran
+// (HW_ID / XCC_ID): 24 doubles per wave in kp.g64out -- what a launch's duration is made of (dispatch ramp, first loads,
+// passes under contention, tail).
+#ifdef DEXR_WAVE_TRACE
+#define WTRACE_DECL long long wt_t0 = wall_clock64(), wt_t1 = 0, wt_p[16]; int wt_n = 0;
+#define WTRACE_LOADED() if (wt_t1 == 0) wt_t1 = wall_clock64();
+#define WTRACE_PASS() { if (wt_n < 16) wt_p[wt_n] = wall_clock64(); ++wt_n; }
+#define WTRACE_FLUSH()                                                                              \
+  if (lane == 0 && kp.g64out) {                                                                     \
+    double* o = kp.g64out + (size_t)wave_global * 24;                                               \
+    o[0] = (double)wt_t0; o[1] = (double)wt_t1; o[2] = (double)wall_clock64(); o[3] = (double)wt_n; \
+    o[4] = (double)__builtin_amdgcn_s_getreg(63492); o[5] = (double)__builtin_amdgcn_s_getreg(63508); \
+    for (int i = 0; i < 16; ++i) o[8 + i] = i < wt_n ? (double)wt_p[i] : 0.0;                       \
+  }
+#else
+#define WTRACE_DECL
+#define WTRACE_LOADED()
+#define WTRACE_PASS()
+#define WTRACE_FLUSH()
 #endif
 
 enum { MODE_SOLVE = 0, MODE_EVAL = 1, MODE_FK = 2 };
@@ -594,10 +620,11 @@ struct LaneSolver {
 // EXT = true adds the extended addressing of KernelParams (fleet buckets, frame sequences).  The small-component
 // kernels are instantiated both ways so that the plain single-model launch keeps its register budget; the large ones
 // always carry it.
-// TIP = true (CHAIN, 4 joints, float32 solve only): every component is a tip component and its pass is dexr_tip.hpp's.
+// TIP = true (CHAIN, 4 joints, solve only): every component is a tip component and its pass is dexr_tip.hpp's (float32:
+// packed arithmetic, constants pinned; float64 since round 4: the reference's own arithmetic type on the same pass).
 template <int NMAX, typename real, int MODE, bool CHAIN = false, bool EXT = (NMAX > 8), bool TIP = false>
-__global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4) ? DEXR_CHAIN_MINW : 1) dexr_kernel(const KernelParams kp, const dexr_comp_table* __restrict__ comps) {
-  static_assert(!TIP || (CHAIN && NMAX == 4 && sizeof(real) == 4 && MODE == MODE_SOLVE), "tip pass: 4-joint float32 chain solve only");
+__global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4) ? DEXR_CHAIN_MINW : (TIP ? DEXR_TIP64_MINW : 1)) dexr_kernel(const KernelParams kp, const dexr_comp_table* __restrict__ comps) {
+  static_assert(!TIP || (CHAIN && NMAX == 4 && MODE == MODE_SOLVE), "tip pass: 4-joint chain solve only");
   extern __shared__ __align__(16) unsigned char lds_raw[];
   using LS = LaneSolver<NMAX, real, CHAIN>;
   using RT = RealTraits<real>;
@@ -678,6 +705,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
 
   // column of last_qpos / qpos_out of local joint k.  A tip component's four joints are consecutive columns (checked when the
   // kernel is selected): one pinned base index instead of four table loads, and the per-joint addresses share one base
+  constexpr bool TIP32 = TIP && sizeof(real) == 4;  // the float32 tip kernel prunes every path only float64 launches take
   const int tip_api0 = TIP ? tip_pin((int)tb.api[0]) : 0;
   auto api_of = [&](int k) -> int { if constexpr (TIP) return tip_api0 + k; else return tb.api[k]; };
 
@@ -702,7 +730,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
           real v;
           if (MODE == MODE_EVAL) v = (real)kp.xin[it * kp.n_opt + api_of(k)];
           else if (carry) v = (real)(float)prev;  // the reference carries the float32 result (optimizer.py:99)
-          else if (!TIP && kp.x0) v = (real)kp.x0[r0 * ld + api_of(k)];  // (float64 polish launches only)
+          else if (!TIP32 && kp.x0) v = (real)kp.x0[r0 * ld + api_of(k)];  // (float64 polish launches only)
           else v = (real)kp.last[r0 * ld + api_of(k)];
           real l = carry ? v : (real)kp.last[r0 * ld + api_of(k)];
           if (seq) {  // seq_retarget.py:118-120: last_qpos clipped to the joint limits before every solve
@@ -837,16 +865,17 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
     // re-solve with more damping.
     auto run = [&](const auto& tbl) {
     // loop-invariant scalars of the pass; the tip kernel pins them in SGPRs (a kernel-argument load + wait each otherwise)
-    auto hot = [](float v) -> float { if constexpr (TIP) return tip_pin(v); else return v; };
-    auto hoti = [](int v) -> int { if constexpr (TIP) return tip_pin(v); else return v; };
+    constexpr bool PIN = TIP && sizeof(real) == 4;  // (the float64 tip kernel does not pin: SGPR pairs run out)
+    auto hot = [](float v) -> float { if constexpr (PIN) return tip_pin(v); else return v; };
+    auto hoti = [](int v) -> int { if constexpr (PIN) return tip_pin(v); else return v; };
     const real k_lam0 = (real)hot(kp.lam0), k_tol = (real)hot(kp.tol), k_blind_tol = (real)hot(kp.blind_tol);
     const real k_step_cap = (real)hot(kp.step_cap), k_lam_jump = (real)hot(kp.lam_jump), k_lam_fastdec = (real)hot(kp.lam_fastdec);
     const real k_lam_recover = (real)hot(kp.lam_recover), k_stall_ratio = (real)hot(kp.stall_ratio), k_stall_cap = (real)hot(kp.stall_cap);
     const int k_stall_from = hoti(kp.stall_from), k_max_blind = hoti(kp.max_blind), k_max_iter = hoti(kp.max_iter);
     const real k_delta = (real)hot((float)delta);
     // (tip kernel) loss constants of the component's single term
-    const float tip_beta = hot(kp.huber_delta), tip_ibeta = hot(1.f / kp.huber_delta), tip_w = hot(kp.inv_norm);
-    const float tip_nw = hot(kp.newton != 0 ? 1.f : 0.f);
+    const real tip_beta = (real)hot(kp.huber_delta), tip_ibeta = sizeof(real) == 4 ? (real)hot(1.f / kp.huber_delta) : (real)1 / (real)kp.huber_delta;
+    const real tip_w = (real)hot(kp.inv_norm), tip_nw = (real)hot(kp.newton != 0 ? 1.f : 0.f);
     const unsigned QCHUNK = kp.qchunk;
     real Hs[LS::NH], gs[NMAX], xo[NMAX];
     real F = 0, lam = k_lam0, nu = 2, sprev = (real)1e30;
@@ -869,6 +898,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
     }
     unsigned* queue = kp.queue + comp;
     SPROF_DECL
+    WTRACE_DECL
 
     for (;;) {
       SPROF_START();
@@ -916,6 +946,14 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
         continue;
       }
       SPROF_STAGE(0)
+      WTRACE_LOADED()
+#ifdef DEXR_PRIO
+      // experiment (not in the shipped library unless it measures): waves that still hold frames past DEXR_PRIO passes, or
+      // frames that saw a rejected step, are the launch's critical path -- give them VALU issue priority over the waves
+      // they share a SIMD with
+      if (__any(has && (my_iters >= DEXR_PRIO || nrej > 0))) __builtin_amdgcn_s_setprio(3);
+      else __builtin_amdgcn_s_setprio(0);
+#endif
 
       // (2) step from the accepted model (lanes holding a fresh frame evaluate their start point instead)
       real smax = 0, pred = 0;
@@ -982,7 +1020,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
       SPROF_STAGE(1)
       real Ft;
       if constexpr (TIP) {
-        Ft = tip_eval(tbl, S.x, T[lane], T[64 + lane], T[128 + lane], tip_beta, tip_ibeta, tip_w, tip_nw, S.g, S.H);
+        Ft = tip_eval<real>(tbl, S.x, T[lane], T[64 + lane], T[128 + lane], tip_beta, tip_ibeta, tip_w, tip_nw, S.g, S.H);
         SPROF_STAGE(2)
       } else {
         S.fk(tb, nj, P, lane);
@@ -1077,6 +1115,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
           if (!finished && my_iters >= k_max_iter) finished = true;  // status stays ST_MAXITER
         }
       }
+      WTRACE_PASS()
 #pragma unroll
       for (int k = 0; k < NMAX; ++k) {
         S.x[k] = accept ? S.x[k] : xo[k];
@@ -1104,7 +1143,7 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
             const real v = bad ? S.xl[k] : S.x[k];
             S.x[k] = v;  // (sequence mode: the value the next frame starts from)
             kp.qout[orow * ld + api_of(k)] = (float)v;
-            if (!TIP && kp.qout64) kp.qout64[orow * ld + api_of(k)] = (double)v;  // (float64 launches only)
+            if (!TIP32 && kp.qout64) kp.qout64[orow * ld + api_of(k)] = (double)v;  // (float64 launches only)
           }
         }
         if (kp.status) atomicMax(&kp.status[orow], status);
@@ -1132,9 +1171,10 @@ __global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4)
       SPROF_STAGE(5)
     }
     SPROF_FLUSH()
+    WTRACE_FLUSH()
     };
     if constexpr (TIP) {
-      TipTab tt;  // every constant of the pass pinned in SGPRs (dexr_tip.hpp)
+      TipTabT<real> tt;  // float32: every constant of the pass pinned in SGPRs (dexr_tip.hpp)
       tt.load(tb, tb.term_task[0], tb.term_origin[0], W + 64 * kp.lds_terms, lane);
       run(tt);
     } else if constexpr (CHAIN) {

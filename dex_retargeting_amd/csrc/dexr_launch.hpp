@@ -2,9 +2,32 @@
 // (each lives in its own translation unit, see dexr_inst.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <mutex>
+
 #include "dexr_kernel.hpp"
 
 namespace dexr {
+// Dynamic LDS above 64 KB has to be requested per kernel AND per device (hipFuncSetAttribute acts on the current device's
+// copy of the function).  One DynLds per kernel instantiation caches the largest size granted so far on each device, under
+// a lock: model handles are created and launched from several host threads, and one process may drive several GPUs.
+struct DynLds {
+  static constexpr int MAX_DEV = 64;
+  size_t configured[MAX_DEV] = {};
+  std::mutex mu;
+  hipError_t ensure(const void* kernel, size_t lds) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    const bool known = dev >= 0 && dev < MAX_DEV;
+    if (known && lds <= configured[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess && known) configured[dev] = lds;
+    return e;
+  }
+};
+
 typedef hipError_t (*launch_fn)(const KernelParams& kp, dim3 grid, dim3 block, size_t lds, hipStream_t st);
 
 #define DEXR_DECL_F32(N) hipError_t launch_##N##_0_0(const KernelParams&, dim3, dim3, size_t, hipStream_t); /* f32 solve */
@@ -35,6 +58,8 @@ hipError_t launch_ext_chain_4_0_0(const KernelParams&, dim3, dim3, size_t, hipSt
 // tip specialisation of the serial-chain kernel (dexr_tip.hpp): one vector term from a base frame to a frame on the last joint
 hipError_t launch_tip_4_0_0(const KernelParams&, dim3, dim3, size_t, hipStream_t);
 hipError_t launch_ext_tip_4_0_0(const KernelParams&, dim3, dim3, size_t, hipStream_t);
+hipError_t launch_tip_4_1_0(const KernelParams&, dim3, dim3, size_t, hipStream_t);      // the same pass in float64
+hipError_t launch_ext_tip_4_1_0(const KernelParams&, dim3, dim3, size_t, hipStream_t);
 
 // large-component kernel (dexr_big.hpp): float64 kinematics + float32 Hessian in LDS
 hipError_t launch_big_16(const KernelParams&, dim3, dim3, size_t, hipStream_t);
@@ -83,7 +108,8 @@ hipError_t launch_gen(int mode, const KernelParams& kp, const GenTab& tb, dim3 g
 size_t gen_lds_bytes(const GenTab& tb);
 
 static inline launch_fn find_launcher(int bucket, int f64, int mode, bool chain = false, bool ext = false, bool tip = false) {
-  if (tip && chain && bucket == 4 && !f64 && mode == MODE_SOLVE) return ext ? launch_ext_tip_4_0_0 : launch_tip_4_0_0;
+  if (tip && chain && bucket == 4 && mode == MODE_SOLVE)
+    return f64 ? (ext ? launch_ext_tip_4_1_0 : launch_tip_4_1_0) : (ext ? launch_ext_tip_4_0_0 : launch_tip_4_0_0);
   if (ext && mode == MODE_SOLVE && bucket <= 8) {
     if (chain && bucket == 4 && !f64) return launch_ext_chain_4_0_0;
     if (bucket == 4) return f64 ? launch_ext_4_1_0 : launch_ext_4_0_0;

@@ -12,13 +12,9 @@ namespace dexr {
 #define DEXR_QCAT(a, b) DEXR_QCAT_(a, b)
 
 hipError_t DEXR_QCAT(launch_quad_, DEXR_NMAX)(const KernelParams& kp, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  static size_t configured = 0;  // dynamic LDS above 64 KB has to be requested once per kernel
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dexr_quad_kernel<DEXR_NMAX>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    configured = lds;
-  }
+  static DynLds dyn;  // dynamic LDS above 64 KB: requested per kernel and per device (dexr_launch.hpp)
+  hipError_t e = dyn.ensure(reinterpret_cast<const void*>(&dexr_quad_kernel<DEXR_NMAX>), lds);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL((dexr_quad_kernel<DEXR_NMAX>), grid, block, lds, st, kp, kp.comps);
   return hipGetLastError();
 }

@@ -11,13 +11,9 @@ namespace dexr {
 #define DEXR_RCAT_(a, b) a##b
 #define DEXR_RCAT(a, b) DEXR_RCAT_(a, b)
 hipError_t DEXR_RCAT(launch_red_, DEXR_NV)(const KernelParams& kp, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  static size_t configured = 0;  // dynamic LDS above 64 KB has to be requested once per kernel
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dexr_red_kernel<DEXR_NV>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    configured = lds;
-  }
+  static DynLds dyn;  // dynamic LDS above 64 KB: requested per kernel and per device (dexr_launch.hpp)
+  hipError_t e = dyn.ensure(reinterpret_cast<const void*>(&dexr_red_kernel<DEXR_NV>), lds);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL((dexr_red_kernel<DEXR_NV>), grid, block, lds, st, kp, kp.comps);
   return hipGetLastError();
 }

@@ -19,14 +19,24 @@
 //   * sines / cosines of the four joint angles evaluated two at a time, reduced by pi instead of pi/2 (one sign flip
 //     instead of a quadrant selection).
 // No scalar loads, no branches; LDS only for the target and the broadcast constants.
+//
+// Round 4: the same pass in FLOAT64 (TipTabT<double> / tip_eval<double>: the reference's own arithmetic type,
+// optimizer.py:249-304).  The formulas are the ones above written on a two-component vector type, which is a register
+// pair of v_pk_* operands for float and simply two scalars (v_fma_f64 each) for double; constants are not pinned there
+// (46+ SGPR pairs do not fit) -- joint 0 / offset / box come from the tables as scalar loads hoisted by the compiler, the
+// placements of joints 1..3 are broadcast from LDS as doubles.
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "dexr_math.hpp"
 #include "dexr_tables.h"
 
 namespace dexr {
 
 typedef float kv2 __attribute__((ext_vector_type(2)));  // a register pair: operands of v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+template <typename R> struct TipVec;
+template <> struct TipVec<float> { typedef float v2 __attribute__((ext_vector_type(2))); };
+template <> struct TipVec<double> { typedef double v2 __attribute__((ext_vector_type(2))); };
 
 // A wave-uniform value the compiler must KEEP (in an SGPR, or a VGPR lane when those run out): the empty asm makes its source
 // opaque (a vector register of unknown contents), so the readfirstlane can neither be folded back into the kernel-argument /
@@ -37,6 +47,12 @@ static __device__ __forceinline__ int tip_pin(int v) {
 }
 static __device__ __forceinline__ float tip_pin(float v) { return __int_as_float(tip_pin(__float_as_int(v))); }
 static __device__ __forceinline__ kv2 tip_splat(float v) { return kv2{v, v}; }
+static __device__ __forceinline__ typename TipVec<double>::v2 tip_splat(double v) { return typename TipVec<double>::v2{v, v}; }
+// constants of the float32 pass are pinned; the float64 pass takes them as they come (see the header)
+template <typename R> static __device__ __forceinline__ R tip_const(float v) {
+  if constexpr (sizeof(R) == 4) return tip_pin(v);
+  else return (R)v;
+}
 
 // Wave-uniform constants of one tip component.  The origin frame's position is folded into the first joint's placement:
 // every world position below is relative to it, which leaves the residual, the Jacobian and the Hessian unchanged.
@@ -44,41 +60,44 @@ static __device__ __forceinline__ kv2 tip_splat(float v) { return kv2{v, v}; }
 // kernel's scalar state past the 102 SGPRs a wave has (spilled to VGPR lanes: a v_readlane per use, measured 80 per pass), so
 // they sit in 144 bytes of the wave's LDS, already paired, and are read where they are used (ds_read_b64 of a wave-uniform
 // address: a broadcast, no VALU slot).
-struct TipTab {
-  kv2 A0[3];        // joint 0 (its parent is the base, R = I): (X0[i][0], X0[i][1])
-  float c0[3];      // X0[i][2]: joint 0's axis
-  float p0[3];      // X0's translation - origin frame position
-  const kv2* xl;    // LDS, joints k = 1..3:  xl[6 (k-1) + j]     = (Xk[j][0], Xk[j][1])   (row j of the placement's rotation)
+template <typename R>
+struct TipTabT {
+  typedef typename TipVec<R>::v2 v2;
+  v2 A0[3];         // joint 0 (its parent is the base, R = I): (X0[i][0], X0[i][1])
+  R c0[3];          // X0[i][2]: joint 0's axis
+  R p0[3];          // X0's translation - origin frame position
+  const v2* xl;     // LDS, joints k = 1..3:  xl[6 (k-1) + j]     = (Xk[j][0], Xk[j][1])   (row j of the placement's rotation)
                     //                        xl[6 (k-1) + 3 + j] = (Xk[j][2], Xk's translation[j])
-  float off[3];     // task frame origin in the last joint's frame
-  float lo[4], hi[4];
-  __device__ __forceinline__ kv2 XA(int k1, int j) const { return xl[6 * k1 + j]; }
-  __device__ __forceinline__ kv2 XB(int k1, int j) const { return xl[6 * k1 + 3 + j]; }
+  R off[3];         // task frame origin in the last joint's frame
+  R lo[4], hi[4];
+  __device__ __forceinline__ v2 XA(int k1, int j) const { return xl[6 * k1 + j]; }
+  __device__ __forceinline__ v2 XB(int k1, int j) const { return xl[6 * k1 + 3 + j]; }
 
-  // `ft`: task frame (on joint 3); `fo`: origin frame on the base, or -1; `lds`: 36 floats of the wave's LDS
-  __device__ __forceinline__ void load(const dexr_comp_table& tb, int ft, int fo, float* lds, int lane) {
+  // `ft`: task frame (on joint 3); `fo`: origin frame on the base, or -1; `lds`: 36 reals of the wave's LDS
+  __device__ __forceinline__ void load(const dexr_comp_table& tb, int ft, int fo, R* lds, int lane) {
     if (lane < 36) {
       const int q = lane >> 1, h = lane & 1, k = q / 6 + 1, jj = q % 6;
       const int src = jj < 3 ? 3 * jj + h : (h == 0 ? 3 * (jj - 3) + 2 : 9 + (jj - 3));
-      lds[lane] = (&tb.X[0][0])[k * 12 + src];
+      lds[lane] = (R)(&tb.X[0][0])[k * 12 + src];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    xl = reinterpret_cast<const kv2*>(lds);
+    xl = reinterpret_cast<const v2*>(lds);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      A0[i] = kv2{tip_pin(tb.X[0][3 * i]), tip_pin(tb.X[0][3 * i + 1])};
-      c0[i] = tip_pin(tb.X[0][3 * i + 2]);
-      p0[i] = tip_pin(tb.X[0][9 + i] - (fo >= 0 ? tb.frame_off[fo][i] : 0.f));
-      off[i] = tip_pin(tb.frame_off[ft][i]);
+      A0[i] = v2{tip_const<R>(tb.X[0][3 * i]), tip_const<R>(tb.X[0][3 * i + 1])};
+      c0[i] = tip_const<R>(tb.X[0][3 * i + 2]);
+      p0[i] = tip_const<R>(tb.X[0][9 + i] - (fo >= 0 ? tb.frame_off[fo][i] : 0.f));
+      off[i] = tip_const<R>(tb.frame_off[ft][i]);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      lo[k] = tip_pin(tb.lo[k]);
-      hi[k] = tip_pin(tb.hi[k]);
+      lo[k] = tip_const<R>(tb.lo[k]);
+      hi[k] = tip_const<R>(tb.hi[k]);
     }
   }
 };
+typedef TipTabT<float> TipTab;
 
 // sin / cos of two angles at once.  Reduction by pi (k = rint(a / pi), two-constant Cody-Waite: 3.140625 has 9 significant
 // bits, so k * 3.140625 is exact), minimax polynomials of degree 9 / 10 on [-pi/2, pi/2] (fitted in float64; errors
@@ -102,21 +121,34 @@ static __device__ __forceinline__ void tip_sincos2(kv2 a, kv2* s, kv2* c) {
   *c = kv2{__int_as_float(__float_as_int(cp.x) ^ sx), __int_as_float(__float_as_int(cp.y) ^ sy)};
 }
 
+// float64: both angles through the shared Cody-Waite / fdlibm routine (dexr_math.hpp)
+static __device__ __forceinline__ void tip_sincos2(typename TipVec<double>::v2 a, typename TipVec<double>::v2* s,
+                                                   typename TipVec<double>::v2* c) {
+  double s0, c0, s1, c1;
+  sincos_f64(a.x, &s0, &c0);
+  sincos_f64(a.y, &s1, &c1);
+  *s = typename TipVec<double>::v2{s0, s1};
+  *c = typename TipVec<double>::v2{c0, c1};
+}
+
 // One pass at x: returns the data term (reference "huber_distance", no regulariser), writes its gradient g and the lower
 // triangle of its Hessian H (hidx order: 00 | 10 11 | 20 21 22 | 30 31 32 33).  t0..t2: the lane's target (origin folded, see
 // TipTab); w: the 'mean' factor; nw: 1 with the second-order kinematic term (Newton), 0 without.
-static __device__ __forceinline__ float tip_eval(const TipTab& tt, const float (&x)[4], float t0, float t1, float t2,
-                                                 float beta, float ibeta, float w, float nw,
-                                                 float (&g)[4], float (&H)[10]) {
+template <typename R>
+static __device__ __forceinline__ R tip_eval(const TipTabT<R>& tt, const R (&x)[4], R t0, R t1, R t2,
+                                             R beta, R ibeta, R w, R nw,
+                                             R (&g)[4], R (&H)[10]) {
+  typedef typename TipVec<R>::v2 kv2;  // (shadows the float pair: every formula below is written on this type)
+  typedef R RR;
   kv2 sA, cA, sB, cB;  // joints (0,1) and (2,3)
   tip_sincos2(kv2{x[0], x[1]}, &sA, &cA);
   tip_sincos2(kv2{x[2], x[3]}, &sB, &cB);
-  const float sn[4] = {sA.x, sA.y, sB.x, sB.y}, cs[4] = {cA.x, cA.y, cB.x, cB.y};
+  const RR sn[4] = {sA.x, sA.y, sB.x, sB.y}, cs[4] = {cA.x, cA.y, cB.x, cB.y};
 
   // ---- forward kinematics -------------------------------------------------------------------------------------------
   kv2 rp[3];      // (R[i][0], R[i][1]) of the running rotation
-  float r2[3];    // R[i][2]
-  float p[3];     // running origin
+  RR r2[3];    // R[i][2]
+  RR p[3];     // running origin
   kv2 ao[4][3];   // (axis component i, origin component i) of joint k
   {
     const kv2 sc = kv2{sn[0], -sn[0]};
@@ -151,23 +183,27 @@ static __device__ __forceinline__ float tip_eval(const TipTab& tt, const float (
     }
   }
   // task frame: origin_3 + (Rn Rz(q3)) off = origin_3 + Rn (Rz off)
-  const float ox = cs[3] * tt.off[0] - sn[3] * tt.off[1], oy = sn[3] * tt.off[0] + cs[3] * tt.off[1];
-  float pt[3];
+  const RR ox = cs[3] * tt.off[0] - sn[3] * tt.off[1], oy = sn[3] * tt.off[0] + cs[3] * tt.off[1];
+  RR pt[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) pt[i] = ao[3][i].y + n01[i].x * ox + n01[i].y * oy + ao[3][i].x * tt.off[2];
 
   // ---- residual (LaneSolver::residuals' vector-norm branch) -------------------------------------------------------------
-  const float r[3] = {pt[0] - t0, pt[1] - t1, pt[2] - t2};
+  const RR r[3] = {pt[0] - t0, pt[1] - t1, pt[2] - t2};
   // SmoothL1 of the vector norm (optimizer.py:272-273); 1-ulp v_sqrt / v_rcp
-  const float d2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-  const float d = __builtin_amdgcn_sqrtf(d2);
+  const RR d2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  RR d;
+  if constexpr (sizeof(R) == 4) d = __builtin_amdgcn_sqrtf(d2);
+  else d = ::sqrt(d2);
   const bool quad = d < beta;
-  const float F = w * (quad ? 0.5f * d2 * ibeta : d - 0.5f * beta);
-  const float id = quad ? ibeta : __builtin_amdgcn_rcpf(d);  // d >= beta > 0 in the linear branch
-  const float psi = w * id;
-  const float fvec[3] = {psi * r[0], psi * r[1], psi * r[2]};
-  const float kap = quad ? 0.f : psi * id * id;
-  const float fn[3] = {nw * fvec[0], nw * fvec[1], nw * fvec[2]};
+  const RR F = w * (quad ? (RR)0.5 * d2 * ibeta : d - (RR)0.5 * beta);
+  RR id;  // d >= beta > 0 in the linear branch
+  if constexpr (sizeof(R) == 4) id = quad ? ibeta : __builtin_amdgcn_rcpf(d);
+  else id = quad ? ibeta : (RR)1 / d;
+  const RR psi = w * id;
+  const RR fvec[3] = {psi * r[0], psi * r[1], psi * r[2]};
+  const RR kap = quad ? (RR)0 : psi * id * id;
+  const RR fn[3] = {nw * fvec[0], nw * fvec[1], nw * fvec[2]};
 
   // ---- Jacobian columns, gradient, Hessian: joint pairs A = (0,1), B = (2,3) ----------------------------------------------
   kv2 axA[3], ogA[3], axB[3], ogB[3];
@@ -202,7 +238,7 @@ static __device__ __forceinline__ float tip_eval(const TipTab& tt, const float (
   g[0] = gA.x; g[1] = gA.y; g[2] = gB.x; g[3] = gB.y;
 
   // entries (r, c) and (r, c + 1) of row r against the joint pair Q = (c, c + 1)
-  auto rowpair = [&](float cw0, float cw1, float cw2, float ku, float cf0, float cf1, float cf2, const kv2 (&colQ)[3],
+  auto rowpair = [&](RR cw0, RR cw1, RR cw2, RR ku, RR cf0, RR cf1, RR cf2, const kv2 (&colQ)[3],
                      const kv2& uQ, const kv2 (&axQ)[3]) -> kv2 {
     return colQ[0] * cw0 + colQ[1] * cw1 + colQ[2] * cw2 - uQ * ku + axQ[0] * cf0 + axQ[1] * cf1 + axQ[2] * cf2;
   };

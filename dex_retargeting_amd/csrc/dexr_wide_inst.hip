@@ -27,13 +27,9 @@ namespace dexr {
 #define DEXR_WCAT(a, b) DEXR_WCAT_(a, b)
 
 hipError_t DEXR_WNAME(launch_wide_)(const KernelParams& kp, const WideTable* wt, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  static size_t configured = 0;  // dynamic LDS above 64 KB has to be requested once per kernel
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dexr_wide_kernel<DEXR_NMAX, (DEXR_MIMIC != 0), (DEXR_MODCHOL != 0)>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    configured = lds;
-  }
+  static DynLds dyn;  // dynamic LDS above 64 KB: requested per kernel and per device (dexr_launch.hpp)
+  hipError_t e = dyn.ensure(reinterpret_cast<const void*>(&dexr_wide_kernel<DEXR_NMAX, (DEXR_MIMIC != 0), (DEXR_MODCHOL != 0)>), lds);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL((dexr_wide_kernel<DEXR_NMAX, (DEXR_MIMIC != 0), (DEXR_MODCHOL != 0)>), grid, block, lds, st, kp, kp.comps, wt);
   return hipGetLastError();
 }

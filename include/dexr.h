@@ -105,7 +105,17 @@ typedef struct dexr_tuning {
                            `stream` by an event and joined before the call returns, so that they fill the CUs the big
                            launch's tail leaves idle (further big models get internal streams of their own).  1 on, 0 off
                            (everything on `stream`), -1 policy (on)                                                     */
+  uint32_t user_mask;   /* which damping fields are CALLER OVERRIDES: DEXR_TUNE_LAM_JUMP, DEXR_TUNE_LAM_FASTDEC.  Their
+                           defaults depend on the kernel family a launch dispatches (they scale different quantities per
+                           family), so dexr_model_get_tuning reports the value in use for the selected family with the bit
+                           CLEAR, and dexr_model_set_tuning takes lam_jump / lam_fastdec as an override -- which then holds
+                           for every family -- only when the bit is SET; with the bit clear the field is ignored and any
+                           earlier override is dropped.  (Until round 3 an override was inferred from "differs from the
+                           reported value", which pinned stale values of re-used structs and made defaults sticky.)
+                           A caller whose (older) struct ends before this field leaves the override state untouched.   */
 } dexr_tuning;
+#define DEXR_TUNE_LAM_JUMP 1u
+#define DEXR_TUNE_LAM_FASTDEC 2u
 
 const char* dexr_last_error(void);
 const char* dexr_version(void);

@@ -6,20 +6,22 @@ own float64 kernel.
 Bar (BASELINE.json north_star: 1e-4 rad per joint): every frame's qpos is within 1e-4 rad of the oracle's, or the two
 answers are DIFFERENT local minima (human targets are multi-modal: e.g. a mimic finger whose objective has a minimum at
 either joint limit) and the GPU's is certified: a tight float64 minimisation of F started AT the GPU answer neither
-moves it by 1e-4 rad nor lowers F.  Of those other-minimum frames the GPU's is usually the better one; where it is the
-worse one the oracle's undamped Newton step has leapt across the joint range while the GPU's trust radius (0.3 rad per
-step) kept it in the basin of the start point -- which is also where the REFERENCE-AS-CONFIGURED SLSQP ends up (83 % of
-363 such frames, 10 % in the oracle's basin; column "slsqp@gpu").  The per-config table is written to
-gpurun_out/all_configs_parity.txt.
+moves it by 1e-4 rad nor lowers F.  HOW MANY such frames a config may have is pinned PER CONFIG in
+tests/golden/parity_ceilings.json ("far": frames >= 1e-4 rad from the oracle, "worse": those whose certified minimum has
+the higher F): the measured count of the round it was last refreshed in plus a small margin, and ZERO for every config
+that measured zero -- the headline config cannot regress from 0 to 80 far frames and stay green.
+Round 4: the oracle's LM only steps from positive-definite models (oracle/solvers.py docstring,
+tests/test_oracle.py::test_lm_oracle_stays_in_the_basin_slsqp_converges_to); the table keeps a column with the counts
+against the rounds 1-3 oracle.  The per-config table is written to gpurun_out/all_configs_parity.txt, the measured
+counts to gpurun_out/parity_ceilings_measured.json.
 
 Second part: distance to the REFERENCE-AS-CONFIGURED answers (SLSQP with ftol_abs 1e-6/1e-5 driven by the reference's
 value-without / gradient-with-regulariser pair, optimizer.py:96-99,136,239,397): reported, and F(q_gpu) <= F(q_slsqp)
 asserted -- the GPU returns the point the reference's gradient field defines, SLSQP stops ~1e-2 rad short of it.
 """
 import glob
-import multiprocessing as mp
+import json
 import os
-from concurrent.futures import ProcessPoolExecutor
 
 import numpy as np
 import pytest
@@ -36,11 +38,8 @@ ALL = sorted(os.path.relpath(p, cases.CONFIG_DIR) for p in glob.glob(os.path.joi
 B = 4096
 TOL = 1e-4
 BASELINE3 = ["teleop/allegro_hand_right.yml", "teleop/shadow_hand_right_dexpilot.yml", "offline/leap_hand_right.yml"]
-
-
-def _pool():
-    n = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 48)
-    return ProcessPoolExecutor(max_workers=max(1, n), mp_context=mp.get_context("spawn"))
+CEILINGS = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parity_ceilings.json")))
+_pool = oracle_jobs.host_pool
 
 
 def _gpu_solve(rel, n):
@@ -63,7 +62,15 @@ def table(require_gpu):
     """GPU phase for all configs, then the oracle phase fanned over host cores."""
     runs = {rel: _gpu_solve(rel, B) for rel in ALL}
     with _pool() as ex:
-        res = list(ex.map(oracle_jobs.oracle_solve, [(rel, r["ref"], r["last"], r["st_in"], r["q"]) for rel, r in runs.items()]))
+        # chunks of 512 frames per job: 39 x 8 jobs keep every host core busy
+        jobs = [(rel, slice(i, i + 512)) for rel in runs for i in range(0, B, 512)]
+        parts = list(ex.map(oracle_jobs.oracle_solve,
+                            [(rel, runs[rel]["ref"][c], runs[rel]["last"][c], None if runs[rel]["st_in"] is None else runs[rel]["st_in"][c],
+                              runs[rel]["q"][c], True) for rel, c in jobs]))
+        res = []
+        for rel in runs:
+            mine = [p for (r_, _), p in zip(jobs, parts) if r_ == rel]
+            res.append({k: np.concatenate([p[k] for p in mine]) for k in mine[0]})
         rows = {}
         todo = []
         for (rel, r), o in zip(runs.items(), res):
@@ -71,7 +78,8 @@ def table(require_gpu):
             far = dq >= TOL
             not_worse = far & (o["F_gpu"] <= o["F_want"] + 1e-10)
             rest = np.nonzero(far & ~not_worse)[0]
-            rows[rel] = dict(dq=dq, far=far, not_worse=not_worse, rest=rest, o=o, r=r)
+            rows[rel] = dict(dq=dq, far=far, not_worse=not_worse, rest=rest, o=o, r=r,
+                             far_r3=int((np.abs(r["q"] - o["want_r3"]).max(1) >= TOL).sum()))
             if far.any():  # every excuse is certified (up to 64 frames per config, the furthest first)
                 sel = np.nonzero(far)[0]
                 sel = sel[np.argsort(-dq[sel])][:64]
@@ -111,13 +119,17 @@ def table(require_gpu):
     np.savez_compressed(os.path.join(out, "all_configs_far_frames.npz"), **dump)
     with open(os.path.join(out, "all_configs_parity.txt"), "w") as f:
         f.write(f"# {B} frames per config, library defaults; dq = max_j |q_gpu - q_oracle| (float64 oracle LM/Newton on F)\n")
+        f.write(f"# oracle: LM steps from positive-definite models only (round 4); '>=1e-4 r3' = the count against the rounds 1-3 oracle\n")
         f.write(f"{'config':44s} {'kernel':>14s} {'p50 dq':>9s} {'p99.9 dq':>9s} {'max dq':>9s} {'>=1e-4':>7s} {'not worse':>9s} "
-                f"{'worse':>6s} {'cert moved':>10s} {'status!=0':>9s} {'slsqp@gpu/@oracle of':>22s}\n")
+                f"{'worse':>6s} {'cert moved':>10s} {'status!=0':>9s} {'slsqp@gpu/@oracle of':>22s} {'>=1e-4 r3':>10s}\n")
         for rel, w in rows.items():
             f.write(f"{rel:44s} {str(w['r']['kernel']):>14s} {np.median(w['dq']):9.1e} {np.percentile(w['dq'], 99.9):9.1e} "
                     f"{w['dq'].max():9.1e} {int(w['far'].sum()):7d} {int(w['not_worse'].sum()):9d} {len(w['rest']):6d} "
                     f"{(w['cert'][1].max() if 'cert' in w else 0.0):10.1e} {int((w['r']['info']['status'] != 0).sum()):9d} "
-                    + (f"{w['slsqp'][1]:>8d}/{w['slsqp'][2]}/{w['slsqp'][0]}" if "slsqp" in w else f"{'-':>12s}") + "\n")
+                    + (f"{w['slsqp'][1]:>8d}/{w['slsqp'][2]}/{w['slsqp'][0]}" if "slsqp" in w else f"{'-':>12s}")
+                    + f" {w['far_r3']:10d}\n")
+    json.dump({rel: {"far": int(w["far"].sum()), "worse": len(w["rest"])} for rel, w in rows.items()},
+              open(os.path.join(out, "parity_ceilings_measured.json"), "w"), indent=1)
     return rows
 
 
@@ -125,14 +137,24 @@ def table(require_gpu):
 def test_default_options_meet_1e4_rad_against_oracle(rel, table):
     w = table[rel]
     assert (w["r"]["info"]["status"] != 2).all()
-    # (1) same minimum: within tolerance.  (2) other minimum: certified (test_no_flat_valley_excuses).  Frames in which
-    # the GPU's certified minimum is the worse of the two stay below 1 % of the batch.
-    n_rest = len(w["rest"])
-    assert n_rest <= B // 100, (rel, n_rest, np.sort(w["dq"])[-5:])
+    # (1) same minimum: within tolerance.  (2) other minimum: certified (test_no_flat_valley_excuses) and counted against
+    # this config's pinned ceilings (0 where 0 was measured)
+    cap = CEILINGS[rel]
+    n_far, n_rest = int(w["far"].sum()), len(w["rest"])
+    assert n_far <= cap["far"], (rel, n_far, cap, np.sort(w["dq"])[-5:])
+    assert n_rest <= cap["worse"], (rel, n_rest, cap)
     # frames that share the oracle's minimum are well inside the tolerance
     same = ~w["far"]
     assert np.percentile(w["dq"][same], 99.9) < TOL
-    assert w["far"].mean() < 0.02, (rel, int(w["far"].sum()))
+
+
+def test_ceilings_table_is_tight_where_it_matters():
+    """The committed table: one row per shipped config; the three BASELINE configs and every config that measured 0 stay
+    at 0; no row is looser than the global gate of rounds 2-3 (2 % far, 1 % worse)."""
+    assert sorted(CEILINGS) == ALL
+    for rel, cap in CEILINGS.items():
+        assert 0 <= cap["worse"] <= cap["far"] <= B // 50 and cap["worse"] <= B // 100, (rel, cap)
+    assert CEILINGS["teleop/allegro_hand_right.yml"] == {"far": 0, "worse": 0}
 
 
 @pytest.mark.parametrize("rel", ALL)

@@ -1187,9 +1187,18 @@ def test_damping_default_follows_the_dispatched_kernel_family():
     assert model.kernel()[0] == _lib.KERNEL_LDS and abs(model.get_tuning().lam_jump - 0.3) < 1e-7
     model.tune(kernel=_lib.KERNEL_QUAD)
     assert abs(model.get_tuning().lam_jump - 1.0) < 1e-7
+    # a struct read BEFORE a family change and handed back later must not pin the old family's default ...
+    stale = model.get_tuning()                      # quad family: 1.0, no override bit
+    model.tune(kernel=_lib.KERNEL_LDS)              # LDS family: 0.3
+    stale.kernel = _lib.KERNEL_LDS
+    _lib.check(_lib.load().dexr_model_set_tuning(model._h, _lib.C.byref(stale)))
+    assert abs(model.get_tuning().lam_jump - 0.3) < 1e-7 and model.get_tuning().user_mask == 0
+    model.tune(kernel=_lib.KERNEL_QUAD)
     model.tune(lam_jump=0.5)  # an explicit value survives family changes
     model.tune(kernel=_lib.KERNEL_LDS)
-    assert abs(model.get_tuning().lam_jump - 0.5) < 1e-7
+    assert abs(model.get_tuning().lam_jump - 0.5) < 1e-7 and model.get_tuning().user_mask == _lib.TUNE_LAM_JUMP
+    model.tune(lam_jump=None)  # ... and an override can be dropped again: back to the family default
+    assert abs(model.get_tuning().lam_jump - 0.3) < 1e-7 and model.get_tuning().user_mask == 0
 
 
 def test_hip_graph_capture_with_caller_fixed_joints():
@@ -1334,6 +1343,41 @@ def test_tip_pass_agrees_with_the_table_driven_kernels(rel):
     e_tip = np.abs(res[1][0] - q64).max(1)
     e_tab = np.abs(res[2][0] - q64).max(1)
     assert np.percentile(e_tip, 99) < 2e-5 and np.percentile(e_tip, 99) < 2 * np.percentile(e_tab, 99) + 1e-6
+
+
+@pytest.mark.parametrize("rel", ["teleop/allegro_hand_right.yml", "teleop/leap_hand_left.yml"])
+def test_float64_tip_pass_agrees_with_the_table_driven_float64_kernel_and_the_oracle(rel):
+    """Round 4: float64 launches of the per-finger vector models (dexr_solve_options.precision = 1 -- the reference's own
+    arithmetic type, optimizer.py:249-304) take the tip pass too (dexr_kernel<4, double, SOLVE, CHAIN, EXT, TIP>).  Against
+    the generic float64 register kernel (dexr_tuning.chain = 0) on the same frames: the same minimisers to 1e-9 rad and the
+    same iteration counts on nearly every frame; against the float64 oracle: 1e-6 rad (the tolerance of the solve); the
+    float64 host entry point (dexr_retarget_f64: float64 result rows) goes the same way."""
+    seq, prob = build(rel)
+    model = seq.optimizer.device_model()
+    B = 4096
+    kp = np.ascontiguousarray(cases.human_keypoints(B + 1, seed=cases.SEED))
+    mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
+    o64 = _lib.default_options(precision=1)
+    res = {}
+    try:
+        model.tune(chain=1)
+        last = model.retarget(kp[:-1], None, mid, keypoints=True)
+        ref = np.ascontiguousarray(cases.ref_from_keypoints(prob, kp[1:]), dtype=np.float32)
+        for chain in (1, 0):
+            model.tune(chain=chain)
+            q, info = model.retarget(kp[1:], None, last, keypoints=True, want_info=True, opts=o64)
+            assert np.array_equal(q, model.retarget(kp[1:], None, last, keypoints=True, opts=o64))  # deterministic
+            assert (info["status"] == 0).all()
+            res[chain] = (q.astype(np.float64), info["iters"], model.retarget_f64(ref, None, last))
+    finally:
+        model.tune(chain=1)
+    d32 = np.abs(res[1][0] - res[0][0]).max(1)      # float32 result rows of the two float64 kernels
+    d64 = np.abs(res[1][2] - res[0][2]).max(1)      # float64 result rows (dexr_retarget_f64)
+    assert d32.max() < 2e-7 and np.percentile(d64, 99) < 1e-8 and d64.max() < 1e-6, (d32.max(), np.percentile(d64, [50, 99, 100]))
+    assert (res[1][1] != res[0][1]).mean() < 0.02
+    want = solvers.solve_lm_batched(prob, ref, None, last, newton=True, max_iter=100)
+    e = np.abs(res[1][2] - want).max(1)
+    assert np.percentile(e, 99.9) < 2e-6 and e.max() < 1e-4, np.percentile(e, [50, 99.9, 100])
 
 
 def test_tip_pass_needs_its_pattern():

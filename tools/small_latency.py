@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Developer tool (GPU): launch duration of a small-component model against the batch size -- the floor (a few waves: the
-slowest frame's passes at lone-wave latency) and the full launch.  DEXR_LIB selects a library variant.
+slowest frame's passes at lone-wave latency) and the full launch.  DEXR_LIB selects a library variant,
+DEXR_TOOL_KNOBS="persist_from=1,persist_occ=2,qchunk=64" developer knobs (tools/_tune.py), "f64" the float64 launch.
 
-    python tools/small_latency.py [config] [B ...]
+    python tools/small_latency.py [config] [f64] [B ...]
 """
 import os
 import sys
@@ -17,16 +18,27 @@ from dex_retargeting_amd.constants import DEFAULT_URDF_DIR  # noqa: E402
 from dex_retargeting_amd.retargeting_config import RetargetingConfig  # noqa: E402
 from oracle import cases  # noqa: E402  (input recipes only)
 
-args = [a for a in sys.argv[1:]]
+args = [a for a in sys.argv[1:] if a != "f64"]
+F64 = "f64" in sys.argv[1:]
 rel = args[0] if args and not args[0].isdigit() else "teleop/allegro_hand_right.yml"
 sizes = [int(a) for a in args if a.isdigit()] or [64, 4096, 16384, 65536, 262144]
 RetargetingConfig.set_default_urdf_dir(str(DEFAULT_URDF_DIR))
 seq = RetargetingConfig.load_from_file(os.path.join(cases.CONFIG_DIR, rel)).build()
 model = seq.optimizer.device_model()
+opts = None
+if os.environ.get("DEXR_TOOL_KNOBS"):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _tune
+
+    _, opts = _tune.apply(model, dict(kv.split("=") for kv in os.environ["DEXR_TOOL_KNOBS"].split(",")))
+if F64:
+    from dex_retargeting_amd import _lib
+
+    opts = _lib.default_options(precision=1)
 prob = cases.problem_from_config(rel)
 dexpilot = prob.kind == "dexpilot"
 dev = torch.device("cuda:0")
-print(f"# {rel}: kernel {model.kernel()}  lib {os.environ.get('DEXR_LIB', 'default')}")
+print(f"# {rel}: kernel {model.kernel()}  lib {os.environ.get('DEXR_LIB', 'default')}  knobs {os.environ.get('DEXR_TOOL_KNOBS', '-')}  {'f64' if F64 else 'f32'}")
 for B in sizes:
     kp = cases.human_keypoints(B + 1, seed=cases.SEED)
     mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
@@ -42,7 +54,7 @@ for B in sizes:
         if dexpilot:
             t_st.zero_()
         model.retarget_dev(B, t_kp.data_ptr(), 0, t_last.data_ptr(), t_st.data_ptr() if dexpilot else 0, t_q.data_ptr(),
-                           iters_ptr=t_it.data_ptr() if diag else 0, stream=s.cuda_stream, keypoints=True)
+                           iters_ptr=t_it.data_ptr() if diag else 0, stream=s.cuda_stream, keypoints=True, opts=opts)
 
     for _ in range(3):
         go()
