@@ -316,7 +316,8 @@ class Workload:
         fam, bucket, chain = self.model.kernel()
         kname = KERNEL_NAMES[fam] + f", bucket {bucket}" + (", serial-chain specialisation" + (" with the tip pass" if chain == 2 else "") if chain else "")
         if precision == "f64":
-            kname = f"dexr_kernel<{bucket}, double> (register kernel, float64 arithmetic)"
+            kname = f"dexr_kernel<{bucket}, double" + (", CHAIN, TIP> (the tip pass of the serial-chain kernel in float64 arithmetic, "
+                                                        "dexr_tip.hpp)" if chain == 2 else "> (register kernel, float64 arithmetic)")
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic, "valu_issue_frac": valu_frac, "pmc_note": pmc_note,
                 "valu": {"achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf,
@@ -612,6 +613,16 @@ def parity_block(wl, batch, q_gpu, n_par, n_slsqp):
             "reference": f"oracle restatement of the reference objective (value without, gradient with the regulariser) + "
                          f"scipy SLSQP ftol {prob.ftol:g} standing in for nlopt LD_SLSQP ftol_abs (optimizer.py:96-99)"}
     return out, prob, ref, last, kw_for
+
+
+def cgroup_cpu_max():
+    """The container's CPU quota as the kernel reports it ("max 100000" = none; "<quota> <period>" = quota / period CPUs)."""
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            return open(path).read().strip()
+        except OSError:
+            continue
+    return None
 
 
 def job_env(args):
@@ -989,7 +1000,8 @@ def run_single(args):
                     "value": res[0] / res[1], "unit": "frames/s", "cores": res[2], "kind": "port",
                     "sample": f"{res[0]} frames = {res[2]} processes x {per_proc} frames of the same workload (frame i mod "
                               f"{B} once the batch is exhausted), started together, same solver as cpu_baseline; "
-                              f"{avail} CPUs available to the process"}
+                              f"{avail} CPUs in the process's affinity mask, cgroup cpu.max = {cgroup_cpu_max()!r} (a quota "
+                              f"below the process count caps what the workers can use together)"}
     print(json.dumps(out))
     if comm is not None:
         comm.close()

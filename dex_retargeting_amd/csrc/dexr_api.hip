@@ -274,7 +274,10 @@ int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st)
   const int64_t tiles = (kp.B + 3) / 4;
   // waves per SIMD: 2 (256 VGPRs; 15-17 KB of LDS per wave); the 16-row joint grid is built for 3 (168 VGPRs, 11.8 KB):
   // LEAP DexPilot 1.24 -> 1.14 ms, Allegro DexPilot 0.84 -> 0.75 ms
-  const int occ = (!m->wide_mimic && m->wbucket == 16) ? 3 : 2;
+#ifndef DEXR_WIDE24_OCC
+#define DEXR_WIDE24_OCC 2  // (3 needs the 24-row kernel built with -DDEXR_WIDE_MINW=3: 168 VGPRs, 85 registers spilled -- measured)
+#endif
+  const int occ = (!m->wide_mimic && m->wbucket == 16) ? 3 : (!m->wide_mimic && m->wbucket == 24) ? DEXR_WIDE24_OCC : 2;
   int64_t resident = (int64_t)m->n_cu * 4 * occ;
   if (m->tune.resident_waves > 0) resident = m->tune.resident_waves;
   int64_t per_comp = (resident + kp.n_comp - 1) / kp.n_comp;
@@ -497,7 +500,10 @@ int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStr
   // (the tip pass keeps the placements of joints 1..3 in 64 more floats of the wave's LDS, dexr_tip.hpp)
   const bool tip_kernel = m->tip && m->chain && m->bucket == 4 && mode == dexr::MODE_SOLVE;
   const size_t per_wave = 64 * real_sz * (size_t)(3 * m->lds_frames + 4 * m->lds_terms + (tip_kernel ? 1 : 0));
-  int wpb = 4;
+#ifndef DEXR_WPB
+#define DEXR_WPB 4  // waves per block of the register kernels (the kernels never synchronise across waves)
+#endif
+  int wpb = DEXR_WPB;
   while (wpb > 1 && per_wave * wpb > 48 * 1024) wpb >>= 1;
   if (per_wave > 64 * 1024) return fail(DEXR_ERR_UNSUPPORTED, "component needs %zu B of LDS per wave", per_wave);
   const int64_t tiles = (kp.B + 63) / 64;

@@ -23,6 +23,9 @@
 #ifndef DEXR_TIP64_MINW
 #define DEXR_TIP64_MINW 2  // float64 tip kernel: waves per SIMD requested (256 VGPRs)
 #endif
+#ifndef DEXR_BLOCK_MAX
+#define DEXR_BLOCK_MAX 256  // threads per block of the register kernels (launch geometry: dexr_api.hip, DEXR_WPB waves)
+#endif
 #ifndef DEXR_CHAIN_MINW
 #define DEXR_CHAIN_MINW 4  // minimum waves per SIMD requested for the serial-chain kernel (caps its VGPR budget at 128)
 #endif
@@ -623,7 +626,7 @@ struct LaneSolver {
 // TIP = true (CHAIN, 4 joints, solve only): every component is a tip component and its pass is dexr_tip.hpp's (float32:
 // packed arithmetic, constants pinned; float64 since round 4: the reference's own arithmetic type on the same pass).
 template <int NMAX, typename real, int MODE, bool CHAIN = false, bool EXT = (NMAX > 8), bool TIP = false>
-__global__ void __launch_bounds__(256, (CHAIN && NMAX <= 4 && sizeof(real) == 4) ? DEXR_CHAIN_MINW : (TIP ? DEXR_TIP64_MINW : 1)) dexr_kernel(const KernelParams kp, const dexr_comp_table* __restrict__ comps) {
+__global__ void __launch_bounds__(DEXR_BLOCK_MAX, (CHAIN && NMAX <= 4 && sizeof(real) == 4) ? DEXR_CHAIN_MINW : (TIP ? DEXR_TIP64_MINW : 1)) dexr_kernel(const KernelParams kp, const dexr_comp_table* __restrict__ comps) {
   static_assert(!TIP || (CHAIN && NMAX == 4 && MODE == MODE_SOLVE), "tip pass: 4-joint chain solve only");
   extern __shared__ __align__(16) unsigned char lds_raw[];
   using LS = LaneSolver<NMAX, real, CHAIN>;

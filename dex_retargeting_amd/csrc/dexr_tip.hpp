@@ -33,10 +33,28 @@
 
 namespace dexr {
 
+#ifndef DEXR_TIP_SCALAR
 typedef float kv2 __attribute__((ext_vector_type(2)));  // a register pair: operands of v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+static __device__ __forceinline__ kv2 tip_yx(kv2 v) { return v.yx; }
+#else
+// -DDEXR_TIP_SCALAR=1 (experiment): the same formulas on a plain pair of floats -- v_fma_f32 / v_mul_f32 per component
+// instead of v_pk_* (tools/valu_rate.hip measures what each costs to issue)
+struct kv2 {
+  float x, y;
+};
+static __device__ __forceinline__ kv2 operator+(kv2 a, kv2 b) { return kv2{a.x + b.x, a.y + b.y}; }
+static __device__ __forceinline__ kv2 operator-(kv2 a, kv2 b) { return kv2{a.x - b.x, a.y - b.y}; }
+static __device__ __forceinline__ kv2 operator*(kv2 a, kv2 b) { return kv2{a.x * b.x, a.y * b.y}; }
+static __device__ __forceinline__ kv2 operator*(kv2 a, float b) { return kv2{a.x * b, a.y * b}; }
+static __device__ __forceinline__ kv2 operator*(float b, kv2 a) { return kv2{a.x * b, a.y * b}; }
+static __device__ __forceinline__ kv2 operator+(kv2 a, float b) { return kv2{a.x + b, a.y + b}; }
+static __device__ __forceinline__ kv2 operator-(kv2 a, float b) { return kv2{a.x - b, a.y - b}; }
+static __device__ __forceinline__ kv2 tip_yx(kv2 v) { return kv2{v.y, v.x}; }
+#endif
 template <typename R> struct TipVec;
-template <> struct TipVec<float> { typedef float v2 __attribute__((ext_vector_type(2))); };
+template <> struct TipVec<float> { typedef kv2 v2; };
 template <> struct TipVec<double> { typedef double v2 __attribute__((ext_vector_type(2))); };
+static __device__ __forceinline__ typename TipVec<double>::v2 tip_yx(typename TipVec<double>::v2 v) { return v.yx; }
 
 // A wave-uniform value the compiler must KEEP (in an SGPR, or a VGPR lane when those run out): the empty asm makes its source
 // opaque (a vector register of unknown contents), so the readfirstlane can neither be folded back into the kernel-argument /
@@ -155,7 +173,7 @@ static __device__ __forceinline__ R tip_eval(const TipTabT<R>& tt, const R (&x)[
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const kv2 a = tt.A0[i];
-      rp[i] = a * cs[0] + a.yx * sc;
+      rp[i] = a * cs[0] + tip_yx(a) * sc;
       r2[i] = tt.c0[i];
       p[i] = tt.p0[i];
       ao[0][i] = kv2{tt.c0[i], tt.p0[i]};
@@ -176,7 +194,7 @@ static __device__ __forceinline__ R tip_eval(const TipTabT<R>& tt, const R (&x)[
       const kv2 sc = kv2{sn[k], -sn[k]};
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        rp[i] = n01[i] * cs[k] + n01[i].yx * sc;
+        rp[i] = n01[i] * cs[k] + tip_yx(n01[i]) * sc;
         r2[i] = ao[k][i].x;
         p[i] = ao[k][i].y;
       }
