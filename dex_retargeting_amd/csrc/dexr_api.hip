@@ -87,6 +87,7 @@ struct dexr_model {
   // work-queue heads for the persistent-lane kernels: QSLOTS independent sets of n_comp counters handed out
   // round-robin, so launches in flight on different streams never share a queue
   static constexpr int QSLOTS = 64;
+  static constexpr int QSTRIDE = 8;  // counters per component (the sixteen-lane kernel keeps one per XCD, dexr_wide.hpp)
   unsigned* d_queue = nullptr;
   mutable std::atomic<unsigned> qnext{0};
   int n_cu = 256;
@@ -287,8 +288,8 @@ int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st)
   if (blocks > 0x7fffffffLL) return fail(DEXR_ERR_INVALID, "batch too large for one launch");
   kp.q0 = (uint32_t)(per_comp * 4);
   const unsigned slot = m->qnext.fetch_add(1u) % dexr_model::QSLOTS;
-  kp.queue = m->d_queue + (size_t)slot * kp.n_comp;
-  hipError_t qe = hipMemsetAsync(kp.queue, 0, (size_t)kp.n_comp * sizeof(unsigned), st);
+  kp.queue = m->d_queue + (size_t)slot * kp.n_comp * dexr_model::QSTRIDE;  // QSTRIDE counters per component: one per XCD
+  hipError_t qe = hipMemsetAsync(kp.queue, 0, (size_t)kp.n_comp * dexr_model::QSTRIDE * sizeof(unsigned), st);
   if (qe != hipSuccess) return fail(DEXR_ERR_HIP, "queue reset failed: %s", hipGetErrorString(qe));
 #ifdef DEXR_WIDE_PROF
   static double* wprof = nullptr;  // profiling build only: stage cycles of wave 0 (dexr_wide.hpp WPROF_*)
@@ -504,6 +505,15 @@ int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStr
 #define DEXR_WPB 4  // waves per block of the register kernels (the kernels never synchronise across waves)
 #endif
   int wpb = DEXR_WPB;
+#ifndef DEXR_TIP_WPB_BIG
+#define DEXR_TIP_WPB_BIG 8
+#endif
+  // float32 tip kernel, launches that fill the chip four waves deep (>= 4 096 waves): blocks of 8 waves.  The workgroup
+  // dispatcher places the chip's first two waves per SIMD within ~4 us and needs another ~12 us for the third and fourth
+  // (tools/wave_trace.sh); with half as many workgroups to place the launch of 65 536 Allegro frames takes 45.0 instead of
+  // 47.5 us (16 waves per block: 47.9; 1 wave per block: 52.3).  Smaller launches are faster in blocks of 4 (16 384 frames:
+  // 27.2 vs 33.3 us), so the policy is by size.
+  if (tip_kernel && !f64 && (kp.B + 63) / 64 * kp.n_comp >= 4096) wpb = DEXR_TIP_WPB_BIG;
   while (wpb > 1 && per_wave * wpb > 48 * 1024) wpb >>= 1;
   if (per_wave > 64 * 1024) return fail(DEXR_ERR_UNSUPPORTED, "component needs %zu B of LDS per wave", per_wave);
   const int64_t tiles = (kp.B + 63) / 64;
@@ -990,7 +1000,7 @@ int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out) {
     e = hipMalloc((void**)&m->d_wide, m->wide_tabs.size() * sizeof(dexr::WideTable));
     if (e == hipSuccess) e = hipMemcpy(m->d_wide, m->wide_tabs.data(), m->wide_tabs.size() * sizeof(dexr::WideTable), hipMemcpyHostToDevice);
   }
-  if (e == hipSuccess) e = hipMalloc((void**)&m->d_queue, (size_t)dexr_model::QSLOTS * h.n_comp * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc((void**)&m->d_queue, (size_t)dexr_model::QSLOTS * h.n_comp * dexr_model::QSTRIDE * sizeof(unsigned));
   if (e == hipSuccess) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess &&

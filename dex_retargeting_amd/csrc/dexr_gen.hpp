@@ -312,6 +312,7 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
           for (int u = 0; u <= lane; ++u) H[(size_t)lane * nv + u] = 0.0;
         }
         __syncthreads();
+        double cf[3] = {0.0, 0.0, 0.0};  // lane k: CF_k (see below)
         for (int t = 0; t < nt; ++t) {
           const int ft = l_ttask[t], fo = l_torigin[t];
           const unsigned long long at = l_fanc[ft], ao = fo >= 0 ? l_fanc[fo] : 0ull;
@@ -334,6 +335,12 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
               }
             }
             for (int i = 0; i < 3; ++i) jcol[k * 3 + i] = c[i];
+            // second-order kinematic term, first half: CF_k = sum over the terms of (column of joint k) x (force of the
+            // term) -- the entry for a pair (joint k, revolute ancestor-or-self j) is m_j m_k a_j . CF_k, formed ONCE per
+            // pass after this loop (tg . (a_j x c) = a_j . (c x tg))
+            cf[0] += c[1] * tg[t * 3 + 2] - c[2] * tg[t * 3 + 1];
+            cf[1] += c[2] * tg[t * 3] - c[0] * tg[t * 3 + 2];
+            cf[2] += c[0] * tg[t * 3 + 1] - c[1] * tg[t * 3];
           }
           __syncthreads();
           if (lane < nv) {
@@ -363,49 +370,41 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
             }
           }
           __syncthreads();
-          if (kp.newton) {
-            // second-order kinematic term: sum over the term's frames (sign), joints k on the frame's chain and their
-            // revolute ancestors-or-self j of  m_j m_k  tg . (a_j x col_k)
-            for (int side = 0; side < 2; ++side) {
-              const int fr = side ? fo : ft;
-              if (fr < 0) continue;
-              const double sg = side ? -1.0 : 1.0;
-              for (int k = l_fjoint[fr]; k >= 0; k = l_parent[k]) {  // wave-uniform walk up the chain
-                const int vk = l_var[k];
-                if (vk < 0) continue;
-                double ck[3];
-                if (l_jtype[k] == DEXR_JOINT_REVOLUTE) {
-                  const double dx = P[fr * 3] - Tw[k * 12 + 9], dy = P[fr * 3 + 1] - Tw[k * 12 + 10], dz = P[fr * 3 + 2] - Tw[k * 12 + 11];
-                  ck[0] = aw[k * 3 + 1] * dz - aw[k * 3 + 2] * dy;
-                  ck[1] = aw[k * 3 + 2] * dx - aw[k * 3] * dz;
-                  ck[2] = aw[k * 3] * dy - aw[k * 3 + 1] * dx;
-                } else {
-                  for (int i = 0; i < 3; ++i) ck[i] = aw[k * 3 + i];
-                }
-                const unsigned long long ak = l_janc[k];
-                if (lane < nj) {
-                  const int j = lane;
-                  double val = 0.0;
-                  if (((ak >> j) & 1ull) && l_jtype[j] == DEXR_JOINT_REVOLUTE && l_var[j] >= 0) {
-                    const double cx = aw[j * 3 + 1] * ck[2] - aw[j * 3 + 2] * ck[1], cy = aw[j * 3 + 2] * ck[0] - aw[j * 3] * ck[2],
-                                 cz = aw[j * 3] * ck[1] - aw[j * 3 + 1] * ck[0];
-                    val = sg * l_jmul[j] * l_jmul[k] * (tg[t * 3] * cx + tg[t * 3 + 1] * cy + tg[t * 3 + 2] * cz);
-                    if (j != k && l_var[j] == vk) val *= 2.0;  // both orders of an unordered pair inside one family
-                  }
-                  tmp[j] = val;
-                }
-                __syncthreads();
-                if (lane < nv) {
-                  double sum = 0.0;
-                  for (int e = l_famoff[lane]; e < l_famoff[lane + 1]; ++e) sum += tmp[l_fam[e]];
-                  if (sum != 0.0) {
-                    const int hi_ = lane > vk ? lane : vk, lo_ = lane > vk ? vk : lane;
-                    H[(size_t)hi_ * nv + lo_] += sum;
-                  }
-                }
-                __syncthreads();
+        }
+        if (kp.newton) {
+          // second-order kinematic term, second half: for every joint k that moves with a variable and every revolute
+          // ancestor-or-self j of k that does too,  H[var j][var k] += m_j m_k a_j . CF_k  (twice for j != k inside one
+          // family: both orders of the unordered pair).  One sweep over the joints per PASS: lane j forms the entry of
+          // pair (j, k), lane v sums its variable's family and adds into its own entries.  (Round 3 walked the chains of
+          // every TERM instead -- terms x chain depth x 2 block barriers, ~1 500 per pass for an arm + hand: it was most of
+          // the ~300 us a pass of that model took.)
+          if (lane < nj) {
+            for (int i = 0; i < 3; ++i) jcol[lane * 3 + i] = cf[i];
+          }
+          __syncthreads();
+          for (int k = 0; k < nj; ++k) {  // wave-uniform
+            const int vk = l_var[k];
+            if (vk < 0) continue;
+            const unsigned long long ak = l_janc[k];
+            if (lane < nj) {
+              const int j = lane;
+              double val = 0.0;
+              if (((ak >> j) & 1ull) && l_jtype[j] == DEXR_JOINT_REVOLUTE && l_var[j] >= 0) {
+                val = l_jmul[j] * l_jmul[k] * (aw[j * 3] * jcol[k * 3] + aw[j * 3 + 1] * jcol[k * 3 + 1] + aw[j * 3 + 2] * jcol[k * 3 + 2]);
+                if (j != k && l_var[j] == vk) val *= 2.0;
+              }
+              tmp[j] = val;
+            }
+            __syncthreads();
+            if (lane < nv) {
+              double sum = 0.0;
+              for (int e = l_famoff[lane]; e < l_famoff[lane + 1]; ++e) sum += tmp[l_fam[e]];
+              if (sum != 0.0) {
+                const int hi_ = lane > vk ? lane : vk, lo_ = lane > vk ? vk : lane;
+                H[(size_t)hi_ * nv + lo_] += sum;
               }
             }
+            __syncthreads();
           }
         }
         return fval;

@@ -26,6 +26,9 @@
 #ifndef DEXR_BLOCK_MAX
 #define DEXR_BLOCK_MAX 256  // threads per block of the register kernels (launch geometry: dexr_api.hip, DEXR_WPB waves)
 #endif
+#ifndef DEXR_TIP_BLOCK_MAX
+#define DEXR_TIP_BLOCK_MAX 512  // the float32 tip kernel also runs in blocks of 8 waves (full-chip launches, see dexr_api.hip launch())
+#endif
 #ifndef DEXR_CHAIN_MINW
 #define DEXR_CHAIN_MINW 4  // minimum waves per SIMD requested for the serial-chain kernel (caps its VGPR budget at 128)
 #endif
@@ -626,7 +629,7 @@ struct LaneSolver {
 // TIP = true (CHAIN, 4 joints, solve only): every component is a tip component and its pass is dexr_tip.hpp's (float32:
 // packed arithmetic, constants pinned; float64 since round 4: the reference's own arithmetic type on the same pass).
 template <int NMAX, typename real, int MODE, bool CHAIN = false, bool EXT = (NMAX > 8), bool TIP = false>
-__global__ void __launch_bounds__(DEXR_BLOCK_MAX, (CHAIN && NMAX <= 4 && sizeof(real) == 4) ? DEXR_CHAIN_MINW : (TIP ? DEXR_TIP64_MINW : 1)) dexr_kernel(const KernelParams kp, const dexr_comp_table* __restrict__ comps) {
+__global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MAX : DEXR_BLOCK_MAX, (CHAIN && NMAX <= 4 && sizeof(real) == 4) ? DEXR_CHAIN_MINW : (TIP ? DEXR_TIP64_MINW : 1)) dexr_kernel(const KernelParams kp, const dexr_comp_table* __restrict__ comps) {
   static_assert(!TIP || (CHAIN && NMAX == 4 && MODE == MODE_SOLVE), "tip pass: 4-joint chain solve only");
   extern __shared__ __align__(16) unsigned char lds_raw[];
   using LS = LaneSolver<NMAX, real, CHAIN>;
@@ -954,7 +957,7 @@ __global__ void __launch_bounds__(DEXR_BLOCK_MAX, (CHAIN && NMAX <= 4 && sizeof(
       // experiment (not in the shipped library unless it measures): waves that still hold frames past DEXR_PRIO passes, or
       // frames that saw a rejected step, are the launch's critical path -- give them VALU issue priority over the waves
       // they share a SIMD with
-      if (__any(has && (my_iters >= DEXR_PRIO || nrej > 0))) __builtin_amdgcn_s_setprio(3);
+      if (__any(has && (my_iters >= DEXR_PRIO || nrej > 0))) __builtin_amdgcn_s_setprio(3);  // (DEXR_PRIO=99: rejections only)
       else __builtin_amdgcn_s_setprio(0);
 #endif
 

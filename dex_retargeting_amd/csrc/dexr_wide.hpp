@@ -1167,10 +1167,29 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   double F = 0;
   float smax = 0, pred = 0;
   bool ok = true;
-  unsigned pool_next = (unsigned)((tile * 4 < (int64_t)kp.q0 && tile * 4 < nB) ? tile * 4 : 0);
-  unsigned pool_end = (unsigned)((tile * 4 < (int64_t)kp.q0 && tile * 4 < nB) ? ((tile * 4 + 4 < nB) ? tile * 4 + 4 : nB) : 0);
+  // XCD-LOCAL HAND-OUT (plain batches).  A frame's 252 bytes of keypoints straddle 128-byte lines it shares with its
+  // neighbours; handed out one by one from a single counter, neighbouring frames land on different XCDs -- different L2s --
+  // and every shared line is fetched twice (41 MB per Shadow-DexPilot launch against 29.6 MB of algorithmic bytes,
+  // profiles/r03).  So the frames a wave takes are contiguous PER XCD: the static first tiles are laid out XCD-major (block
+  // b runs on XCD b mod 8), the dynamic range [q0, nB) is cut into 8 contiguous chunks with a counter each, and a wave
+  // draws from the chunk of the XCD it runs on (XCC_ID) until that is dry, then helps with the others in turn.
+  // Index lists (fleet buckets, longest-first order) keep the single in-order queue: their order is the point.
+  constexpr int NXCD = 8;
+  const bool xcd_local = kp.perm == nullptr && !seq && kp.n_comp == 1;
+  int64_t tile_s = tile;  // static tile of this wave
+  if (xcd_local && (gridDim.x % NXCD) == 0) {
+    const int64_t bpx = gridDim.x / NXCD;
+    tile_s = (((int64_t)blockIdx.x % NXCD) * bpx + (int64_t)blockIdx.x / NXCD) * waves_per_block + wave_in_block;
+  }
+  unsigned pool_next = (unsigned)((tile_s * 4 < (int64_t)kp.q0 && tile_s * 4 < nB) ? tile_s * 4 : 0);
+  unsigned pool_end = (unsigned)((tile_s * 4 < (int64_t)kp.q0 && tile_s * 4 < nB) ? ((tile_s * 4 + 4 < nB) ? tile_s * 4 + 4 : nB) : 0);
   bool dry = false;
-  unsigned* queue = kp.queue + comp;
+  unsigned* queue = kp.queue + comp * NXCD;  // NXCD counters per component (only the first is used by in-order queues)
+  const int64_t dyn = nB > (int64_t)kp.q0 ? nB - (int64_t)kp.q0 : 0;
+  const int64_t chunk = xcd_local ? (dyn + NXCD - 1) / NXCD : dyn;  // frames per chunk of the dynamic range
+  const int n_chunk = xcd_local ? NXCD : 1;
+  const int my_xcc = xcd_local ? (int)(__builtin_amdgcn_s_getreg(63508) & 7u) : 0;  // XCC_ID (hardware register 20)
+  int q_rot = 0;  // wave-uniform: chunks this wave has found dry so far
   auto reset_state = [&]() {
     done = false;
     pending = false;
@@ -1202,14 +1221,23 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         // take exactly as many frames as there are idle rows: a frame parked in this wave's pool while its other rows
         // are busy would start late (near the end of the queue other waves' rows are idle by then)
         const unsigned nwant = (unsigned)__popcll(want) >> 4;
-        unsigned base = 0;
-        if (lane == 0) base = atomicAdd(queue, nwant);
-        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + kp.q0;
-        if ((int64_t)base >= nB) {
-          dry = true;
-        } else {
-          pool_next = base;
-          pool_end = (unsigned)(((int64_t)base + nwant < nB) ? base + nwant : nB);
+        for (;;) {  // own chunk first, then the next ones (wave-uniform loop: at most n_chunk rounds per wave and launch)
+          const int c = (my_xcc + q_rot) % n_chunk;
+          unsigned off = 0;
+          if (lane == 0) off = atomicAdd(queue + c, nwant);
+          off = (unsigned)__builtin_amdgcn_readfirstlane((int)off);
+          const int64_t lo = (int64_t)kp.q0 + (int64_t)c * chunk + (int64_t)off;
+          int64_t hi = (int64_t)kp.q0 + (int64_t)(c + 1) * chunk;
+          hi = hi < nB ? hi : nB;
+          if (lo < hi) {
+            pool_next = (unsigned)lo;
+            pool_end = (unsigned)((lo + nwant < hi) ? lo + nwant : hi);
+            break;
+          }
+          if (++q_rot >= n_chunk) {
+            dry = true;
+            break;
+          }
         }
       }
       if (pool_next < pool_end) {
