@@ -615,6 +615,44 @@ def parity_block(wl, batch, q_gpu, n_par, n_slsqp):
     return out, prob, ref, last, kw_for
 
 
+def reference_stack_record(rel, n_frames=621):
+    """The TRUE reference stack (pinocchio + nlopt + the dex_retargeting package itself), if this box happens to have it:
+    the reference's own profiling loop (example/profiling/profile_online_retargeting.py:18-36 -- one
+    SeqRetargeting.retarget(ref_value) per fixture frame, perf_counter around the call) on its own classes, with this repo's
+    URDFs and YAMLs as inputs.  Labelled apart from cpu_baseline.  On the
+    images seen so far none of the three imports: the record then says which are missing and nothing is timed."""
+    import importlib
+
+    missing = []
+    for mod in ("pinocchio", "nlopt", "dex_retargeting"):
+        try:
+            importlib.import_module(mod)
+        except Exception:
+            missing.append(mod)
+    if missing:
+        return {"available": False, "missing": missing,
+                "note": "the reference's own stack is not installed here: cpu_baseline (kind 'port') stands in for it"}
+    import bench_data
+    from dex_retargeting.retargeting_config import RetargetingConfig as RefConfig  # the reference package itself
+    from dex_retargeting_amd.constants import DEFAULT_URDF_DIR
+
+    RefConfig.set_default_urdf_dir(str(DEFAULT_URDF_DIR))
+    retargeting = RefConfig.load_from_file(os.path.join(bench_data.CONFIG_DIR, rel)).build()
+    data = np.load(bench_data.HUMAN_FIXTURE)[:n_frames].astype(np.float64)
+    indices = retargeting.optimizer.target_link_human_indices
+    position = retargeting.optimizer.retargeting_type == "POSITION"
+    dt = []
+    for joint_pos in data:
+        ref_value = joint_pos[indices, :] if position else joint_pos[indices[1, :], :] - joint_pos[indices[0, :], :]
+        tic = time.perf_counter()
+        retargeting.retarget(ref_value)
+        dt.append(time.perf_counter() - tic)
+    dt = np.array(dt)
+    return {"available": True, "kind": "reference", "cores": 1, "frames": len(dt), "value": len(dt) / dt.sum(), "unit": "frames/s",
+            "mean_ms": float(dt.mean() * 1e3), "p99_ms": float(np.percentile(dt, 99) * 1e3),
+            "note": "dex_retargeting's own SeqRetargeting on pinocchio + nlopt, this repo's URDF / YAML files as inputs"}
+
+
 def cgroup_cpu_max():
     """The container's CPU quota as the kernel reports it ("max 100000" = none; "<quota> <period>" = quota / period CPUs)."""
     for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
@@ -687,27 +725,46 @@ def gather_records(timed_fn, comm, B, n_cols, dev, steps, warmup, world, graph_f
     1-GPU box): dexr_allgather of the (B, n_cols) f32 result rows.  Returns
     (elapsed, kernel_ms, record dict).
 
-    headline       = one collective per step on a second HIP stream, ordered after the solve by an event: the next step's
-                     solve overlaps it; every gather has completed when the timed region ends;
-    no_gather      = the same steps, same barrier bracket, no collective (SURVEY 8e: "with and without the all-gather");
-    on solve stream= the collective on the solve stream itself (strictly serial);
-    every k steps  = ONE collective per k steps (k from distributed.steps_per_gather_for: the gathers must keep up with the
-                     solves at <= 60 % of the xGMI ingest), on the second stream;
-    graph replay   = [solve -> all-gather] x 4 captured into one HIP graph;
-    strong scaling = the metric's 65 536 frames over the whole node (B / N per GPU) with the per-step gather.
+    no_gather      = the steps with the usual barrier bracket and NO collective ("with and without the
+                     all-gather"); its step time picks k (distributed.steps_per_gather_for: the gathers must keep up with
+                     the solves at <= 60 % of the xGMI ingest);
+    headline       = ONE collective per k steps on a second HIP stream, ordered after the solves by an event: the next
+                     steps' solves overlap it; every gather has completed when the timed region ends (k = 1 for every
+                     workload whose solve hides a per-step gather);
+    other mode     = k = 1 when the headline used k > 1 (and k = 4 with one rank, to exercise the grouped path);
+    on solve stream= one collective per step on the solve stream itself (strictly serial);
+    strong scaling = the metric's 65 536 frames over the whole node (B / N per GPU) with the per-step gather;
+    graph replay   = [solve -> all-gather] x 4 captured into one HIP graph.
     Everything after the headline runs under a watchdog."""
     from dex_retargeting_amd.distributed import NativeGather, steps_per_gather_for
 
     wd = Watchdog(rank, float(os.environ.get("DEXR_BENCH_WATCHDOG_S", "120")))
     depth = min(8, steps + warmup + 1)
-    elapsed, kernel_ms = timed_fn(NativeGather(comm, B, n_cols, dev, depth=depth, overlap=True))
     shard_mb = B * n_cols * 4 / 1e6
+
+    def fig(e, note, frames=None):
+        return {"value": (world * B if frames is None else frames) * steps / e, "unit": "frames/s", "ms_per_step": e / steps * 1e3, "note": note}
+
+    # (1) the shards alone: no collective.  Its step time (maximum over the ranks: every rank derives the same k) decides how
+    # many steps share one all-gather in the headline
+    e0, _ = timed_fn(None)
+    k = steps_per_gather_for(e0 / steps * 1e3, B * n_cols * 4, world)
+    while steps % k:
+        k -= 1  # whole groups inside the timed region
+    # (2) headline: one all-gather per k steps on the second stream (k = 1 whenever the solve hides a per-step gather: every
+    # workload but the 47 us Allegro step at N >= 4; with one rank always 1)
+    elapsed, kernel_ms = timed_fn(NativeGather(comm, B, n_cols, dev, depth=depth if k == 1 else 2, overlap=True, steps_per_gather=k))
     rec = wd.done
     rec.update({
-        "collective": "dexr_allgather (C-ABI of libdexr.so -> RCCL ncclAllGather, bound with dlopen), one per step, "
-                      "enqueued on a second HIP stream behind an event recorded after the solve; all gathers "
-                      "complete inside the timed region",
+        "collective": f"dexr_allgather (C-ABI of libdexr.so -> RCCL ncclAllGather, bound with dlopen): ONE per {k} step(s) "
+                      f"({k} x {shard_mb:.2f} MB per rank), enqueued on a second HIP stream behind an event recorded after the "
+                      f"solve; every gather completes inside the timed region",
+        "steps_per_gather": k,
+        "steps_per_gather_policy": "smallest k for which a gather at 60 % of 537 GB/s xGMI ingest + 30 us of collective overhead "
+                                   "fits into k solve steps (distributed.steps_per_gather_for); the largest divisor of the step "
+                                   "count <= 16 when one step's wire time already exceeds the step",
         "rccl_world_size": world, "rccl_version": comm.rccl_version(), "rccl_env": rccl_env(),
+        "no_gather": fig(e0, "same steps and barrier bracket with NO collective: what the shards alone sustain"),
         "xgmi": {"shard_MB_per_rank_per_step": shard_mb, "received_MB_per_gpu_per_step": shard_mb * (world - 1),
                  "note": "every GPU receives (N-1) shards per step over its 7 xGMI links (~76.8 GB/s per link and "
                          "direction, 537 GB/s aggregate ingest at best): the all-gather lower bound per step is "
@@ -715,30 +772,16 @@ def gather_records(timed_fn, comm, B, n_cols, dev, steps, warmup, world, graph_f
                          f"{shard_mb * (world - 1) / 76.8 * 1e3:.1f} us on a single ring direction"}})
     if on_headline is not None:
         wd.line = on_headline(elapsed, kernel_ms)
-
-    def fig(e, note, frames=None):
-        return {"value": (world * B if frames is None else frames) * steps / e, "unit": "frames/s", "ms_per_step": e / steps * 1e3, "note": note}
-
-    wd.arm("no_gather")
-    e0, _ = timed_fn(None)
-    rec["no_gather"] = fig(e0, "same steps and barrier bracket with NO collective: what the shards alone sustain")
+    k2 = 1 if k > 1 else 4  # the other mode, for comparison (one rank: k = 4 exercises the grouped path)
+    while steps % k2:
+        k2 -= 1
+    wd.arm("gather_other_mode")
+    ek, _ = timed_fn(NativeGather(comm, B, n_cols, dev, depth=depth if k2 == 1 else 2, overlap=True, steps_per_gather=k2))
+    rec["gather_every_%d_step%s" % (k2, "" if k2 == 1 else "s")] = fig(
+        ek, f"ONE all-gather per {k2} step(s) on the second stream: the mode the headline did not use")
     wd.arm("gather_on_solve_stream")
     e2, _ = timed_fn(NativeGather(comm, B, n_cols, dev, depth=depth, overlap=False))
-    rec["gather_on_solve_stream"] = fig(e2, "same steps with the all-gather enqueued on the solve stream (serial)")
-    # e0 is the maximum over ranks (comm.max_f64): every rank derives the same k
-    k = steps_per_gather_for(e0 / steps * 1e3, B * n_cols * 4, world)
-    if world == 1:
-        k = 4  # one rank: nothing to hide, but the code path is exercised and timed
-    while steps % k:
-        k -= 1  # whole groups inside the timed region
-    wd.arm("gather_every_k_steps")
-    ek, _ = timed_fn(NativeGather(comm, B, n_cols, dev, depth=2, overlap=True, steps_per_gather=k))
-    rec["gather_every_k_steps"] = dict(fig(ek, f"ONE all-gather per {k} steps ({k} x {shard_mb:.2f} MB per rank) on the second "
-                                               f"stream: same bytes, 1/{k} of the collectives; results reach the other ranks up "
-                                               f"to {k - 1} steps later"), k=k,
-                                       policy="smallest k for which a gather at 60 % of 537 GB/s ingest + 30 us of collective "
-                                              "overhead fits into k solve steps (distributed.steps_per_gather_for); 16 when one "
-                                              "step's wire time already exceeds the step")
+    rec["gather_on_solve_stream"] = fig(e2, "one all-gather per step enqueued on the solve stream itself (serial)")
     if strong_fn is not None and world > 1:
         wd.arm("strong_scaling")
         rec["strong_scaling"] = strong_fn()
@@ -783,7 +826,8 @@ def run_single(args):
             "config": {"workload": f"{wl.title}, {B} frames/GPU, human-keypoint refs (fixture frame b mod 621 + 2 mm noise), "
                                    f"warm start = previous frame's solution; {N_BATCHES} staged batches rotated over the steps",
                        "config_file": wl.rel, "batch_per_gpu": B, "n_opt": wl.n_opt, "n_ref": wl.n_ref,
-                       "collective": "none" if comm is None else "dexr_allgather (RCCL ncclAllGather), one per step, second stream",
+                       "collective": "none" if comm is None else "dexr_allgather (RCCL ncclAllGather) on a second stream, one per "
+                                                                 "k steps (k: multi_gpu.steps_per_gather)",
                        "rccl_world_size": None if comm is None else world},
             "solver": dict(diag, tol_rad=2e-6, newton=1),
             "roofline": dict(wl.roofline(kernel_ms, diag["iters_mean"], world=world),
@@ -982,6 +1026,10 @@ def run_single(args):
                                "note": "optimistic stand-in for pinocchio + nlopt + torch: the reference additionally pays "
                                        "torch autograd overhead in every evaluation (optimizer.py:266-291)",
                                "host_cpus": os.cpu_count()}
+        try:
+            out["reference_stack"] = reference_stack_record(wl.rel)
+        except Exception as e:  # an installed but unusable stack must not cost the line
+            out["reference_stack"] = {"available": False, "error": repr(e)}
         d2, t2, _ = timed_cpu(lambda *a, **k: solvers.solve_ref_as_configured(prob, *a, **k), 4.0, 25)
         out["cpu_baseline_numpy_port"] = {"value": d2 / t2, "unit": "frames/s", "cores": 1, "kind": "port",
                                           "sample": f"first {d2} frames, the same solve with the numpy closure "

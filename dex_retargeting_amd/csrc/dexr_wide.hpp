@@ -1175,7 +1175,10 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   // draws from the chunk of the XCD it runs on (XCC_ID) until that is dry, then helps with the others in turn.
   // Index lists (fleet buckets, longest-first order) keep the single in-order queue: their order is the point.
   constexpr int NXCD = 8;
-  const bool xcd_local = kp.perm == nullptr && !seq && kp.n_comp == 1;
+#ifndef DEXR_WIDE_XCD
+#define DEXR_WIDE_XCD 1
+#endif
+  const bool xcd_local = DEXR_WIDE_XCD && kp.perm == nullptr && !seq && kp.n_comp == 1;
   int64_t tile_s = tile;  // static tile of this wave
   if (xcd_local && (gridDim.x % NXCD) == 0) {
     const int64_t bpx = gridDim.x / NXCD;
