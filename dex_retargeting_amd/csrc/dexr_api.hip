@@ -87,7 +87,6 @@ struct dexr_model {
   // work-queue heads for the persistent-lane kernels: QSLOTS independent sets of n_comp counters handed out
   // round-robin, so launches in flight on different streams never share a queue
   static constexpr int QSLOTS = 64;
-  static constexpr int QSTRIDE = 8;  // counters per component (the sixteen-lane kernel keeps one per XCD, dexr_wide.hpp)
   unsigned* d_queue = nullptr;
   mutable std::atomic<unsigned> qnext{0};
   int n_cu = 256;
@@ -275,10 +274,9 @@ int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st)
   const int64_t tiles = (kp.B + 3) / 4;
   // waves per SIMD: 2 (256 VGPRs; 15-17 KB of LDS per wave); the 16-row joint grid is built for 3 (168 VGPRs, 11.8 KB):
   // LEAP DexPilot 1.24 -> 1.14 ms, Allegro DexPilot 0.84 -> 0.75 ms
-#ifndef DEXR_WIDE24_OCC
-#define DEXR_WIDE24_OCC 2  // (3 needs the 24-row kernel built with -DDEXR_WIDE_MINW=3: 168 VGPRs, 85 registers spilled -- measured)
-#endif
-  const int occ = (!m->wide_mimic && m->wbucket == 16) ? 3 : (!m->wide_mimic && m->wbucket == 24) ? DEXR_WIDE24_OCC : 2;
+  // (the 24-row grid at three waves per SIMD -- 168 VGPRs, 85 registers spilled -- measured 34-40 % SLOWER in round 4, with the
+  // LDS slot shrunk to make room for it: DESIGN.md section 4)
+  const int occ = (!m->wide_mimic && m->wbucket == 16) ? 3 : 2;
   int64_t resident = (int64_t)m->n_cu * 4 * occ;
   if (m->tune.resident_waves > 0) resident = m->tune.resident_waves;
   int64_t per_comp = (resident + kp.n_comp - 1) / kp.n_comp;
@@ -288,8 +286,8 @@ int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st)
   if (blocks > 0x7fffffffLL) return fail(DEXR_ERR_INVALID, "batch too large for one launch");
   kp.q0 = (uint32_t)(per_comp * 4);
   const unsigned slot = m->qnext.fetch_add(1u) % dexr_model::QSLOTS;
-  kp.queue = m->d_queue + (size_t)slot * kp.n_comp * dexr_model::QSTRIDE;  // QSTRIDE counters per component: one per XCD
-  hipError_t qe = hipMemsetAsync(kp.queue, 0, (size_t)kp.n_comp * dexr_model::QSTRIDE * sizeof(unsigned), st);
+  kp.queue = m->d_queue + (size_t)slot * kp.n_comp;
+  hipError_t qe = hipMemsetAsync(kp.queue, 0, (size_t)kp.n_comp * sizeof(unsigned), st);
   if (qe != hipSuccess) return fail(DEXR_ERR_HIP, "queue reset failed: %s", hipGetErrorString(qe));
 #ifdef DEXR_WIDE_PROF
   static double* wprof = nullptr;  // profiling build only: stage cycles of wave 0 (dexr_wide.hpp WPROF_*)
@@ -478,8 +476,27 @@ int launch_gen_model(const dexr_model* m, int mode, dexr::KernelParams kp, hipSt
   per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
   int64_t blocks = (int64_t)m->n_cu * per_cu;
   if (blocks > kp.B) blocks = kp.B;
+#ifdef DEXR_GEN_PROF
+  static double* gprof = nullptr;  // profiling build only: stage cycles of block 0 (dexr_gen.hpp GPROF_*)
+  if (mode == dexr::MODE_SOLVE) {
+    if (!gprof) (void)hipMalloc((void**)&gprof, 12 * sizeof(double));
+    (void)hipMemsetAsync(gprof, 0, 12 * sizeof(double), st);
+    kp.g64out = gprof;
+  }
+#endif
   hipError_t e = dexr::launch_gen(mode, kp, m->gen_tab, dim3((unsigned)blocks), lds, st);
   if (e != hipSuccess) return fail(DEXR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
+#ifdef DEXR_GEN_PROF
+  if (mode == dexr::MODE_SOLVE) {
+    double h[12];
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h, gprof, sizeof(h), hipMemcpyDeviceToHost);
+    const char* names[8] = {"kinematics", "terms", "term loop", "2nd order", "active set + matrix", "factorisation", "solves", "step + pred"};
+    fprintf(stderr, "[gprof] B=%lld blocks=%lld lds=%zu passes(block 0)=%.0f cycles per pass:", (long long)kp.B, (long long)blocks, lds, h[11]);
+    for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.0f |", names[i], h[11] > 0 ? h[i] / h[11] : 0.0);
+    fprintf(stderr, "\n");
+  }
+#endif
   return DEXR_OK;
 }
 
@@ -1000,7 +1017,7 @@ int dexr_model_create(const void* blob, size_t nbytes, dexr_model** out) {
     e = hipMalloc((void**)&m->d_wide, m->wide_tabs.size() * sizeof(dexr::WideTable));
     if (e == hipSuccess) e = hipMemcpy(m->d_wide, m->wide_tabs.data(), m->wide_tabs.size() * sizeof(dexr::WideTable), hipMemcpyHostToDevice);
   }
-  if (e == hipSuccess) e = hipMalloc((void**)&m->d_queue, (size_t)dexr_model::QSLOTS * h.n_comp * dexr_model::QSTRIDE * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc((void**)&m->d_queue, (size_t)dexr_model::QSLOTS * h.n_comp * sizeof(unsigned));
   if (e == hipSuccess) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess &&

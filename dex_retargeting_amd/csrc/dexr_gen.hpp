@@ -12,8 +12,11 @@
 //                          world transform (LDS) with their placement and motion -- depth, not joint count, steps
 //   frames / terms         lane f = target link f; lane t = residual term t (SmoothL1 value, gradient, curvature)
 //   gradient / Hessian     per term: lane k forms joint k's column a x (p - o), lane v folds its variable's joint family
-//                          (kinematics_adaptor.py:102-113) and accumulates ITS ROW of the lower triangle of H; the
-//                          second-order kinematic term walks the term's chains, lane j = revolute ancestor j
+//                          (kinematics_adaptor.py:102-113); the lower triangle of H is dealt out ENTRY by entry over the 64
+//                          lanes (entry e = r (r + 1) / 2 + c on lane e mod 64) and accumulated over the terms in registers
+//                          (round 4; round 3 gave lane v row v and read-modify-wrote it in LDS: the longest row set the
+//                          pace); the second-order kinematic term is one sweep over the joints per pass from per-joint
+//                          sums CF_k (round 3: a chain walk per term)
 //   Cholesky / solves      lane = row, columns in sequence
 // Solver: the projected Levenberg-Marquardt / Newton iteration on F = f + norm_delta |x - last|^2 that
 // oracle/solvers.solve_lm_batched states (exact SmoothL1 curvature, second-order kinematic term, Nielsen damping), plus
@@ -38,11 +41,31 @@ struct GenTab {  // device pointers into the uploaded generic table
 // doubles of LDS one wave needs
 __host__ __device__ inline size_t gen_lds_doubles(int nj, int nf, int nt, int nv, int nfam) {
   const size_t state = (size_t)nj * 12 + nj * 3 + nj + (size_t)nf * 3 + (size_t)nt * 3 + nt + (size_t)nt * 3 + nt + (size_t)nt * 3 +
-                       (size_t)nt * 3 + (size_t)nv * 8 + 2 * (size_t)nv * nv + (size_t)nj * 3 + (size_t)nv * 3 + nj + 8;
+                       (size_t)nt * 3 + (size_t)nv * 8 + (size_t)nv * (nv + 1) /* H, Hf: packed lower triangles */ + (size_t)nj * 3 + (size_t)nv * 3 + nj + 8;
   // wave-local copies of the tables the inner loops index (see "tables" in the kernel)
-  const size_t ints = 3 * (size_t)nj + (size_t)nv + 1 + (size_t)nfam + (size_t)nf + 2 * (size_t)nt;
+  const size_t ints = 3 * (size_t)nj + (size_t)nv + 1 + (size_t)nfam + (size_t)nf + 2 * (size_t)nt +
+                      ((size_t)nv * (nv + 1) / 2 + 1) / 2 /* (row, column) of every entry of the packed triangle, 2 x uint8 */;
   return state + (size_t)nj /* jmul */ + (size_t)nf + (size_t)nj /* masks */ + (ints + 1) / 2;
 }
+
+#define GEN_TRI(r, c) ((size_t)(r) * ((r) + 1) / 2 + (c))
+// -DDEXR_GEN_PROF=1 (tools/prof_gen_stages.sh; never in the shipped library): block 0 accumulates the core cycles of every
+// stage of its passes and adds them to kp.g64out[stage] at the end (solve mode leaves that pointer unused otherwise).
+#ifdef DEXR_GEN_PROF
+#define GPROF_DECL long long gp_t0 = 0, gp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define GPROF_START() gp_t0 = clock64()
+#define GPROF_STAGE(i) { const long long gp_t1 = clock64(); gp_acc[i] += gp_t1 - gp_t0; gp_t0 = gp_t1; }
+#define GPROF_COUNT(i) gp_acc[i] += 1
+#define GPROF_FLUSH() if (MODE == MODE_SOLVE && blockIdx.x == 0 && lane == 0 && kp.g64out) { for (int i = 0; i < 12; ++i) atomicAdd(&kp.g64out[i], (double)gp_acc[i]); }
+#else
+#define GPROF_DECL
+#define GPROF_START()
+#define GPROF_STAGE(i)
+#define GPROF_COUNT(i)
+#define GPROF_FLUSH()
+#endif
+// entries of the packed triangle per lane (accumulated in registers): 12 serves up to 38 variables (741 entries), 33 up to 64
+constexpr int GEN_SLOTS_SMALL = 12, GEN_SLOTS_BIG = 33;
 
 __device__ __forceinline__ double gen_wave_sum(double v) {
 #pragma unroll
@@ -55,8 +78,99 @@ __device__ __forceinline__ double gen_wave_max(double v) {
   return v;
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb) {
+
+// a double of lane `src` (a compile-time constant at every call site below) as a wave-uniform value: two v_readlane_b32
+__device__ __forceinline__ double gen_readlane(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// Solve (H restricted to the free set + lam I) d = -g for the step d, IN REGISTERS: lane r holds row r of the lower
+// triangle (NV doubles, statically indexed in fully unrolled loops), the factor is formed column by column
+// (Cholesky-Crout): entry (r, c) = (A[r][c] - sum_{k<c} L[r][k] L[c][k]) / L[c][c] with row c's entries read from lane c
+// (v_readlane with a constant lane: scalar operands, no LDS, no barrier).  Forward substitution column-wise (y_k broadcast
+// from lane k); for the backward substitution the factor is transposed once through LDS (`Lt`, a packed triangle that is
+// free at this point) so that it is column-wise too.  Round 3 kept the matrix in LDS, lane = row, one block barrier + a
+// read-modify-write sweep per column: 113 k of the 303 k cycles of a 37-variable pass, 26 k more for the solves.
+// Not inlined: inside the kernel the register allocator carried ~400 live registers through the unrolled columns (92 on
+// its own); as a call it costs 22 spilled registers at the call site.
+// Returns false when a pivot is not positive (the damped model is indefinite: the caller raises lambda).
+template <int NV>
+__device__ __noinline__ bool gen_factor_solve(int lane, int nv, const double* H, const double* g, const double* act, double lam,
+                                              double* Lt, double* s_out) {
+  const bool rowv = lane < nv;
+  const bool a_r = rowv ? act[lane] != 0.0 : true;
+  const int base = lane * (lane + 1) / 2;
+  double L[NV];
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    double v = 0.0;
+    if (c < nv && rowv && c <= lane) {
+      const bool au = a_r || act[c] != 0.0;
+      v = au ? (c == lane ? 1.0 : 0.0) : H[base + c] + (c == lane ? lam : 0.0);
+    }
+    L[c] = v;
+  }
+  double rhs = (rowv && !a_r) ? -g[lane] : 0.0;
+  double invd = 0.0;  // 1 / L[lane][lane]
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    if (c < nv && ok) {  // wave-uniform
+      double acc = L[c];
+#pragma unroll
+      for (int k = 0; k < c; ++k) acc = fma(-L[k], gen_readlane(L[k], c), acc);  // L[k] of lane c = L[c][k]
+      const double d = gen_readlane(acc, c);
+      if (!(d > 0.0)) {
+        ok = false;
+      } else {
+        // 1 / sqrt(d): hardware estimate + two Newton steps (full double precision for the well-scaled pivots of a damped
+        // Hessian; a correctly rounded sqrt and a division cost three times the instructions, 38 times per solve)
+        double ip = __builtin_amdgcn_rsq(d);
+        ip = ip * fma(-0.5 * d * ip, ip, 1.5);
+        ip = ip * fma(-0.5 * d * ip, ip, 1.5);
+        L[c] = lane == c ? d * ip : (lane > c ? acc * ip : 0.0);
+        if (lane == c) invd = ip;
+      }
+    }
+  }
+  if (!ok) return false;
+  // the factor, transposed through LDS: lane c then holds column c (entries L[k][c], k >= c) in T[k]
+  if (rowv) {
+#pragma unroll
+    for (int c = 0; c < NV; ++c)
+      if (c < nv && c <= lane) Lt[base + c] = L[c];
+  }
+  // L y = rhs: y_k is final on lane k once the columns before k have been subtracted
+  double y = 0.0;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    if (k < nv) {
+      const double yk = gen_readlane(rhs * invd, k);
+      if (lane == k) y = yk;
+      if (lane > k) rhs = fma(-L[k], yk, rhs);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) L[k] = (k < nv && rowv && k >= lane) ? Lt[k * (k + 1) / 2 + lane] : 0.0;  // column `lane`
+  // L^T s = y: s_k = y_k / L[k][k] once the rows after k have been subtracted; lane j < k then takes L[k][j] s_k off y_j
+  double sv = 0.0;
+#pragma unroll
+  for (int k = NV - 1; k >= 0; --k) {
+    if (k < nv) {
+      const double sk = gen_readlane(y * invd, k);
+      if (lane == k) sv = sk;
+      if (lane < k) y = fma(-L[k], sk, y);
+    }
+  }
+  if (rowv) s_out[lane] = sv;
+  return true;
+}
+
+template <int MODE, int NSLOT>
+__global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen_kernel(KernelParams kp, GenTab tb) {
   extern __shared__ double gen_lds[];
   const int lane = threadIdx.x;
   const int nj = tb.nj, nf = tb.nf, nt = tb.nt, nv = tb.nv;
@@ -78,9 +192,10 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
   double* rhs = s + nv;
   double* act = rhs + nv;
   double* ybuf = act + nv;
-  double* H = ybuf + nv;           // nv x nv, lower triangle used
-  double* Hf = H + (size_t)nv * nv;
-  double* jcol = Hf + (size_t)nv * nv;  // nj x 3
+  const int ntri = nv * (nv + 1) / 2;
+  double* H = ybuf + nv;           // lower triangle, packed by rows: entry (r, c), c <= r, at r (r + 1) / 2 + c
+  double* Hf = H + ntri;
+  double* jcol = Hf + ntri;        // nj x 3
   double* vcol = jcol + nj * 3;         // nv x 3
   double* tmp = vcol + nv * 3;          // nj
   double* flag = tmp + nj;              // 8 scalars
@@ -98,6 +213,7 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
   int32_t* l_fjoint = l_fam + tb.nfam;                                            // nf
   int32_t* l_ttask = l_fjoint + nf;                                               // nt
   int32_t* l_torigin = l_ttask + nt;                                              // nt
+  uint16_t* l_rc = reinterpret_cast<uint16_t*>(l_torigin + nt);                   // ntri: row | column << 8 of entry e
   for (int i = lane; i < nj; i += 64) {
     l_jmul[i] = tb.jmul[i];
     l_janc[i] = tb.joint_anc[i];
@@ -115,8 +231,34 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
     l_ttask[i] = tb.term_task[i];
     l_torigin[i] = tb.term_origin[i];
   }
+  for (int e = lane; e < nv * (nv + 1) / 2; e += 64) {  // entry e of the packed triangle: row r, column c
+    int r = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= e) ++r;  // (guards the rounding of the square root)
+    while (r * (r + 1) / 2 > e) --r;
+    l_rc[e] = (uint16_t)(r | ((e - r * (r + 1) / 2) << 8));
+  }
   __syncthreads();
 
+  // Lane k IS joint k (and variable k, frame k) for the whole kernel: what the tables say about them is read ONCE, into
+  // registers.  (Round 3 re-read depth / placement / axis / offsets from global memory in every level of every forward
+  // kinematics -- two dependent ~1 us round trips per level, 19 levels for an arm + hand, twice per pass: most of a pass.)
+  const bool is_j = lane < nj, is_v = lane < nv, is_f = lane < nf;
+  const int my_depth = is_j ? tb.depth[lane] : -1;
+  const int my_src = is_j ? tb.src_idx[lane] : 0;
+  double myX[12], my_ax[3], my_fo[3];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) myX[i] = is_j ? tb.X[(size_t)lane * 12 + i] : 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    my_ax[i] = is_j ? tb.axis[lane * 3 + i] : 0.0;
+    my_fo[i] = is_f ? tb.frame_off[(size_t)lane * 3 + i] : 0.0;
+  }
+  const double my_joff = is_j ? tb.joff[lane] : 0.0;
+  const double my_lo = is_v ? tb.lo[lane] : 0.0, my_hi = is_v ? tb.hi[lane] : 0.0;
+  const int my_api = is_v ? tb.var_api[lane] : 0;
+
+  const bool no_mimic = tb.nfam == nv;  // every variable drives exactly one joint (families partition the driven joints)
+  GPROF_DECL
   const int64_t cnt = kp.bucket ? (int64_t)kp.bucket[1] : kp.B;
   const int64_t boff = kp.bucket ? (int64_t)kp.bucket[0] : 0;
   const int ld = kp.ld;
@@ -144,7 +286,7 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
       };
       // ---- load the frame -------------------------------------------------------------------------------------------
       if (MODE != MODE_FK && lane < nv) {
-        const int api = tb.var_api[lane];
+        const int api = my_api;
         double v, l;
         if (MODE == MODE_EVAL) v = kp.xin[it * kp.n_opt + api];
         else if (carry) v = (double)(float)x[lane];  // the reference carries the float32 result (optimizer.py:99)
@@ -152,7 +294,7 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
         else v = (double)kp.last[r0 * ld + api];
         l = carry ? v : (double)kp.last[r0 * ld + api];
         if (seq) {  // seq_retarget.py:118-120: last_qpos clipped to the joint limits before every solve
-          l = fmin(fmax(l, tb.lo[lane] + (double)kp.clip_eps), tb.hi[lane] - (double)kp.clip_eps);
+          l = fmin(fmax(l, my_lo + (double)kp.clip_eps), my_hi - (double)kp.clip_eps);
           v = l;
         }
         x[lane] = v;
@@ -214,39 +356,41 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
       }
       __syncthreads();
 
-      // ---- one evaluation at xs: kinematics, terms, value; with `model` also gradient + Hessian of F -------------------
-      auto eval_at = [&](const double* xs, bool model) -> double {
+      // ---- one evaluation at xs: kinematics, terms, value (eval_value); gradient + Hessian of the data term at the point
+      // whose kinematic state is in LDS (assemble_model) ------------------------------------------------------------------
+      auto eval_value = [&](const double* xs) -> double {
+        GPROF_START();
         if (lane < nj) {
           const int v = l_var[lane];
           double q;
-          if (MODE == MODE_FK) q = kp.xin[it * kp.n_q + tb.src_idx[lane]];
-          else if (v >= 0) q = l_jmul[lane] * xs[v] + tb.joff[lane];
-          else q = l_jmul[lane] * (double)kp.fixed[it * kp.ldf + tb.src_idx[lane]] + tb.joff[lane];
+          if (MODE == MODE_FK) q = kp.xin[it * kp.n_q + my_src];
+          else if (v >= 0) q = l_jmul[lane] * xs[v] + my_joff;
+          else q = l_jmul[lane] * (double)kp.fixed[it * kp.ldf + my_src] + my_joff;
           qj[lane] = q;
         }
         __syncthreads();
         for (int d = 0; d <= tb.max_depth; ++d) {
-          if (lane < nj && tb.depth[lane] == d) {
+          if (my_depth == d) {
             const int k = lane, pa = l_parent[k];
             double Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pp[3] = {0, 0, 0};
             if (pa >= 0) {
               for (int i = 0; i < 9; ++i) Rp[i] = Tw[pa * 12 + i];
               for (int i = 0; i < 3; ++i) pp[i] = Tw[pa * 12 + 9 + i];
             }
-            const double* Xk = tb.X + (size_t)k * 12;
+            const double* Xk = myX;
             double Ra[9], pa3[3];
             for (int i = 0; i < 3; ++i) {
               for (int j = 0; j < 3; ++j) Ra[3 * i + j] = Rp[3 * i] * Xk[j] + Rp[3 * i + 1] * Xk[3 + j] + Rp[3 * i + 2] * Xk[6 + j];
               pa3[i] = Rp[3 * i] * Xk[9] + Rp[3 * i + 1] * Xk[10] + Rp[3 * i + 2] * Xk[11] + pp[i];
             }
-            const double ax = tb.axis[k * 3], ay = tb.axis[k * 3 + 1], az = tb.axis[k * 3 + 2];
+            const double ax = my_ax[0], ay = my_ax[1], az = my_ax[2];
             const double a0 = Ra[0] * ax + Ra[1] * ay + Ra[2] * az, a1 = Ra[3] * ax + Ra[4] * ay + Ra[5] * az,
                          a2 = Ra[6] * ax + Ra[7] * ay + Ra[8] * az;
             aw[k * 3] = a0; aw[k * 3 + 1] = a1; aw[k * 3 + 2] = a2;
             const double q = qj[k];
             if (l_jtype[k] == DEXR_JOINT_REVOLUTE) {  // Rodrigues about the local axis: I + sin K + (1 - cos) K^2
               double sn, cs;
-              sincos(q, &sn, &cs);
+              sincos_f64(q, &sn, &cs);  // (dexr_math.hpp: no slow path, unlike ocml's)
               const double c1 = 1.0 - cs;
               const double M[9] = {1 - c1 * (ay * ay + az * az), -sn * az + c1 * ax * ay, sn * ay + c1 * ax * az,
                                    sn * az + c1 * ax * ay, 1 - c1 * (ax * ax + az * az), -sn * ax + c1 * ay * az,
@@ -266,7 +410,7 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
         }
         if (lane < nf) {
           const int j = l_fjoint[lane];
-          const double* o = tb.frame_off + (size_t)lane * 3;
+          const double* o = my_fo;
           if (j < 0) {
             for (int i = 0; i < 3; ++i) P[lane * 3 + i] = o[i];
           } else {
@@ -275,6 +419,7 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
           }
         }
         __syncthreads();
+        GPROF_STAGE(0)  // forward kinematics + frames
         if (MODE == MODE_FK) return 0.0;
         double fpart = 0.0;
         if (lane < nt) {
@@ -306,82 +451,153 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
           }
         }
         const double fval = gen_wave_sum(fpart);
-        if (!model) return fval;
-        if (lane < nv) {
-          g[lane] = 0.0;
-          for (int u = 0; u <= lane; ++u) H[(size_t)lane * nv + u] = 0.0;
-        }
+        GPROF_STAGE(1)  // terms
+        return fval;
+      };
+      auto assemble_model = [&]() {
+        GPROF_START();
+        if (lane < nv) g[lane] = 0.0;
         __syncthreads();
+        double hacc[NSLOT];  // this lane's entries of H, accumulated over the terms (slot i: entry 64 i + lane)
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) hacc[i] = 0.0;
         double cf[3] = {0.0, 0.0, 0.0};  // lane k: CF_k (see below)
-        for (int t = 0; t < nt; ++t) {
+        int rc_[NSLOT];  // (row, column) of this lane's entries: read once per evaluation, not once per term
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) rc_[i] = (64 * i + lane < ntri) ? (int)l_rc[64 * i + lane] : 0;
+        const bool pos = kp.kind == DEXR_KIND_POSITION;
+        // entries of H owned by this lane += the term's contribution; vb: the variables' columns, ub: u . column
+        auto add_entries = [&](int t, const double* vb, const double* ub) {
+          const double k0 = pos ? tc2[t * 3] : tc1[t], k1 = pos ? tc2[t * 3 + 1] : tc1[t], k2 = pos ? tc2[t * 3 + 2] : tc1[t];
+          const double kb = pos ? 0.0 : tc2[t * 3];
+#pragma unroll
+          for (int i4 = 0; i4 < NSLOT; i4 += 4) {
+            if (64 * i4 < ntri) {  // wave-uniform, per group of four slots: the slots of a group overlap their LDS reads
+#pragma unroll
+              for (int i = i4; i < i4 + 4 && i < NSLOT; ++i) {
+                if (64 * i + lane < ntri) {
+                  const int r = rc_[i] & 0xFF, c = rc_[i] >> 8;
+                  // position: sum_i k_i v_r[i] v_c[i]  |  vector kinds: c1 (v_r . v_c) + (c2 - c1) (u . v_r) (u . v_c)
+                  double add = k0 * vb[r * 3] * vb[c * 3] + k1 * vb[r * 3 + 1] * vb[c * 3 + 1] + k2 * vb[r * 3 + 2] * vb[c * 3 + 2];
+                  if (!pos) add += kb * ub[r] * ub[c];  // (0 x uninitialised LDS is not 0)
+                  hacc[i] += add;
+                }
+              }
+            }
+          }
+        };
+        // joint k's column of term t: a x (p - o) over the term's two frames (sign), or the axis (prismatic)
+        auto joint_column = [&](int t, double (&c)[3]) {
           const int ft = l_ttask[t], fo = l_torigin[t];
           const unsigned long long at = l_fanc[ft], ao = fo >= 0 ? l_fanc[fo] : 0ull;
-          if (lane < nj) {
-            const int k = lane;
-            double c[3] = {0, 0, 0};
-            const bool rev = l_jtype[k] == DEXR_JOINT_REVOLUTE;
-            for (int side = 0; side < 2; ++side) {
-              const bool on = ((side ? ao : at) >> k) & 1ull;
-              if (!on) continue;
-              const int fr = side ? fo : ft;
-              const double sg = side ? -1.0 : 1.0;
-              if (rev) {
-                const double dx = P[fr * 3] - Tw[k * 12 + 9], dy = P[fr * 3 + 1] - Tw[k * 12 + 10], dz = P[fr * 3 + 2] - Tw[k * 12 + 11];
-                c[0] += sg * (aw[k * 3 + 1] * dz - aw[k * 3 + 2] * dy);
-                c[1] += sg * (aw[k * 3 + 2] * dx - aw[k * 3] * dz);
-                c[2] += sg * (aw[k * 3] * dy - aw[k * 3 + 1] * dx);
-              } else {
-                for (int i = 0; i < 3; ++i) c[i] += sg * aw[k * 3 + i];
-              }
-            }
-            for (int i = 0; i < 3; ++i) jcol[k * 3 + i] = c[i];
-            // second-order kinematic term, first half: CF_k = sum over the terms of (column of joint k) x (force of the
-            // term) -- the entry for a pair (joint k, revolute ancestor-or-self j) is m_j m_k a_j . CF_k, formed ONCE per
-            // pass after this loop (tg . (a_j x c) = a_j . (c x tg))
-            cf[0] += c[1] * tg[t * 3 + 2] - c[2] * tg[t * 3 + 1];
-            cf[1] += c[2] * tg[t * 3] - c[0] * tg[t * 3 + 2];
-            cf[2] += c[0] * tg[t * 3 + 1] - c[1] * tg[t * 3];
-          }
-          __syncthreads();
-          if (lane < nv) {
-            double c[3] = {0, 0, 0};
-            for (int e = l_famoff[lane]; e < l_famoff[lane + 1]; ++e) {
-              const int k = l_fam[e];
-              const double m = l_jmul[k];
-              for (int i = 0; i < 3; ++i) c[i] += m * jcol[k * 3 + i];
-            }
-            for (int i = 0; i < 3; ++i) vcol[lane * 3 + i] = c[i];
-            g[lane] += tg[t * 3] * c[0] + tg[t * 3 + 1] * c[1] + tg[t * 3 + 2] * c[2];
-          }
-          __syncthreads();
-          if (lane < nv) {
-            const double c0 = vcol[lane * 3], c1v = vcol[lane * 3 + 1], c2v = vcol[lane * 3 + 2];
-            if (kp.kind == DEXR_KIND_POSITION) {
-              const double k0 = tc2[t * 3] * c0, k1 = tc2[t * 3 + 1] * c1v, k2 = tc2[t * 3 + 2] * c2v;
-              for (int u = 0; u <= lane; ++u)
-                H[(size_t)lane * nv + u] += k0 * vcol[u * 3] + k1 * vcol[u * 3 + 1] + k2 * vcol[u * 3 + 2];
+          const int k = lane;
+          c[0] = 0.0; c[1] = 0.0; c[2] = 0.0;
+          const bool rev = l_jtype[k] == DEXR_JOINT_REVOLUTE;
+          for (int side = 0; side < 2; ++side) {
+            const bool on = ((side ? ao : at) >> k) & 1ull;
+            if (!on) continue;
+            const int fr = side ? fo : ft;
+            const double sg = side ? -1.0 : 1.0;
+            if (rev) {
+              const double dx = P[fr * 3] - Tw[k * 12 + 9], dy = P[fr * 3 + 1] - Tw[k * 12 + 10], dz = P[fr * 3 + 2] - Tw[k * 12 + 11];
+              c[0] += sg * (aw[k * 3 + 1] * dz - aw[k * 3 + 2] * dy);
+              c[1] += sg * (aw[k * 3 + 2] * dx - aw[k * 3] * dz);
+              c[2] += sg * (aw[k * 3] * dy - aw[k * 3 + 1] * dx);
             } else {
-              const double a = tc1[t], b = tc2[t * 3];
-              const double uv = tu[t * 3] * c0 + tu[t * 3 + 1] * c1v + tu[t * 3 + 2] * c2v;
-              for (int u = 0; u <= lane; ++u) {
-                const double uu = tu[t * 3] * vcol[u * 3] + tu[t * 3 + 1] * vcol[u * 3 + 1] + tu[t * 3 + 2] * vcol[u * 3 + 2];
-                H[(size_t)lane * nv + u] += a * (c0 * vcol[u * 3] + c1v * vcol[u * 3 + 1] + c2v * vcol[u * 3 + 2]) + b * uv * uu;
-              }
+              for (int i = 0; i < 3; ++i) c[i] += sg * aw[k * 3 + i];
             }
           }
+          // second-order kinematic term, first half: CF_k = sum over the terms of (column of joint k) x (force of the
+          // term) -- the entry for a pair (joint k, revolute ancestor-or-self j) is m_j m_k a_j . CF_k, formed ONCE per
+          // pass after the term loop (tg . (a_j x c) = a_j . (c x tg))
+          cf[0] += c[1] * tg[t * 3 + 2] - c[2] * tg[t * 3 + 1];
+          cf[1] += c[2] * tg[t * 3] - c[0] * tg[t * 3 + 2];
+          cf[2] += c[0] * tg[t * 3 + 1] - c[1] * tg[t * 3];
+        };
+        if (no_mimic) {
+          // every variable drives exactly one joint: lane k writes its variable's column itself, the columns are
+          // double-buffered (vcol | jcol, tmp | act: both spare here) -- ONE barrier per term instead of three
+          const int v = lane < nj ? l_var[lane] : -1;
+          const double m = lane < nj ? l_jmul[lane] : 0.0;
+          for (int t = 0; t < nt; ++t) {
+            double* vb = (t & 1) ? jcol : vcol;
+            double* ub = (t & 1) ? act : tmp;
+            if (lane < nj) {
+              double c[3];
+              joint_column(t, c);
+              if (v >= 0) {
+                const double c0 = m * c[0], c1 = m * c[1], c2 = m * c[2];
+                vb[v * 3] = c0; vb[v * 3 + 1] = c1; vb[v * 3 + 2] = c2;
+                g[v] += tg[t * 3] * c0 + tg[t * 3 + 1] * c1 + tg[t * 3 + 2] * c2;
+                if (!pos) ub[v] = tu[t * 3] * c0 + tu[t * 3 + 1] * c1 + tu[t * 3 + 2] * c2;
+              }
+            }
+            __syncthreads();
+            add_entries(t, vb, ub);
+          }
           __syncthreads();
+        } else {
+          for (int t = 0; t < nt; ++t) {
+            if (lane < nj) {
+              double c[3];
+              joint_column(t, c);
+              for (int i = 0; i < 3; ++i) jcol[lane * 3 + i] = c[i];
+            }
+            __syncthreads();
+            if (lane < nv) {  // the variable's column: its joint family folded (kinematics_adaptor.py:102-113)
+              double c[3] = {0, 0, 0};
+              for (int e = l_famoff[lane]; e < l_famoff[lane + 1]; ++e) {
+                const int k = l_fam[e];
+                const double mk = l_jmul[k];
+                for (int i = 0; i < 3; ++i) c[i] += mk * jcol[k * 3 + i];
+              }
+              for (int i = 0; i < 3; ++i) vcol[lane * 3 + i] = c[i];
+              g[lane] += tg[t * 3] * c[0] + tg[t * 3 + 1] * c[1] + tg[t * 3 + 2] * c[2];
+              // u . column (vector kinds only: the position objective has no unit vector, its tu block is never written)
+              if (!pos) tmp[lane] = tu[t * 3] * c[0] + tu[t * 3 + 1] * c[1] + tu[t * 3 + 2] * c[2];
+            }
+            __syncthreads();
+            add_entries(t, vcol, tmp);
+            __syncthreads();
+          }
         }
+        GPROF_STAGE(2)  // term loop: columns, gradient, Hessian entries
+        // second-order kinematic term, second half: for every joint k that moves with a variable and every revolute
+        // ancestor-or-self j of k that does too,  H[var j][var k] += m_j m_k a_j . CF_k  (twice for j != k inside one
+        // family: both orders of the unordered pair).
         if (kp.newton) {
-          // second-order kinematic term, second half: for every joint k that moves with a variable and every revolute
-          // ancestor-or-self j of k that does too,  H[var j][var k] += m_j m_k a_j . CF_k  (twice for j != k inside one
-          // family: both orders of the unordered pair).  One sweep over the joints per PASS: lane j forms the entry of
-          // pair (j, k), lane v sums its variable's family and adds into its own entries.  (Round 3 walked the chains of
-          // every TERM instead -- terms x chain depth x 2 block barriers, ~1 500 per pass for an arm + hand: it was most of
-          // the ~300 us a pass of that model took.)
           if (lane < nj) {
             for (int i = 0; i < 3; ++i) jcol[lane * 3 + i] = cf[i];
           }
           __syncthreads();
+        }
+        if (kp.newton && no_mimic) {
+          // one joint per variable: the owner of entry (r, c) forms its (at most two) contributions itself -- joint of r as
+          // the moved joint with the joint of c as its ancestor, and the other way round
+#pragma unroll
+          for (int i = 0; i < NSLOT; ++i) {
+            if (64 * i < ntri) {
+              if (64 * i + lane < ntri) {
+                const int r = rc_[i] & 0xFF, c = rc_[i] >> 8;
+                const int jr = l_fam[l_famoff[r]], jc = l_fam[l_famoff[c]];
+                double val = 0.0;
+                if (((l_janc[jr] >> jc) & 1ull) && l_jtype[jc] == DEXR_JOINT_REVOLUTE)  // k = jr, j = jc
+                  val += l_jmul[jc] * l_jmul[jr] * (aw[jc * 3] * jcol[jr * 3] + aw[jc * 3 + 1] * jcol[jr * 3 + 1] + aw[jc * 3 + 2] * jcol[jr * 3 + 2]);
+                if (jr != jc && ((l_janc[jc] >> jr) & 1ull) && l_jtype[jr] == DEXR_JOINT_REVOLUTE)  // k = jc, j = jr
+                  val += l_jmul[jr] * l_jmul[jc] * (aw[jr * 3] * jcol[jc * 3] + aw[jr * 3 + 1] * jcol[jc * 3 + 1] + aw[jr * 3 + 2] * jcol[jc * 3 + 2]);
+                hacc[i] += val;
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i)
+          if (64 * i + lane < ntri) H[64 * i + lane] = hacc[i];
+        __syncthreads();
+        if (kp.newton && !no_mimic) {
+          // families of several joints: one sweep over the joints per PASS -- lane j forms the entry of pair (j, k), lane v
+          // sums its variable's family and adds into its own entries.  (Round 3 walked the chains of every TERM instead --
+          // terms x chain depth x 2 block barriers, ~1 500 per pass for an arm + hand: most of the ~300 us a pass took.)
           for (int k = 0; k < nj; ++k) {  // wave-uniform
             const int vk = l_var[k];
             if (vk < 0) continue;
@@ -401,17 +617,17 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
               for (int e = l_famoff[lane]; e < l_famoff[lane + 1]; ++e) sum += tmp[l_fam[e]];
               if (sum != 0.0) {
                 const int hi_ = lane > vk ? lane : vk, lo_ = lane > vk ? vk : lane;
-                H[(size_t)hi_ * nv + lo_] += sum;
+                H[GEN_TRI(hi_, lo_)] += sum;
               }
             }
             __syncthreads();
           }
         }
-        return fval;
+        GPROF_STAGE(3)  // second-order sweep
       };
 
       if (MODE == MODE_FK) {
-        eval_at(x, false);
+        eval_value(x);
         if (lane < nt) {
           const int f = tb.term_task[lane], row = tb.term_ref[lane];
           for (int i = 0; i < 3; ++i) kp.f64out[(it * kp.n_ref + row) * 3 + i] = P[f * 3 + i];
@@ -420,12 +636,13 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
         continue;
       }
       if (MODE == MODE_EVAL) {  // objective(x, grad): value without, gradient with the regulariser (quirk Q1)
-        const double f = eval_at(x, true);
+        const double f = eval_value(x);
+        assemble_model();
         if (lane == 0) {
           kp.f64out[r0] = f;
           if (dexpilot && kp.state) kp.state[r0] = nst;
         }
-        if (lane < nv) kp.g64out[r0 * kp.n_opt + tb.var_api[lane]] = g[lane] + 2.0 * delta * (x[lane] - xl[lane]);
+        if (lane < nv) kp.g64out[r0 * kp.n_opt + my_api] = g[lane] + 2.0 * delta * (x[lane] - xl[lane]);
         __syncthreads();
         continue;
       }
@@ -436,110 +653,98 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
         if (lane < nv) p = (xs[lane] - xl[lane]) * (xs[lane] - xl[lane]);
         return delta * gen_wave_sum(p);
       };
-      auto add_reg_model = [&]() {
+      auto add_reg_model = [&](const double* xs) {
         if (lane < nv) {
-          g[lane] += 2.0 * delta * (x[lane] - xl[lane]);
-          H[(size_t)lane * nv + lane] += 2.0 * delta;
+          g[lane] += 2.0 * delta * (xs[lane] - xl[lane]);
+          H[GEN_TRI(lane, lane)] += 2.0 * delta;
         }
         __syncthreads();
       };
-      if (lane < nv) x[lane] = fmin(fmax(x[lane], tb.lo[lane]), tb.hi[lane]);
+      if (lane < nv) {
+        x[lane] = fmin(fmax(x[lane], my_lo), my_hi);
+        xt[lane] = x[lane];
+      }
       __syncthreads();
-      double F = eval_at(x, true) + reg_at(x);
-      add_reg_model();
-      double lam = (double)kp.lam0, nu = 2.0;
+      // ONE value evaluation per pass (through ONE call site: every F that is ever compared comes from the same code, so the
+      // comparison is not one of two copies' rounding) and the model -- gradient + Hessian, most of a pass -- only at points
+      // that have been ACCEPTED: the kinematic state in LDS is the trial point's, so an accepted step goes straight on to
+      // assemble_model(), a rejected one costs the kinematics and the terms alone.  (Round 3: value at the trial point,
+      // then value + model again at the same point through a second inlined copy.)  The start point is "trial point 0".
+      double F = 0.0, lam = (double)kp.lam0, nu = 2.0;
       int iters = 0, status = ST_MAXITER;
       const double tol = (double)kp.tol, cap = (double)kp.step_cap;
-      bool bad = !(F == F);
-      while (!bad && iters < kp.max_iter) {
-        ++iters;
-        // active set and damped system (lower triangle), lane = row
-        if (lane < nv) {
-          const bool a = (x[lane] <= tb.lo[lane] && g[lane] > 0) || (x[lane] >= tb.hi[lane] && g[lane] < 0);
-          act[lane] = a ? 1.0 : 0.0;
-        }
-        __syncthreads();
-        if (lane < nv) {
-          const bool a = act[lane] != 0.0;
-          for (int u = 0; u <= lane; ++u) {
-            const bool au = a || act[u] != 0.0;
-            Hf[(size_t)lane * nv + u] = au ? (u == lane ? 1.0 : 0.0) : H[(size_t)lane * nv + u] + (u == lane ? lam : 0.0);
-          }
-          rhs[lane] = a ? 0.0 : -g[lane];
-        }
-        __syncthreads();
+      bool bad = false, first = true;
+      while (!bad && (first || iters < kp.max_iter)) {
         bool chol_ok = true;
-        for (int p = 0; p < nv; ++p) {
-          if (lane == p) {
-            const double dd = Hf[(size_t)p * nv + p];
-            flag[0] = dd > 0 ? sqrt(dd) : -1.0;
+        double smax = 0.0, pred = 0.0;
+        GPROF_START();
+        if (!first) {
+          ++iters;
+          GPROF_COUNT(11);
+          // active set and damped system (lower triangle), lane = row
+          if (lane < nv) {
+            const bool a = (x[lane] <= my_lo && g[lane] > 0) || (x[lane] >= my_hi && g[lane] < 0);
+            act[lane] = a ? 1.0 : 0.0;
           }
           __syncthreads();
-          const double piv = flag[0];
-          if (!(piv > 0)) {
-            chol_ok = false;
-            break;
-          }
-          if (lane == p) Hf[(size_t)p * nv + p] = piv;
-          if (lane > p && lane < nv) Hf[(size_t)lane * nv + p] /= piv;
+          GPROF_STAGE(4)  // active set
+          constexpr int NV = NSLOT == GEN_SLOTS_SMALL ? 38 : 64;  // rows the register factorisation holds
+          chol_ok = gen_factor_solve<NV>(lane, nv, H, g, act, lam, Hf, s);
           __syncthreads();
-          if (lane > p && lane < nv) {
-            const double lip = Hf[(size_t)lane * nv + p];
-            for (int j = p + 1; j <= lane; ++j) Hf[(size_t)lane * nv + j] -= lip * Hf[(size_t)j * nv + p];
+          GPROF_STAGE(5)  // factorisation + triangular solves (registers)
+          if (chol_ok) {
+            GPROF_STAGE(6)
+            double sm = lane < nv ? fabs(s[lane]) : 0.0;
+            sm = gen_wave_max(sm);
+            const double scale = (cap > 0 && sm > cap) ? cap / sm : 1.0;
+            if (lane < nv) {
+              const double xn = fmin(fmax(x[lane] + scale * s[lane], my_lo), my_hi);
+              xt[lane] = xn;
+              s[lane] = xn - x[lane];
+            }
+            __syncthreads();
+            double pp = 0.0, am = 0.0;
+            if (lane < nv) {
+              double hs = 0.0;
+              for (int u = 0; u < nv; ++u) hs += (u <= lane ? H[GEN_TRI(lane, u)] : H[GEN_TRI(u, lane)]) * s[u];
+              pp = -(g[lane] * s[lane] + 0.5 * s[lane] * hs);
+              am = fabs(s[lane]);
+            }
+            pred = gen_wave_sum(pp);
+            smax = gen_wave_max(am);
+            GPROF_STAGE(7)  // step, predicted decrease
+            if (lam <= (double)kp.lam0 && smax < (double)kp.blind_tol) {
+              // an essentially undamped Newton step of a verified model shorter than blind_tol: its error is ~C s^2, far
+              // below tol -- taken without a further evaluation (the rule of the specialised kernels)
+              if (lane < nv) x[lane] = xt[lane];
+              __syncthreads();
+              status = ST_CONVERGED;
+              break;
+            }
           }
-          __syncthreads();
         }
         bool accept = false;
-        double smax = 0.0, pred = 0.0, Ft = 0.0;
+        double Ft = 0.0;
         if (chol_ok) {
-          for (int p = 0; p < nv; ++p) {  // L y = rhs
-            if (lane == p) ybuf[p] = rhs[p] / Hf[(size_t)p * nv + p];
-            __syncthreads();
-            if (lane > p && lane < nv) rhs[lane] -= Hf[(size_t)lane * nv + p] * ybuf[p];
-            __syncthreads();
+          Ft = eval_value(xt) + reg_at(xt);
+          accept = first || ((Ft <= F) && (pred > 0));
+        }
+        if (first) {
+          first = false;
+          F = Ft;
+          bad = !(F == F);
+          if (!bad) {
+            assemble_model();
+            add_reg_model(xt);
           }
-          for (int p = nv - 1; p >= 0; --p) {  // L^T s = y
-            if (lane == p) s[p] = ybuf[p] / Hf[(size_t)p * nv + p];
-            __syncthreads();
-            if (lane < p) ybuf[lane] -= Hf[(size_t)p * nv + lane] * s[p];
-            __syncthreads();
-          }
-          double sm = lane < nv ? fabs(s[lane]) : 0.0;
-          sm = gen_wave_max(sm);
-          const double scale = (cap > 0 && sm > cap) ? cap / sm : 1.0;
-          if (lane < nv) {
-            const double xn = fmin(fmax(x[lane] + scale * s[lane], tb.lo[lane]), tb.hi[lane]);
-            xt[lane] = xn;
-            s[lane] = xn - x[lane];
-          }
-          __syncthreads();
-          double pp = 0.0, am = 0.0;
-          if (lane < nv) {
-            double hs = 0.0;
-            for (int u = 0; u < nv; ++u) hs += (u <= lane ? H[(size_t)lane * nv + u] : H[(size_t)u * nv + lane]) * s[u];
-            pp = -(g[lane] * s[lane] + 0.5 * s[lane] * hs);
-            am = fabs(s[lane]);
-          }
-          pred = gen_wave_sum(pp);
-          smax = gen_wave_max(am);
-          if (lam <= (double)kp.lam0 && smax < (double)kp.blind_tol) {
-            // an essentially undamped Newton step of a verified model shorter than blind_tol: its error is ~C s^2, far
-            // below tol -- taken without a further evaluation (the rule of the specialised kernels)
-            if (lane < nv) x[lane] = xt[lane];
-            __syncthreads();
-            status = ST_CONVERGED;
-            break;
-          }
-          Ft = eval_at(xt, false) + reg_at(xt);
-          accept = (Ft <= F) && (pred > 0);
+          continue;
         }
         if (accept) {
           const double rho = (F - Ft) / fmax(pred, 1e-300);
           const bool small = smax < tol || pred <= 1e-18 * fmax(F, 1e-30);
           if (lane < nv) x[lane] = xt[lane];
           __syncthreads();
-          F = eval_at(x, true) + reg_at(x);
-          add_reg_model();
+          F = Ft;
           const double t3 = 2.0 * rho - 1.0;
           double shrink = fmax(1.0 / 3.0, 1.0 - t3 * t3 * t3);
           if (kp.lam_fastdec > 0 && rho > 0.9) shrink = (double)kp.lam_fastdec;  // an accurate model: take the damping back fast
@@ -549,12 +754,11 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
             status = ST_CONVERGED;
             break;
           }
+          assemble_model();  // the model of the point just accepted (its kinematics are still in LDS)
+          add_reg_model(x);
         } else {
           lam *= nu;
           nu *= 2.0;
-          if (!(Ft == Ft) && chol_ok) {
-            // a non-finite trial value is a rejected step; a non-finite CURRENT value is caught below
-          }
           if (lam > 1e12) {
             status = ST_CONVERGED;  // no descent direction left at any damping: x is stationary to rounding
             break;
@@ -570,8 +774,8 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
       if (lane < nv) {
         const double v = nonfinite ? xl[lane] : x[lane];
         if (nonfinite) x[lane] = v;
-        kp.qout[it * ld + tb.var_api[lane]] = (float)v;
-        if (kp.qout64) kp.qout64[it * ld + tb.var_api[lane]] = v;
+        kp.qout[it * ld + my_api] = (float)v;
+        if (kp.qout64) kp.qout64[it * ld + my_api] = v;
       }
       if (lane == 0) {
         if (kp.status) kp.status[it] = status;
@@ -584,6 +788,7 @@ __global__ void __launch_bounds__(64) dexr_gen_kernel(KernelParams kp, GenTab tb
     if (MODE == MODE_SOLVE && dexpilot && kp.state && lane == 0) kp.state[r0] = st_carry;
     __syncthreads();
   }
+  GPROF_FLUSH()
 }
 
 }  // namespace dexr

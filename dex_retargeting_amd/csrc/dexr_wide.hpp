@@ -130,36 +130,25 @@ struct WideLds {
                                                        // origin frame); the joint-space grids keep them in the spare
                                                        // words 13 / 14 of XT row t
   static constexpr int SLOT0 = TM + (MIMIC ? 128 : 0);
-  // per frame slot.  Round 4: arrays whose lifetimes within a pass do not overlap share their bytes -- LDS decides how many
-  // waves a CU holds (a 24-row slot was 3 776 B, 17.4 KB per wave: two waves per SIMD whatever the registers allowed):
-  //   * JR (the term in flight's weighted Jacobian rows, term loop only) overlays P | SC (frame positions: dead once
-  //     terms() has published the term blocks; sines / cosines: dead once the chains are walked).  The positions of frames
-  //     on the fixed base are therefore re-written by fk() in every pass instead of once per kernel;
-  //   * CF (second-order vectors, written after the term loop) overlays TB (the term blocks, read by the term loop only);
-  //     the variable grid (MIMIC) keeps both, its second-order stage re-uses TB for the per-lane sums;
-  //   * XV (joint values for the mimic map) exists on the variable grid only.
+  // per frame slot
   static constexpr int P = 0;                          // 16 frames x 3 doubles
-  static constexpr int SC = P + 384;                   // NJ x 2 doubles: (sin q, cos q) of a revolute joint, (q, -) of a
-                                                       // prismatic one, computed by the joint's slot lane
-  static constexpr int JR = 0;                         // 4 rows x 4 classes x NRP floats (overlays P | SC)
-  static constexpr int JR_BYTES = 4 * 4 * NRP * 4;
-  static_assert(JR_BYTES <= 384 + NJ * 16, "the Jacobian rows overlay P | SC");
-  static constexpr int AX = SC + NJ * 16;              // NJ x 4 floats
+  static constexpr int AX = P + 384;                   // NJ x 4 floats
   static constexpr int OG = AX + NJ * 16;              // NJ x 4 floats
-  static constexpr int XV = OG + NJ * 16;              // MIMIC: NJ floats, the variables' values of the trial point
-  static constexpr int QJ = XV + (MIMIC ? NJ * 4 : 0); // MIMIC: NJ floats, values of the fixed joints of the frame
+  static constexpr int SC = OG + NJ * 16;              // NJ x 2 doubles: (sin q, cos q) of a revolute joint, (q, -) of a
+                                                       // prismatic one, computed by the joint's slot lane
+  static constexpr int XV = SC + NJ * 16;              // NJ floats: joint values of the trial point (MIMIC: variables)
+  static constexpr int QJ = XV + NJ * 4;               // MIMIC: NJ floats, values of the fixed joints of the frame
   static constexpr int GV = QJ + (MIMIC ? NJ * 4 : 0); // NMAX floats: gradient
-  static constexpr int TB = GV + NMAX * 4;             // 16 terms x 16 floats (MIMIC: reused for the second-order sums)
-  static constexpr int CF = MIMIC ? TB + 1024 : TB;    // NJ x 4 floats: second-order vectors (joint grids: overlay TB)
-  static_assert(NJ * 16 <= 1024, "the second-order vectors overlay the term blocks");
-  static constexpr int FS = TB + 1024 + (MIMIC ? NJ * 16 : 0);  // 32 bytes: row of the frame's inputs / of its item, item, frame of
+  static constexpr int CF = GV + NMAX * 4;             // NJ x 4 floats: second-order vectors
+  static constexpr int TB = CF + NJ * 16;              // 16 terms x 16 floats (MIMIC: reused for the second-order sums)
+  static constexpr int JR = TB + 1024;                 // 4 rows x 4 classes x NRP floats
+  static constexpr int FS = JR + 4 * 4 * NRP * 4;      // 32 bytes: row of the frame's inputs / of its item, item, frame of
                                                        // the sequence, DexPilot bits (registers are the scarce resource)
   static constexpr int XL = FS + 32;                   // NMAX floats: regularisation target (the frame's start row)
   static constexpr int SLOT = XL + NMAX * 4;
-  // LDS decides the occupancy (160 KB per CU, blocks of four waves): three blocks per CU for the joint grids of 16 and 24
-  // rows, two for the others (+ 512 B per block of compiler-allocated LDS)
-  static_assert(2 * (4 * (SLOT0 + 4 * SLOT) + 512) <= 160 * 1024, "two blocks per CU must fit");
-  static_assert(MIMIC || NMAX > 24 || 3 * (4 * (SLOT0 + 4 * SLOT) + 512) <= 160 * 1024, "three blocks per CU must fit");
+  // LDS decides the occupancy: two blocks of four waves per CU (160 KB); the 16-row joint grid is built for three
+  static_assert(2 * 4 * (SLOT0 + 4 * SLOT) <= 160 * 1024, "two blocks per CU must fit");
+  static_assert(MIMIC || NMAX != 16 || 3 * (4 * (SLOT0 + 4 * SLOT) + 512) <= 160 * 1024, "three blocks per CU must fit");
   static constexpr int WAVE = SLOT0 + 4 * SLOT;
 };
 
@@ -503,16 +492,9 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 
   // ---- float64 forward kinematics, one root-to-leaf chain per lane --------------------------------------------------
   auto fk = [&]() {
-    // frames on the fixed base never move, but their slots are overlaid by the Jacobian rows of the previous pass
-    if (l < tb.n_base_frame) {
 #pragma unroll
-      for (int i = 0; i < 3; ++i) Pl[l * 3 + i] = (double)tb.frame_off[l][i];
-    }
-    if (MIMIC) {
-#pragma unroll
-      for (int s = 0; s < NJ2; ++s)
-        if (jin[s]) XVl[jo_[s]] = xj[s];
-    }
+    for (int s = 0; s < NJ2; ++s)
+      if (jin[s]) XVl[jo_[s]] = xj[s];
     if (MIMIC) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -1167,32 +1149,10 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   double F = 0;
   float smax = 0, pred = 0;
   bool ok = true;
-  // XCD-LOCAL HAND-OUT (plain batches).  A frame's 252 bytes of keypoints straddle 128-byte lines it shares with its
-  // neighbours; handed out one by one from a single counter, neighbouring frames land on different XCDs -- different L2s --
-  // and every shared line is fetched twice (41 MB per Shadow-DexPilot launch against 29.6 MB of algorithmic bytes,
-  // profiles/r03).  So the frames a wave takes are contiguous PER XCD: the static first tiles are laid out XCD-major (block
-  // b runs on XCD b mod 8), the dynamic range [q0, nB) is cut into 8 contiguous chunks with a counter each, and a wave
-  // draws from the chunk of the XCD it runs on (XCC_ID) until that is dry, then helps with the others in turn.
-  // Index lists (fleet buckets, longest-first order) keep the single in-order queue: their order is the point.
-  constexpr int NXCD = 8;
-#ifndef DEXR_WIDE_XCD
-#define DEXR_WIDE_XCD 1
-#endif
-  const bool xcd_local = DEXR_WIDE_XCD && kp.perm == nullptr && !seq && kp.n_comp == 1;
-  int64_t tile_s = tile;  // static tile of this wave
-  if (xcd_local && (gridDim.x % NXCD) == 0) {
-    const int64_t bpx = gridDim.x / NXCD;
-    tile_s = (((int64_t)blockIdx.x % NXCD) * bpx + (int64_t)blockIdx.x / NXCD) * waves_per_block + wave_in_block;
-  }
-  unsigned pool_next = (unsigned)((tile_s * 4 < (int64_t)kp.q0 && tile_s * 4 < nB) ? tile_s * 4 : 0);
-  unsigned pool_end = (unsigned)((tile_s * 4 < (int64_t)kp.q0 && tile_s * 4 < nB) ? ((tile_s * 4 + 4 < nB) ? tile_s * 4 + 4 : nB) : 0);
+  unsigned pool_next = (unsigned)((tile * 4 < (int64_t)kp.q0 && tile * 4 < nB) ? tile * 4 : 0);
+  unsigned pool_end = (unsigned)((tile * 4 < (int64_t)kp.q0 && tile * 4 < nB) ? ((tile * 4 + 4 < nB) ? tile * 4 + 4 : nB) : 0);
   bool dry = false;
-  unsigned* queue = kp.queue + comp * NXCD;  // NXCD counters per component (only the first is used by in-order queues)
-  const int64_t dyn = nB > (int64_t)kp.q0 ? nB - (int64_t)kp.q0 : 0;
-  const int64_t chunk = xcd_local ? (dyn + NXCD - 1) / NXCD : dyn;  // frames per chunk of the dynamic range
-  const int n_chunk = xcd_local ? NXCD : 1;
-  const int my_xcc = xcd_local ? (int)(__builtin_amdgcn_s_getreg(63508) & 7u) : 0;  // XCC_ID (hardware register 20)
-  int q_rot = 0;  // wave-uniform: chunks this wave has found dry so far
+  unsigned* queue = kp.queue + comp;
   auto reset_state = [&]() {
     done = false;
     pending = false;
@@ -1224,23 +1184,14 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         // take exactly as many frames as there are idle rows: a frame parked in this wave's pool while its other rows
         // are busy would start late (near the end of the queue other waves' rows are idle by then)
         const unsigned nwant = (unsigned)__popcll(want) >> 4;
-        for (;;) {  // own chunk first, then the next ones (wave-uniform loop: at most n_chunk rounds per wave and launch)
-          const int c = (my_xcc + q_rot) % n_chunk;
-          unsigned off = 0;
-          if (lane == 0) off = atomicAdd(queue + c, nwant);
-          off = (unsigned)__builtin_amdgcn_readfirstlane((int)off);
-          const int64_t lo = (int64_t)kp.q0 + (int64_t)c * chunk + (int64_t)off;
-          int64_t hi = (int64_t)kp.q0 + (int64_t)(c + 1) * chunk;
-          hi = hi < nB ? hi : nB;
-          if (lo < hi) {
-            pool_next = (unsigned)lo;
-            pool_end = (unsigned)((lo + nwant < hi) ? lo + nwant : hi);
-            break;
-          }
-          if (++q_rot >= n_chunk) {
-            dry = true;
-            break;
-          }
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(queue, nwant);
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + kp.q0;
+        if ((int64_t)base >= nB) {
+          dry = true;
+        } else {
+          pool_next = base;
+          pool_end = (unsigned)(((int64_t)base + nwant < nB) ? base + nwant : nB);
         }
       }
       if (pool_next < pool_end) {
