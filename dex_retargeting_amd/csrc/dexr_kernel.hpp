@@ -953,13 +953,6 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
       }
       SPROF_STAGE(0)
       WTRACE_LOADED()
-#ifdef DEXR_PRIO
-      // experiment (not in the shipped library unless it measures): waves that still hold frames past DEXR_PRIO passes, or
-      // frames that saw a rejected step, are the launch's critical path -- give them VALU issue priority over the waves
-      // they share a SIMD with
-      if (__any(has && (my_iters >= DEXR_PRIO || nrej > 0))) __builtin_amdgcn_s_setprio(3);  // (DEXR_PRIO=99: rejections only)
-      else __builtin_amdgcn_s_setprio(0);
-#endif
 
       // (2) step from the accepted model (lanes holding a fresh frame evaluate their start point instead)
       real smax = 0, pred = 0;

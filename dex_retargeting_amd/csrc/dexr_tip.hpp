@@ -33,24 +33,11 @@
 
 namespace dexr {
 
-#ifndef DEXR_TIP_SCALAR
 typedef float kv2 __attribute__((ext_vector_type(2)));  // a register pair: operands of v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
 static __device__ __forceinline__ kv2 tip_yx(kv2 v) { return v.yx; }
-#else
-// -DDEXR_TIP_SCALAR=1 (experiment): the same formulas on a plain pair of floats -- v_fma_f32 / v_mul_f32 per component
-// instead of v_pk_* (tools/valu_rate.hip measures what each costs to issue)
-struct kv2 {
-  float x, y;
-};
-static __device__ __forceinline__ kv2 operator+(kv2 a, kv2 b) { return kv2{a.x + b.x, a.y + b.y}; }
-static __device__ __forceinline__ kv2 operator-(kv2 a, kv2 b) { return kv2{a.x - b.x, a.y - b.y}; }
-static __device__ __forceinline__ kv2 operator*(kv2 a, kv2 b) { return kv2{a.x * b.x, a.y * b.y}; }
-static __device__ __forceinline__ kv2 operator*(kv2 a, float b) { return kv2{a.x * b, a.y * b}; }
-static __device__ __forceinline__ kv2 operator*(float b, kv2 a) { return kv2{a.x * b, a.y * b}; }
-static __device__ __forceinline__ kv2 operator+(kv2 a, float b) { return kv2{a.x + b, a.y + b}; }
-static __device__ __forceinline__ kv2 operator-(kv2 a, float b) { return kv2{a.x - b, a.y - b}; }
-static __device__ __forceinline__ kv2 tip_yx(kv2 v) { return kv2{v.y, v.x}; }
-#endif
+// (Measured in round 4, tools/valu_rate.hip: with four waves on a SIMD a v_pk_fma_f32 issues in 2.74 cycles against 1.74 for
+// a v_fma_f32 -- 21 % cheaper per flop -- and a lone wave issues either every 5.07 cycles, so packing halves the lone-wave
+// time; the same pass on plain float pairs ran the headline launch in 46.4 instead of 47.5 us: no difference.)
 template <typename R> struct TipVec;
 template <> struct TipVec<float> { typedef kv2 v2; };
 template <> struct TipVec<double> { typedef double v2 __attribute__((ext_vector_type(2))); };
