@@ -4,7 +4,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
-T=${1:-r3z}
+T=${1:-r4z}
 cd "$R"
 timeout 2400 python -m pytest tests -m gpu -q > "$O/${T}_tests.txt" 2>&1
 grep "passed\|failed" "$O/${T}_tests.txt" | tail -1
@@ -16,7 +16,8 @@ for w in allegro_vector leap_position mixed_fleet; do
 import json,sys
 try:
     d=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
-    print(sys.argv[1].split("/")[-1], "n_gpus", d["n_gpus"], "rccl_world_size", d["config"].get("rccl_world_size"), "%.4g frames/s" % d["value"], "%.4f ms" % d["ms_per_step"], "serial", round(d["multi_gpu"]["gather_on_solve_stream"]["ms_per_step"],4), "graph", d["multi_gpu"]["graph_replay"])
+    m=d["multi_gpu"]
+    print(sys.argv[1].split("/")[-1], "n_gpus", d["n_gpus"], "rccl_world_size", d["config"].get("rccl_world_size"), "%.4g frames/s" % d["value"], "%.4f ms" % d["ms_per_step"], "k", m.get("steps_per_gather"), "no gather", round(m["no_gather"]["ms_per_step"],4), "serial", round(m["gather_on_solve_stream"]["ms_per_step"],4), "graph", m.get("graph_replay"))
 except Exception as e: print(sys.argv[1], "ERR", e)
 PY
 done

@@ -14,5 +14,5 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_fleet_kt -- python $R/be
 python $R/tools/timeline.py $O/prof_fleet_kt 30 > $O/prof_fleet_timeline.txt
 rm -rf $O/prof_fleet_kt
 cd "$R"
-timeout 900 python tools/all_configs.py > "$O/r3_all_configs.txt" 2>&1
-tail -3 "$O/r3_all_configs.txt"
+timeout 900 python tools/all_configs.py > "$O/all_configs_timing.txt" 2>&1
+tail -3 "$O/all_configs_timing.txt"
