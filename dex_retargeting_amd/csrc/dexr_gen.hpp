@@ -31,17 +31,26 @@
 namespace dexr {
 
 struct GenTab {  // device pointers into the uploaded generic table
-  int32_t nj, nf, nt, nv, nfam, max_depth, has_kp, pad_;
+  int32_t nj, nf, nt, nv, nfam, max_depth, has_kp;
+  int32_t lt_in_lds;  // the backward substitution transposes the factor through a second packed triangle in LDS (see
+                      // gen_factor_solve; chosen at model creation: create_generic in dexr_api.hip)
   const double *X, *axis, *jmul, *joff, *lo, *hi, *frame_off;
   const unsigned long long *frame_anc, *joint_anc;
   const int32_t *jtype, *parent, *depth, *src_idx, *var, *var_api, *fam_off, *fam, *frame_joint, *term_task, *term_origin,
       *term_ref, *row_ho, *row_ht;
 };
 
+// entries of the packed triangles in LDS: the Hessian and -- when the backward substitution transposes the factor through
+// LDS (gen_factor_solve) -- the transposed factor
+__host__ __device__ inline size_t gen_tri_doubles(int nv, bool lt_in_lds) {
+  const size_t ntri = (size_t)nv * (nv + 1) / 2;
+  return lt_in_lds ? 2 * ntri : ntri;
+}
+
 // doubles of LDS one wave needs
-__host__ __device__ inline size_t gen_lds_doubles(int nj, int nf, int nt, int nv, int nfam) {
+__host__ __device__ inline size_t gen_lds_doubles(int nj, int nf, int nt, int nv, int nfam, bool lt_in_lds) {
   const size_t state = (size_t)nj * 12 + nj * 3 + nj + (size_t)nf * 3 + (size_t)nt * 3 + nt + (size_t)nt * 3 + nt + (size_t)nt * 3 +
-                       (size_t)nt * 3 + (size_t)nv * 8 + (size_t)nv * (nv + 1) /* H, Hf: packed lower triangles */ + (size_t)nj * 3 + (size_t)nv * 3 + nj + 8;
+                       (size_t)nt * 3 + (size_t)nv * 6 + gen_tri_doubles(nv, lt_in_lds) + (size_t)nj * 3 + (size_t)nv * 3 + nj + 8;
   // wave-local copies of the tables the inner loops index (see "tables" in the kernel)
   const size_t ints = 3 * (size_t)nj + (size_t)nv + 1 + (size_t)nfam + (size_t)nf + 2 * (size_t)nt +
                       ((size_t)nv * (nv + 1) / 2 + 1) / 2 /* (row, column) of every entry of the packed triangle, 2 x uint8 */;
@@ -90,8 +99,7 @@ __device__ __forceinline__ double gen_readlane(double v, int src) {
 // triangle (NV doubles, statically indexed in fully unrolled loops), the factor is formed column by column
 // (Cholesky-Crout): entry (r, c) = (A[r][c] - sum_{k<c} L[r][k] L[c][k]) / L[c][c] with row c's entries read from lane c
 // (v_readlane with a constant lane: scalar operands, no LDS, no barrier).  Forward substitution column-wise (y_k broadcast
-// from lane k); for the backward substitution the factor is transposed once through LDS (`Lt`, a packed triangle that is
-// free at this point) so that it is column-wise too.  Round 3 kept the matrix in LDS, lane = row, one block barrier + a
+// from lane k); the backward substitution needs columns: see its two variants below.  Round 3 kept the matrix in LDS, lane = row, one block barrier + a
 // read-modify-write sweep per column: 113 k of the 303 k cycles of a 37-variable pass, 26 k more for the solves.
 // Not inlined: inside the kernel the register allocator carried ~400 live registers through the unrolled columns (92 on
 // its own); as a call it costs 22 spilled registers at the call site.
@@ -136,12 +144,6 @@ __device__ __noinline__ bool gen_factor_solve(int lane, int nv, const double* H,
     }
   }
   if (!ok) return false;
-  // the factor, transposed through LDS: lane c then holds column c (entries L[k][c], k >= c) in T[k]
-  if (rowv) {
-#pragma unroll
-    for (int c = 0; c < NV; ++c)
-      if (c < nv && c <= lane) Lt[base + c] = L[c];
-  }
   // L y = rhs: y_k is final on lane k once the columns before k have been subtracted
   double y = 0.0;
 #pragma unroll
@@ -152,17 +154,48 @@ __device__ __noinline__ bool gen_factor_solve(int lane, int nv, const double* H,
       if (lane > k) rhs = fma(-L[k], yk, rhs);
     }
   }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < NV; ++k) L[k] = (k < nv && rowv && k >= lane) ? Lt[k * (k + 1) / 2 + lane] : 0.0;  // column `lane`
-  // L^T s = y: s_k = y_k / L[k][k] once the rows after k have been subtracted; lane j < k then takes L[k][j] s_k off y_j
+  // L^T s = y needs the COLUMNS of the factor, which no lane holds
   double sv = 0.0;
+  bool in_regs = false;
+  if constexpr (NV <= 38) in_regs = Lt == nullptr;  // wave-uniform
+  if (in_regs) {
+    // (38-variable instantiation, chosen per model when it buys a resident wave: an arm + hand's wave needs 20 KB of LDS
+    // instead of 26 KB without the transposed copy -- 8 instead of 6 waves per CU, 29 -> 26 ms per 65 536 frames -- while
+    // small models, whose LDS was not the limit, lose 10 % to the extra instructions.)  Every lane carries the whole
+    // vector y as wave-uniform values (yv[k] = y_k read from lane k) and runs the substitution redundantly:
+    // s_k = yv[k] / L[k][k], then yv[j] -= L[k][j] s_k with row k's entries read from lane k -- 2 v_readlane + 1 FMA per
+    // entry like the factorisation, no LDS
+    constexpr int NY = NV <= 38 ? NV : 1;
+    double yv[NY];
 #pragma unroll
-  for (int k = NV - 1; k >= 0; --k) {
-    if (k < nv) {
-      const double sk = gen_readlane(y * invd, k);
-      if (lane == k) sv = sk;
-      if (lane < k) y = fma(-L[k], sk, y);
+    for (int k = 0; k < NY; ++k) yv[k] = k < nv ? gen_readlane(y, k) : 0.0;
+#pragma unroll
+    for (int k = NY - 1; k >= 0; --k) {
+      if (k < nv) {
+        const double sk = yv[k] * gen_readlane(invd, k);
+        if (lane == k) sv = sk;
+#pragma unroll
+        for (int j = 0; j < k; ++j) yv[j] = fma(-gen_readlane(L[j], k), sk, yv[j]);
+      }
+    }
+  } else {
+    // the factor is transposed once through LDS (`Lt`, a second packed triangle), lane c then holds column c (entries
+    // L[k][c], k >= c) and the substitution is column-wise like the forward one
+    if (rowv) {
+#pragma unroll
+      for (int c = 0; c < NV; ++c)
+        if (c < nv && c <= lane) Lt[base + c] = L[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) L[k] = (k < nv && rowv && k >= lane) ? Lt[k * (k + 1) / 2 + lane] : 0.0;  // column `lane`
+#pragma unroll
+    for (int k = NV - 1; k >= 0; --k) {
+      if (k < nv) {
+        const double sk = gen_readlane(y * invd, k);
+        if (lane == k) sv = sk;
+        if (lane < k) y = fma(-L[k], sk, y);
+      }
     }
   }
   if (rowv) s_out[lane] = sv;
@@ -189,13 +222,11 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
   double* xt = xl + nv;
   double* g = xt + nv;
   double* s = g + nv;
-  double* rhs = s + nv;
-  double* act = rhs + nv;
-  double* ybuf = act + nv;
+  double* act = s + nv;
   const int ntri = nv * (nv + 1) / 2;
-  double* H = ybuf + nv;           // lower triangle, packed by rows: entry (r, c), c <= r, at r (r + 1) / 2 + c
-  double* Hf = H + ntri;
-  double* jcol = Hf + ntri;        // nj x 3
+  double* H = act + nv;            // lower triangle, packed by rows: entry (r, c), c <= r, at r (r + 1) / 2 + c
+  double* Lt = H + ntri;           // (tb.lt_in_lds only: the transposed factor, see gen_factor_solve)
+  double* jcol = H + gen_tri_doubles(nv, tb.lt_in_lds != 0);  // nj x 3
   double* vcol = jcol + nj * 3;         // nv x 3
   double* tmp = vcol + nv * 3;          // nj
   double* flag = tmp + nj;              // 8 scalars
@@ -689,7 +720,7 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
           __syncthreads();
           GPROF_STAGE(4)  // active set
           constexpr int NV = NSLOT == GEN_SLOTS_SMALL ? 38 : 64;  // rows the register factorisation holds
-          chol_ok = gen_factor_solve<NV>(lane, nv, H, g, act, lam, Hf, s);
+          chol_ok = gen_factor_solve<NV>(lane, nv, H, g, act, lam, tb.lt_in_lds ? Lt : nullptr, s);
           __syncthreads();
           GPROF_STAGE(5)  // factorisation + triangular solves (registers)
           if (chol_ok) {

@@ -4,7 +4,7 @@
 #include "dexr_launch.hpp"
 
 namespace dexr {
-size_t gen_lds_bytes(const GenTab& tb) { return gen_lds_doubles(tb.nj, tb.nf, tb.nt, tb.nv, tb.nfam) * sizeof(double); }
+size_t gen_lds_bytes(const GenTab& tb) { return gen_lds_doubles(tb.nj, tb.nf, tb.nt, tb.nv, tb.nfam, tb.lt_in_lds != 0) * sizeof(double); }
 
 template <int MODE, int NSLOT> static hipError_t launch_gen_mode(const KernelParams& kp, const GenTab& tb, dim3 grid, size_t lds, hipStream_t st) {
   static DynLds dyn;
