@@ -4,14 +4,18 @@ interpreter of the SAME compiled kinematic tables (tests/table_interp.solve_vect
 damped Gauss-Newton steps -- real per-item work whose result depends on every input of the item), plus a trivial
 stand-in for the DexPilot state plumbing.  What is tested is the partition, padding, ordering and state handling that
 bench.py / ShardedRetargeter rely on."""
+import json
 import os
 import socket
+import subprocess
 import sys
 
 import numpy as np
 import pytest
 
 from dex_retargeting_amd.distributed import shard_bounds
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_shard_bounds_partition():
@@ -243,6 +247,41 @@ def test_steps_per_gather_policy():
     assert k == 1
     k2 = steps_per_gather_for(0.047, shard, 2)                             # 2 GPUs: 13 us of wire per 47 us step
     assert 1 <= k2 <= 2
+
+
+def test_bench_watchdog_prints_the_line_it_has_and_ends_the_job():
+    """bench.py's N > 1 path arms a deadline before every optional measurement: a collective that misbehaves across ranks
+    hangs instead of raising.  When the deadline passes, rank 0 prints the headline line it already holds (with what timed
+    out) and the process leaves with exit code 0; a non-zero rank just leaves."""
+    code = ("import sys, time; sys.argv = ['bench.py']; sys.path.insert(0, %r); import bench;"
+            "wd = bench.Watchdog(RANK, 0.6);"
+            "wd.line = {'metric': 'm', 'value': 1.0}; wd.done['no_gather'] = {'ms_per_step': 1.0};"
+            "wd.arm('graph_replay'); time.sleep(30); print('NOT REACHED')") % REPO
+    for rank in (0, 1):
+        r = subprocess.run([sys.executable, "-c", code.replace("RANK", str(rank))], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and "NOT REACHED" not in r.stdout, (r.returncode, r.stdout, r.stderr[-500:])
+        if rank == 0:
+            line = json.loads(r.stdout.strip().splitlines()[-1])
+            assert line["value"] == 1.0 and "graph_replay" in line["multi_gpu"]["watchdog"]
+            assert line["multi_gpu"]["no_gather"] == {"ms_per_step": 1.0}
+        else:
+            assert r.stdout.strip() == ""
+
+
+def test_all_cores_cpu_baseline_starts_the_workers_it_reports():
+    """the all-cores record said 64 processes and had started 7.  plan_workers starts exactly `procs`
+    workers of `frames_per_proc` frames each (wrapping around the batch), and run_all_cores reports the number started."""
+    from oracle import cases, cpu_worker
+
+    assert cpu_worker.plan_workers(65536, 64, 9658) == [(w * 9658, 9658) for w in range(64)]
+    assert cpu_worker.plan_workers(0, 4, 10) == []
+    rel = "teleop/allegro_hand_right.yml"
+    prob = cases.problem_from_config(rel)
+    d = cases.human_set(prob, 6)
+    res = cpu_worker.run_all_cores(rel, d["ref"], d["last"], 3, 4, deadline_s=100.0)
+    assert res is not None
+    frames, seconds, workers = res
+    assert (frames, workers) == (12, 3) and seconds > 0  # 3 workers x 4 frames out of a 6-frame batch: indices wrap
 
 
 def test_bench_gpus_n_starts_n_ranks_by_itself():

@@ -1156,6 +1156,20 @@ def test_native_allgather_world_size_one_and_graph_capture():
         torch.cuda.synchronize()
         assert tuple(full.shape) == (1, B, prob.n_opt)
         assert np.array_equal(full[0].cpu().numpy(), want)
+    # one collective per 3 steps (NativeGather.steps_per_gather): 7 steps = two full groups + a partly filled one that
+    # finish() flushes; every group's block holds its steps' shards in order
+    ng = NativeGather(comm, B, prob.n_opt, dev, depth=2, overlap=True, steps_per_gather=3)
+    outs = []
+    for k in range(7):
+        out = ng.shard(k)
+        model.retarget_dev(B, ref.data_ptr(), 0, last.data_ptr(), 0, out.data_ptr(),
+                           stream=torch.cuda.current_stream().cuda_stream)
+        ng.gather(k)
+        outs.append(out)
+    full = ng.finish()
+    torch.cuda.synchronize()
+    assert ng.collectives == 3 and tuple(full.shape) == (1, 3, B, prob.n_opt)
+    assert np.array_equal(full[0, 0].cpu().numpy(), want)  # step 6, the only one of the last (flushed) group
     # one captured graph of [solve -> all-gather]
     shard = torch.zeros((B, prob.n_opt), dtype=torch.float32, device=dev)
     full = torch.zeros((1, B, prob.n_opt), dtype=torch.float32, device=dev)
