@@ -444,11 +444,13 @@ def online_run(rel):
     return np.array(dt), np.array(qs), np.array(dt_abi), np.array(refs), np.array(lasts), seq
 
 
-def online_record(no_cpu=False):
-    """Sub-record `online_teleop` (BASELINE configs[0]; SURVEY.md row 13 MEASUREMENT TEMPLATE)."""
+def online_record():
+    """Sub-record `online_teleop` (BASELINE configs[0]; SURVEY.md row 13 MEASUREMENT TEMPLATE).  Returns (record, context
+    for online_cpu_port); touches nothing under oracle/."""
     out = {"frames": 621, "protocol": "profile_online_retargeting.py:18-36: one SeqRetargeting.retarget(ref_value) per fixture "
                                     "frame, perf_counter around the call only, B = 1, host arrays",
            "robots": {}}
+    ctx = None
     for rel, title in ONLINE_ROBOTS:
         try:
             dt, qs, dt_abi, refs, lasts, seq = online_run(rel)
@@ -462,30 +464,35 @@ def online_record(no_cpu=False):
                               "p99_ms": float(np.percentile(dt_abi, 99) * 1e3),
                               "note": "dexr_retarget (host pointers) alone, through ctypes: pack -> one H2D -> solve "
                                       "kernel -> one D2H on the handle's private stream -> hipStreamSynchronize"}}
-        if rel == ONLINE_ROBOTS[0][0] and not no_cpu:
-            # the CPU port on the SAME loop (checker code, imported here, after every GPU timing of this record)
-            from oracle import cases, cport
-
-            prob = cases.problem_from_config(rel)
-            cp = cport.CProblem(prob)
-            n_cpu = len(refs)
-            last = lasts[0].astype(np.float64)
-            t_cpu, dq = [], []
-            lo, hi = seq.joint_limits[:, 0], seq.joint_limits[:, 1]
-            for i in range(n_cpu):
-                tic = time.perf_counter()
-                q_ref, _ = cport.solve_ref_as_configured_c(cp, refs[i][None], None, np.clip(last, lo, hi)[None].astype(np.float32))
-                t_cpu.append(time.perf_counter() - tic)
-                last = q_ref[0].astype(np.float64)
-            t_cpu = np.array(t_cpu)
-            rec["cpu_port_same_loop"] = {"frames": n_cpu, "fps": n_cpu / t_cpu.sum(), "mean_ms": float(t_cpu.mean() * 1e3),
-                                         "p99_ms": float(np.percentile(t_cpu, 99) * 1e3), "kind": "port", "cores": 1,
-                                         "note": "the oracle's plain-C closure + scipy's compiled SLSQP at the reference's ftol, its "
-                                                 "own warm-start chain over the 621 fixture frames (the reference's loop, "
-                                                 "profile_online_retargeting.py:18-36, with compiled stand-ins for "
-                                                 "pinocchio / nlopt and no torch overhead)"}
+        if rel == ONLINE_ROBOTS[0][0]:
+            ctx = dict(rel=rel, refs=refs, lasts=lasts, lo=seq.joint_limits[:, 0].copy(), hi=seq.joint_limits[:, 1].copy())
         out["robots"][rel] = rec
-    return out
+    return out, ctx
+
+
+def online_cpu_port(rec, ctx):
+    """Checker-side leg of `online_teleop`: the CPU port on the SAME loop as the first robot (oracle/: imported here, in the
+    checker section of the run, after every GPU timing)."""
+    from oracle import cases, cport
+
+    rel, refs, lasts, lo, hi = ctx["rel"], ctx["refs"], ctx["lasts"], ctx["lo"], ctx["hi"]
+    prob = cases.problem_from_config(rel)
+    cp = cport.CProblem(prob)
+    n_cpu = len(refs)
+    last = lasts[0].astype(np.float64)
+    t_cpu = []
+    for i in range(n_cpu):
+        tic = time.perf_counter()
+        q_ref, _ = cport.solve_ref_as_configured_c(cp, refs[i][None], None, np.clip(last, lo, hi)[None].astype(np.float32))
+        t_cpu.append(time.perf_counter() - tic)
+        last = q_ref[0].astype(np.float64)
+    t_cpu = np.array(t_cpu)
+    rec["robots"][rel]["cpu_port_same_loop"] = {
+        "frames": n_cpu, "fps": n_cpu / t_cpu.sum(), "mean_ms": float(t_cpu.mean() * 1e3),
+        "p99_ms": float(np.percentile(t_cpu, 99) * 1e3), "kind": "port", "cores": 1,
+        "note": "the oracle's plain-C closure + scipy's compiled SLSQP at the reference's ftol, its own warm-start chain over the "
+                "621 fixture frames (the reference's loop, profile_online_retargeting.py:18-36, with compiled stand-ins for "
+                "pinocchio / nlopt and no torch overhead)"}
 
 
 OFFLINE_ROBOTS = ["offline/allegro_hand_right.yml", "offline/shadow_hand_right.yml", "offline/leap_hand_right.yml",
@@ -871,6 +878,7 @@ def run_single(args):
 
     # ---- sub-records (rank 0's GPU only; untouched by the collective) --------------------------------------------
     sub = {}
+    online_ctx = None
     if world > 1:
         args.headline_only = True  # scaling runs: the headline (+ the pipelined-gather figure) only
     if rank == 0 and not args.headline_only:
@@ -909,7 +917,7 @@ def run_single(args):
     if rank == 0 and not args.headline_only and args.workload == "allegro_vector":
         torch.cuda.synchronize()
         try:
-            sub["online_teleop"] = online_record(no_cpu=args.no_cpu_baseline)
+            sub["online_teleop"], online_ctx = online_record()
         except Exception as e:
             sub["online_teleop"] = {"error": repr(e)}
     also = {}
@@ -975,6 +983,11 @@ def run_single(args):
         rec["parity"] = parity_block(w2, b2, q2, min(4096, B), 0 if args.no_cpu_baseline else min(64, B))[0]
         out.setdefault("also", {})[name] = rec
 
+    if online_ctx is not None and not args.no_cpu_baseline:
+        try:
+            online_cpu_port(out["online_teleop"], online_ctx)
+        except Exception as e:
+            out["online_teleop"]["cpu_port_error"] = repr(e)
     if fleet_m is not None:
         import bench_fleet
 
