@@ -19,6 +19,49 @@ ARM_HAND = os.path.join(REPO, "tests", "urdf", "arm_shadow_hand_right.urdf")
 RetargetingConfig.set_default_urdf_dir(str(DEFAULT_URDF_DIR))
 
 
+def comb_hand_urdf(path: str, fingers: int = 6, joints: int = 7, wrist: int = 4) -> str:
+    """A synthetic hand for the tables' upper range: a `wrist`-joint arm, then `fingers` chains of `joints` revolute joints
+    hanging off the palm -- 46 movable joints in ONE component by default (every target link moves with the wrist), more
+    than the 38-variable instantiation of the general kernel holds.  Axes alternate z / y / y / x, 25 mm links, a
+    `f<i>_tip` link at the end of every chain.  Written to `path`, which is returned."""
+    axes = ["0 0 1", "0 1 0", "0 1 0", "1 0 0"]
+    out = ['<?xml version="1.0"?>', '<robot name="comb_hand">', '  <link name="base"/>']
+
+    def revolute(name, parent, child, xyz, rpy, axis):
+        return [f'  <link name="{child}"/>', f'  <joint name="{name}" type="revolute">', f'    <parent link="{parent}"/>',
+                f'    <child link="{child}"/>', f'    <origin xyz="{xyz}" rpy="{rpy}"/>', f'    <axis xyz="{axis}"/>',
+                '    <limit lower="-0.6" upper="0.9" effort="1" velocity="1"/>', '  </joint>']
+
+    parent = "base"
+    for w in range(wrist):
+        child = "palm" if w == wrist - 1 else f"w_l{w}"
+        out += revolute(f"w_j{w}", parent, child, "0 0 0.04", "0 0 0", axes[(w + 1) % 4])
+        parent = child
+    for f in range(fingers):
+        parent = "palm"
+        for j in range(joints):
+            child = f"f{f}_l{j}"
+            xyz = f"{0.02 * (f - fingers / 2):.4f} 0.01 0.0" if j == 0 else "0 0 0.025"
+            out += revolute(f"f{f}_j{j}", parent, child, xyz, f"0 0 {0.1 * f:.2f}", axes[j % 4])
+            parent = child
+        out += [f'  <link name="f{f}_tip"/>', f'  <joint name="f{f}_tipj" type="fixed">', f'    <parent link="{parent}"/>',
+                f'    <child link="f{f}_tip"/>', '    <origin xyz="0 0 0.02" rpy="0 0 0"/>', '  </joint>']
+    out.append("</robot>")
+    with open(path, "w") as fh:
+        fh.write("\n".join(out) + "\n")
+    return path
+
+
+def comb_hand_config(urdf: str, kind: str, fingers: int = 6, joints: int = 7) -> dict:
+    tips = [f"f{f}_tip" for f in range(fingers)]
+    mids = [f"f{f}_l{joints // 2}" for f in range(fingers)]
+    if kind == "position":
+        return dict(type="position", urdf_path=urdf, target_link_names=tips + mids,
+                    target_link_human_indices=list(range(2 * fingers)), low_pass_alpha=1.0)
+    return dict(type="vector", urdf_path=urdf, target_origin_link_names=["base"] * (2 * fingers), target_task_link_names=tips + mids,
+                target_link_human_indices=[[0] * (2 * fingers), list(range(1, 2 * fingers + 1))], scaling_factor=1.0, low_pass_alpha=1.0)
+
+
 def arm_hand_config(kind: str) -> dict:
     """An arm + Shadow hand retargeting problem (31 joints + 6 dummy free joints for the position type).  21 reference
     rows: every MANO keypoint is matched to a link (position), or 20 wrist/elbow-to-link vectors (vector)."""
@@ -114,3 +157,29 @@ def test_fk_table_of_a_long_chain_falls_back_to_the_generic_format():
         assert np.abs(P - want).max() < 1e-12
     else:  # fits the fixed records after all: nothing to check here
         assert cm.n_comp >= 1
+
+
+@pytest.mark.parametrize("kind", ["position", "vector"])
+def test_a_46_variable_model_compiles_to_generic_tables(tmp_path, kind):
+    """46 movable joints in one component (a 4-joint wrist + six chains of seven): beyond the fixed tables and beyond the
+    38-variable instantiation of the general kernel (its 64-variable one serves it).  The interpreter's frame positions ==
+    the oracle's link positions."""
+    urdf = comb_hand_urdf(str(tmp_path / "comb_hand.urdf"))
+    cfg = comb_hand_config(urdf, kind)
+    seq = RetargetingConfig.from_dict(cfg).build()
+    opt = seq.optimizer
+    cm = opt.compiled_model()
+    assert cm.generic is not None and cm.n_comp == 0
+    t = gi.parse(cm.to_blob())
+    assert t["nv"] == opt.opt_dof == 46 and t["nt"] == 12
+    r = OracleRobot(urdf)
+    assert r.dof_joint_names == opt.robot.dof_joint_names
+    rng = np.random.default_rng(5)
+    lim = r.joint_limits
+    names = cfg["target_link_names"] if kind == "position" else list(dict.fromkeys(cfg["target_origin_link_names"] + cfg["target_task_link_names"]))
+    q = rng.uniform(lim[:, 0], lim[:, 1])
+    x = q[opt.idx_pin2target]
+    P = gi.frame_positions(t, gi.joint_values(t, x=np.array([x[a] for a in t["var_api"]]), fixed=q[opt.idx_pin2fixed]))
+    want = r.link_positions(q[None], names)[0]
+    for w in want:  # frames are stored in first-use order of the terms: every wanted link position is one of them
+        assert np.abs(P - w).max(1).min() < 1e-12

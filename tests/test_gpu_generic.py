@@ -17,7 +17,7 @@ from dex_retargeting_amd.retargeting_config import RetargetingConfig
 from oracle import cases, solvers
 from oracle.kin import OracleRobot
 from oracle.objectives import OracleProblem
-from test_generic_tables import ARM_HAND, arm_hand_config
+from test_generic_tables import ARM_HAND, arm_hand_config, comb_hand_config, comb_hand_urdf
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -176,3 +176,36 @@ def test_general_kernel_sequence_mode_equals_frame_by_frame():
                            stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.abs(t_raw.cpu().numpy() - np.stack(want)).max() < 2e-6
+
+
+@pytest.mark.parametrize("kind", ["position", "vector"])
+def test_a_46_variable_model_runs_on_the_64_variable_instantiation(tmp_path, kind):
+    """A 4-joint wrist + six chains of seven revolute joints: 46 variables in one component -- the general kernel's second instantiation (33
+    Hessian entries per lane in registers, 64 rows for the register factorisation, the factor transposed through LDS for
+    the backward substitution).  Solved to the oracle's minimum from near starts; objective closure == the oracle's."""
+    urdf = comb_hand_urdf(str(tmp_path / "comb_hand.urdf"))
+    cfg = comb_hand_config(urdf, kind)
+    seq = RetargetingConfig.from_dict(cfg).build()
+    opt = seq.optimizer
+    r = OracleRobot(urdf)
+    if kind == "position":
+        prob = OracleProblem(r, "position", None, target_link_names=cfg["target_link_names"])
+        prob.target_link_human_indices = np.arange(12)
+    else:
+        prob = OracleProblem(r, "vector", None, target_origin_link_names=cfg["target_origin_link_names"],
+                             target_task_link_names=cfg["target_task_link_names"], scaling=cfg["scaling_factor"])
+        prob.target_link_human_indices = np.array(cfg["target_link_human_indices"])
+    assert opt.device_model().kernel()[0] == _lib.KERNEL_GENERAL and opt.opt_dof == 46
+    B = 64
+    d = cases.reachable_set(prob, B, 0.03)
+    q, info = opt.device_model().retarget(d["ref"], None, d["last"], want_info=True)
+    want = solvers.solve_lm_batched(prob, d["ref"], None, d["last"], newton=True, max_iter=100)
+    l64 = d["last"].astype(np.float64)
+    dq = np.abs(q - want).max(1)
+    F_got, F_want = prob.total(q.astype(np.float64), d["ref"], None, l64), prob.total(want, d["ref"], None, l64)
+    far = dq >= 1e-4
+    assert far.mean() <= 0.05 and np.all(F_got[far] <= F_want[far] + 1e-9), (kind, dq.max(), int(far.sum()))
+    assert np.all(info["status"] <= 1)
+    f, g = opt.device_model().eval(d["ref"][:8], None, d["last"][:8], want[:8])
+    fo, go, _ = prob.evaluate(want[:8], d["ref"][:8], None, d["last"][:8])
+    assert np.allclose(f, fo, rtol=1e-6, atol=1e-12) and np.allclose(g, go, rtol=1e-6, atol=1e-9)
