@@ -497,10 +497,14 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) rc_[i] = (64 * i + lane < ntri) ? (int)l_rc[64 * i + lane] : 0;
         const bool pos = kp.kind == DEXR_KIND_POSITION;
-        // entries of H owned by this lane += the term's contribution; vb: the variables' columns, ub: u . column
-        auto add_entries = [&](int t, const double* vb, const double* ub) {
+        // entries of H owned by this lane += the contributions of term t (columns in vb, u . column in ub) and -- `two` -- of
+        // term t + 1 (vb2, ub2), formed in one body so that both terms' LDS reads are in flight together
+        auto add_entries = [&](int t, const double* vb, const double* ub, bool two, const double* vb2, const double* ub2) {
+          const int t2 = two ? t + 1 : t;
           const double k0 = pos ? tc2[t * 3] : tc1[t], k1 = pos ? tc2[t * 3 + 1] : tc1[t], k2 = pos ? tc2[t * 3 + 2] : tc1[t];
           const double kb = pos ? 0.0 : tc2[t * 3];
+          const double m0 = pos ? tc2[t2 * 3] : tc1[t2], m1 = pos ? tc2[t2 * 3 + 1] : tc1[t2], m2 = pos ? tc2[t2 * 3 + 2] : tc1[t2];
+          const double mb = pos ? 0.0 : tc2[t2 * 3];
 #pragma unroll
           for (int i4 = 0; i4 < NSLOT; i4 += 4) {
             if (64 * i4 < ntri) {  // wave-uniform, per group of four slots: the slots of a group overlap their LDS reads
@@ -511,6 +515,10 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
                   // position: sum_i k_i v_r[i] v_c[i]  |  vector kinds: c1 (v_r . v_c) + (c2 - c1) (u . v_r) (u . v_c)
                   double add = k0 * vb[r * 3] * vb[c * 3] + k1 * vb[r * 3 + 1] * vb[c * 3 + 1] + k2 * vb[r * 3 + 2] * vb[c * 3 + 2];
                   if (!pos) add += kb * ub[r] * ub[c];  // (0 x uninitialised LDS is not 0)
+                  if (two) {
+                    add += m0 * vb2[r * 3] * vb2[c * 3] + m1 * vb2[r * 3 + 1] * vb2[c * 3 + 1] + m2 * vb2[r * 3 + 2] * vb2[c * 3 + 2];
+                    if (!pos) add += mb * ub2[r] * ub2[c];
+                  }
                   hacc[i] += add;
                 }
               }
@@ -550,23 +558,30 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
           // double-buffered (vcol | jcol, tmp | act: both spare here) -- ONE barrier per term instead of three
           const int v = lane < nj ? l_var[lane] : -1;
           const double m = lane < nj ? l_jmul[lane] : 0.0;
-          for (int t = 0; t < nt; ++t) {
-            double* vb = (t & 1) ? jcol : vcol;
-            double* ub = (t & 1) ? act : tmp;
+          // lane k: its variable's column of term t into the buffer pair (vb, ub), its gradient entry
+          auto own_column = [&](int t, double* vb, double* ub) {
+            double c[3];
+            joint_column(t, c);
+            if (v >= 0) {
+              const double c0 = m * c[0], c1 = m * c[1], c2 = m * c[2];
+              vb[v * 3] = c0; vb[v * 3 + 1] = c1; vb[v * 3 + 2] = c2;
+              g[v] += tg[t * 3] * c0 + tg[t * 3 + 1] * c1 + tg[t * 3 + 2] * c2;
+              if (!pos) ub[v] = tu[t * 3] * c0 + tu[t * 3 + 1] * c1 + tu[t * 3 + 2] * c2;
+            }
+          };
+          // terms in PAIRS: both terms' columns are formed and published before one barrier, both terms' entries are added
+          // before the next -- as many barriers per term as the double-buffered single-term loop had (one), but two
+          // independent chains of LDS round trips in flight in either phase
+          for (int t = 0; t < nt; t += 2) {
+            const bool two = t + 1 < nt;  // wave-uniform
             if (lane < nj) {
-              double c[3];
-              joint_column(t, c);
-              if (v >= 0) {
-                const double c0 = m * c[0], c1 = m * c[1], c2 = m * c[2];
-                vb[v * 3] = c0; vb[v * 3 + 1] = c1; vb[v * 3 + 2] = c2;
-                g[v] += tg[t * 3] * c0 + tg[t * 3 + 1] * c1 + tg[t * 3 + 2] * c2;
-                if (!pos) ub[v] = tu[t * 3] * c0 + tu[t * 3 + 1] * c1 + tu[t * 3 + 2] * c2;
-              }
+              own_column(t, vcol, tmp);
+              if (two) own_column(t + 1, jcol, act);
             }
             __syncthreads();
-            add_entries(t, vb, ub);
+            add_entries(t, vcol, tmp, two, jcol, act);
+            __syncthreads();
           }
-          __syncthreads();
         } else {
           for (int t = 0; t < nt; ++t) {
             if (lane < nj) {
@@ -588,7 +603,7 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
               if (!pos) tmp[lane] = tu[t * 3] * c[0] + tu[t * 3 + 1] * c[1] + tu[t * 3 + 2] * c[2];
             }
             __syncthreads();
-            add_entries(t, vcol, tmp);
+            add_entries(t, vcol, tmp, false, vcol, tmp);
             __syncthreads();
           }
         }
