@@ -464,35 +464,42 @@ def online_record():
                               "p99_ms": float(np.percentile(dt_abi, 99) * 1e3),
                               "note": "dexr_retarget (host pointers) alone, through ctypes: pack -> one H2D -> solve "
                                       "kernel -> one D2H on the handle's private stream -> hipStreamSynchronize"}}
-        if rel == ONLINE_ROBOTS[0][0]:
-            ctx = dict(rel=rel, refs=refs, lasts=lasts, lo=seq.joint_limits[:, 0].copy(), hi=seq.joint_limits[:, 1].copy())
+        ctx = ctx or []
+        ctx.append(dict(rel=rel, refs=refs, lasts=lasts, lo=seq.joint_limits[:, 0].copy(), hi=seq.joint_limits[:, 1].copy()))
         out["robots"][rel] = rec
     return out, ctx
 
 
-def online_cpu_port(rec, ctx):
-    """Checker-side leg of `online_teleop`: the CPU port on the SAME loop as the first robot (oracle/: imported here, in the
-    checker section of the run, after every GPU timing)."""
+def online_cpu_port(rec, ctxs):
+    """Checker-side leg of `online_teleop`: the CPU port on the SAME loop, for every robot of the record (oracle/: imported
+    here, in the checker section of the run, after every GPU timing).  DexPilot robots carry their projection state from
+    frame to frame like the reference's optimizer object does (optimizer.py:466-476)."""
     from oracle import cases, cport
 
-    rel, refs, lasts, lo, hi = ctx["rel"], ctx["refs"], ctx["lasts"], ctx["lo"], ctx["hi"]
-    prob = cases.problem_from_config(rel)
-    cp = cport.CProblem(prob)
-    n_cpu = len(refs)
-    last = lasts[0].astype(np.float64)
-    t_cpu = []
-    for i in range(n_cpu):
-        tic = time.perf_counter()
-        q_ref, _ = cport.solve_ref_as_configured_c(cp, refs[i][None], None, np.clip(last, lo, hi)[None].astype(np.float32))
-        t_cpu.append(time.perf_counter() - tic)
-        last = q_ref[0].astype(np.float64)
-    t_cpu = np.array(t_cpu)
-    rec["robots"][rel]["cpu_port_same_loop"] = {
-        "frames": n_cpu, "fps": n_cpu / t_cpu.sum(), "mean_ms": float(t_cpu.mean() * 1e3),
-        "p99_ms": float(np.percentile(t_cpu, 99) * 1e3), "kind": "port", "cores": 1,
-        "note": "the oracle's plain-C closure + scipy's compiled SLSQP at the reference's ftol, its own warm-start chain over the "
-                "621 fixture frames (the reference's loop, profile_online_retargeting.py:18-36, with compiled stand-ins for "
-                "pinocchio / nlopt and no torch overhead)"}
+    for ctx in ctxs:
+        rel, refs, lasts, lo, hi = ctx["rel"], ctx["refs"], ctx["lasts"], ctx["lo"], ctx["hi"]
+        prob = cases.problem_from_config(rel)
+        cp = cport.CProblem(prob)
+        n_cpu = len(refs)
+        last = lasts[0].astype(np.float64)
+        proj = np.zeros((1, prob.n_pair), bool) if prob.kind == "dexpilot" else None
+        t_cpu = []
+        for i in range(n_cpu):
+            tic = time.perf_counter()
+            kw = {}
+            if proj is not None:
+                w, rv, proj = prob.dexpilot_preamble(refs[i][None], proj)
+                kw = dict(weights=w, dexpilot_ref=rv)
+            q_ref, _ = cport.solve_ref_as_configured_c(cp, refs[i][None], None, np.clip(last, lo, hi)[None].astype(np.float32), **kw)
+            t_cpu.append(time.perf_counter() - tic)
+            last = q_ref[0].astype(np.float64)
+        t_cpu = np.array(t_cpu)
+        rec["robots"][rel]["cpu_port_same_loop"] = {
+            "frames": n_cpu, "fps": n_cpu / t_cpu.sum(), "mean_ms": float(t_cpu.mean() * 1e3),
+            "p99_ms": float(np.percentile(t_cpu, 99) * 1e3), "kind": "port", "cores": 1,
+            "note": "the oracle's plain-C closure + scipy's compiled SLSQP at the reference's ftol, its own warm-start chain over "
+                    "the 621 fixture frames (the reference's loop, profile_online_retargeting.py:18-36, with compiled stand-ins "
+                    "for pinocchio / nlopt and no torch overhead)"}
 
 
 OFFLINE_ROBOTS = ["offline/allegro_hand_right.yml", "offline/shadow_hand_right.yml", "offline/leap_hand_right.yml",
