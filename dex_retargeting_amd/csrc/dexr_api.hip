@@ -742,17 +742,6 @@ int create_generic(const dexr_model_header& h, const char* body, size_t nbytes, 
   const double* df = reinterpret_cast<const double*>(d);
   dexr::GenTab& g = m->gen_tab;
   g.nj = nj; g.nf = nf; g.nt = nt; g.nv = nv; g.nfam = nfam; g.max_depth = gh.max_depth; g.has_kp = gh.has_keypoint_map;
-  {
-    // backward substitution of the general kernel: through a transposed copy of the factor in LDS, or -- up to 38 variables
-    // -- in registers, which costs ~10 % more instructions per pass and saves a packed triangle of LDS: taken when that
-    // buys a resident wave (at most 8 per CU: two per SIMD at the kernel's 256 registers)
-    auto per_cu = [&](bool lt) {
-      const size_t b = dexr::gen_lds_doubles(nj, nf, nt, nv, nfam, lt) * sizeof(double);
-      const size_t n = b ? (size_t)(160 * 1024) / b : 8;
-      return n > 8 ? (size_t)8 : n;
-    };
-    g.lt_in_lds = (nv > 38 || per_cu(false) <= per_cu(true)) ? 1 : 0;
-  }
   g.X = df;
   g.axis = g.X + (size_t)nj * 12;
   g.jmul = g.axis + (size_t)nj * 3;

@@ -5,19 +5,25 @@
 // ValueError here; the specialised families (dexr_kernel / dexr_wide / dexr_red) stay the fast path for everything that
 // fits them.
 //
-// Mapping: ONE WAVEFRONT PER FRAME (a block is one wave: barriers are free), float64 throughout, every table read from
-// memory with rolled loops, all per-frame state in LDS:
-//   joint values           lane k = joint k
-//   forward kinematics     level-synchronous over the tree: the joints of depth d (one lane each) compose their parent's
-//                          world transform (LDS) with their placement and motion -- depth, not joint count, steps
-//   frames / terms         lane f = target link f; lane t = residual term t (SmoothL1 value, gradient, curvature)
-//   gradient / Hessian     per term: lane k forms joint k's column a x (p - o), lane v folds its variable's joint family
-//                          (kinematics_adaptor.py:102-113); the lower triangle of H is dealt out ENTRY by entry over the 64
-//                          lanes (entry e = r (r + 1) / 2 + c on lane e mod 64) and accumulated over the terms in registers
-//                          (round 4; round 3 gave lane v row v and read-modify-wrote it in LDS: the longest row set the
-//                          pace); the second-order kinematic term is one sweep over the joints per pass from per-joint
-//                          sums CF_k (round 3: a chain walk per term)
-//   Cholesky / solves      lane = row, columns in sequence
+// Mapping: ONE WAVEFRONT PER FRAME, float64 throughout, rolled loops over tables of any size; the lanes of the wave talk
+// through LDS, which executes one wave's instructions in order -- a write by one lane is seen by every later read of the
+// wave, so the "barriers" below are compiler fences (gen_sync), never a wait:
+//   joint values           lane k = joint k: everything the tables say about joint / variable / link / term k lives in lane
+//                          k's REGISTERS for the whole kernel (placement, axis, box, parent, term masks, targets)
+//   forward kinematics     all joints form their local transform X_k . motion(q_k) at once; then level-synchronous over the
+//                          tree: the joints of depth d (one lane each) compose their parent's world transform (LDS) with it
+//                          -- depth, not joint count, steps of 36 multiply-adds each
+//   frames / terms         lane f = target link f; lane t = residual term t (SmoothL1 value, gradient, curvature), which
+//                          publishes one 16-double record per term (both frame positions, force, unit vector, curvatures)
+//   gradient / Hessian     per term: lane k forms joint k's column a x (p - o) from its own registers + the term's record,
+//                          lane v folds its variable's joint family (kinematics_adaptor.py:102-113); the lower triangle of H
+//                          is tiled over an 8 x 8 LANE GRID -- lane (a, b) owns the entries (a + 8 i, b + 8 j) -- and
+//                          accumulated over the terms in registers: per term a lane reads the <= NI columns of its rows and
+//                          the <= NI of its columns (round 4 first half: entry e on lane e mod 64, six reads per entry and
+//                          term); the second-order kinematic term is added once per pass from per-joint sums CF_k
+//   Cholesky / solves      lane = row in registers; the finished part of the factor is published row-major in LDS, so row c
+//                          is read as wave-uniform pairs where Cholesky-Crout needs it and column `lane` where the backward
+//                          substitution does; that copy overlays the kinematic state, which is dead by then
 // Solver: the projected Levenberg-Marquardt / Newton iteration on F = f + norm_delta |x - last|^2 that
 // oracle/solvers.solve_lm_batched states (exact SmoothL1 curvature, second-order kinematic term, Nielsen damping), plus
 // the trust radius the other kernels use.  What is computed per evaluation follows the reference's closures
@@ -26,35 +32,34 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "dexr_kernel.hpp"
 
 namespace dexr {
 
 struct GenTab {  // device pointers into the uploaded generic table
   int32_t nj, nf, nt, nv, nfam, max_depth, has_kp;
-  int32_t lt_in_lds;  // the backward substitution transposes the factor through a second packed triangle in LDS (see
-                      // gen_factor_solve; chosen at model creation: create_generic in dexr_api.hip)
   const double *X, *axis, *jmul, *joff, *lo, *hi, *frame_off;
   const unsigned long long *frame_anc, *joint_anc;
   const int32_t *jtype, *parent, *depth, *src_idx, *var, *var_api, *fam_off, *fam, *frame_joint, *term_task, *term_origin,
       *term_ref, *row_ho, *row_ht;
 };
 
-// entries of the packed triangles in LDS: the Hessian and -- when the backward substitution transposes the factor through
-// LDS (gen_factor_solve) -- the transposed factor
-__host__ __device__ inline size_t gen_tri_doubles(int nv, bool lt_in_lds) {
+// LDS of one wave, in doubles.  [scratch | live | tables]: "scratch" is everything an evaluation / model assembly
+// produces and the factorisation no longer needs -- world transforms, frame positions, term records, column buffers --
+// and the row-major copy of the Cholesky factor (gen_factor_solve) lies over it.
+__host__ __device__ inline size_t gen_scratch_doubles(int nj, int nf, int nt, int nv) {
+  const size_t kin = (size_t)nj * 12 /* Tw */ + (size_t)nv * 8 /* colA | colB */ + (size_t)nt * 16 /* rec */ +
+                     (size_t)nf * 3 /* P */ + (size_t)nj * 3 /* jcol */ + (size_t)nj /* tmp */;
   const size_t ntri = (size_t)nv * (nv + 1) / 2;
-  return lt_in_lds ? 2 * ntri : ntri;
+  return ((kin > ntri ? kin : ntri) + 1) & ~(size_t)1;
 }
-
-// doubles of LDS one wave needs
-__host__ __device__ inline size_t gen_lds_doubles(int nj, int nf, int nt, int nv, int nfam, bool lt_in_lds) {
-  const size_t state = (size_t)nj * 12 + nj * 3 + nj + (size_t)nf * 3 + (size_t)nt * 3 + nt + (size_t)nt * 3 + nt + (size_t)nt * 3 +
-                       (size_t)nt * 3 + (size_t)nv * 6 + gen_tri_doubles(nv, lt_in_lds) + (size_t)nj * 3 + (size_t)nv * 3 + nj + 8;
-  // wave-local copies of the tables the inner loops index (see "tables" in the kernel)
-  const size_t ints = 3 * (size_t)nj + (size_t)nv + 1 + (size_t)nfam + (size_t)nf + 2 * (size_t)nt +
-                      ((size_t)nv * (nv + 1) / 2 + 1) / 2 /* (row, column) of every entry of the packed triangle, 2 x uint8 */;
-  return state + (size_t)nj /* jmul */ + (size_t)nf + (size_t)nj /* masks */ + (ints + 1) / 2;
+__host__ __device__ inline size_t gen_lds_doubles(int nj, int nf, int nt, int nv, int nfam) {
+  const size_t live = (size_t)nv * 5 /* x xt g s act */ + (size_t)nv * (nv + 1) / 2 /* H */;
+  // wave-local copies of the tables the loops index with data-dependent subscripts (see "tables" in the kernel)
+  const size_t ints = 3 * (size_t)nj + (size_t)nv + 1 + (size_t)nfam + (size_t)nf + 2 * (size_t)nt;
+  return gen_scratch_doubles(nj, nf, nt, nv) + live + (size_t)nj /* jmul */ + (size_t)nf + (size_t)nj /* masks */ + (ints + 1) / 2;
 }
 
 #define GEN_TRI(r, c) ((size_t)(r) * ((r) + 1) / 2 + (c))
@@ -73,167 +78,211 @@ __host__ __device__ inline size_t gen_lds_doubles(int nj, int nf, int nt, int nv
 #define GPROF_COUNT(i)
 #define GPROF_FLUSH()
 #endif
-// entries of the packed triangle per lane (accumulated in registers): 12 serves up to 38 variables (741 entries), 33 up to 64
-constexpr int GEN_SLOTS_SMALL = 12, GEN_SLOTS_BIG = 33;
+// The 8 x 8 lane grid holds NI x NI tiles: NI = 5 serves up to 40 variables (15 entries of the lower triangle per lane, the
+// factorisation's 40 rows in registers, two waves per SIMD), NI = 8 up to 64 (36 entries, one wave per SIMD)
+constexpr int GEN_NI_SMALL = 5, GEN_NI_BIG = 8;
 
-__device__ __forceinline__ double gen_wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+typedef double gen_d2 __attribute__((ext_vector_type(2)));
+
+// Lanes of the wave exchange data through LDS.  A block IS one wave and the LDS executes a wave's instructions in order,
+// so a read issued after a write sees it: all that is needed is that the compiler keeps the order (the same idiom as the
+// sixteen-lane kernel's, dexr_wide.hpp).  __syncthreads() would add a wait for the writes to drain before the first read
+// is even issued -- measured on the first version of this kernel: 19 kinematic levels + ~25 term barriers per pass.
+__device__ __forceinline__ void gen_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ double gen_wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
+
+template <int CTRL> __device__ __forceinline__ double gen_dpp(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
 }
-
-
-// a double of lane `src` (a compile-time constant at every call site below) as a wave-uniform value: two v_readlane_b32
+// a double of lane `src` as a wave-uniform value: two v_readlane_b32
 __device__ __forceinline__ double gen_readlane(double v, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
   return __hiloint2double(hi, lo);
 }
+// sum / maximum over the wave, in every lane: four DPP steps inside the rows of 16 lanes, the four row results through
+// scalar registers (the first version went through ds_bpermute: six dependent LDS round trips per reduction, five
+// reductions per pass)
+__device__ __forceinline__ double gen_wave_sum(double v) {
+  v += gen_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += gen_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += gen_dpp<0x141>(v);  // row_half_mirror
+  v += gen_dpp<0x140>(v);  // row_mirror
+  return (gen_readlane(v, 0) + gen_readlane(v, 16)) + (gen_readlane(v, 32) + gen_readlane(v, 48));
+}
+__device__ __forceinline__ double gen_wave_max(double v) {
+  v = fmax(v, gen_dpp<0xB1>(v));
+  v = fmax(v, gen_dpp<0x4E>(v));
+  v = fmax(v, gen_dpp<0x141>(v));
+  v = fmax(v, gen_dpp<0x140>(v));
+  return fmax(fmax(gen_readlane(v, 0), gen_readlane(v, 16)), fmax(gen_readlane(v, 32), gen_readlane(v, 48)));
+}
 
-// Solve (H restricted to the free set + lam I) d = -g for the step d, IN REGISTERS: lane r holds row r of the lower
-// triangle (NV doubles, statically indexed in fully unrolled loops), the factor is formed column by column
-// (Cholesky-Crout): entry (r, c) = (A[r][c] - sum_{k<c} L[r][k] L[c][k]) / L[c][c] with row c's entries read from lane c
-// (v_readlane with a constant lane: scalar operands, no LDS, no barrier).  Forward substitution column-wise (y_k broadcast
-// from lane k); the backward substitution needs columns: see its two variants below.  Round 3 kept the matrix in LDS, lane = row, one block barrier + a
-// read-modify-write sweep per column: 113 k of the 303 k cycles of a 37-variable pass, 26 k more for the solves.
-// Not inlined: inside the kernel the register allocator carried ~400 live registers through the unrolled columns (92 on
-// its own); as a call it costs 22 spilled registers at the call site.
+// LDS by ADDRESS.  The factorisation below is a real call (not inlined, see there).  Handed generic pointers it reads the
+// Hessian with flat loads, and since the only call site passes the kernel's dynamic LDS the compiler specialised the
+// pointers into a per-kernel lookup of that block's offset (llvm.amdgcn.dynlds.offset.table): one scalar load + wait in
+// every column.  So the function takes 32-bit LDS addresses (made opaque at the call site) and reads / writes through
+// address-space-3 pointers: plain ds_read / ds_write with immediate offsets.
+typedef __attribute__((address_space(3))) double gen_lds_f64;
+typedef __attribute__((address_space(3))) gen_d2 gen_lds_d2;
+__device__ __forceinline__ unsigned gen_lds_addr(const double* p) {
+  unsigned a = (unsigned)(uintptr_t)(const gen_lds_f64*)p;
+  asm volatile("" : "+s"(a));
+  return a;
+}
+
+// Solve (H restricted to the free set + lam I) d = -g for the step d.  Lane r holds row r of the lower triangle in
+// REGISTERS (NV doubles, statically indexed in fully unrolled loops); the factor is formed column by column
+// (Cholesky-Crout): entry (r, c) = (A[r][c] - sum_{k<c} L[r][k] L[c][k]) / L[c][c].  Every finished entry is also written to
+// `Lt`, a row-major packed copy of the factor in LDS, so that
+//   * row c's entries L[c][k] are read as wave-uniform, contiguous pairs (one ds_read_b128 per two entries; round 4's first
+//     version fetched each from lane c with two v_readlane: 3 instructions per multiply-add instead of 1.5) -- the last
+//     two entries of the row, written one and two columns ago, still come from lane c, which keeps the LDS write -> read
+//     latency off the column-to-column chain;
+//   * the backward substitution L^T s = y reads COLUMN `lane` of the factor with one ds_read_b64 per entry (the register
+//     variant it replaces carried y as wave-uniform values in every lane and fetched row k from lane k: as many
+//     instructions again as the factorisation).
+// `Lt` costs no LDS: it overlays the kinematic state of the last evaluation, which nothing reads any more once the model
+// has been assembled (gen_scratch_doubles).  The register rows hold the STRICT lower triangle (zeros on and above the
+// diagonal, 1 / L[r][r] apart): a substitution step is then the same three instructions in every lane -- broadcast of
+// lane k's value, one multiply-add with L[k], no lane == k / lane > k cases -- and the answer is read off at the end.
+// Not inlined: inside the kernel the register allocator carried ~400 live registers through the unrolled columns.
 // Returns false when a pivot is not positive (the damped model is indefinite: the caller raises lambda).
 template <int NV>
-__device__ __noinline__ bool gen_factor_solve(int lane, int nv, const double* H, const double* g, const double* act, double lam,
-                                              double* Lt, double* s_out) {
+__device__ __noinline__ bool gen_factor_solve(int lane, int nv, unsigned aH, unsigned ag, unsigned aact, double lam, unsigned aLt,
+                                              unsigned as_out) {
+  const gen_lds_f64* H = reinterpret_cast<const gen_lds_f64*>((uintptr_t)aH);
+  const gen_lds_f64* g = reinterpret_cast<const gen_lds_f64*>((uintptr_t)ag);
+  const gen_lds_f64* act = reinterpret_cast<const gen_lds_f64*>((uintptr_t)aact);
+  gen_lds_f64* Lt = reinterpret_cast<gen_lds_f64*>((uintptr_t)aLt);
+  gen_lds_f64* s_out = reinterpret_cast<gen_lds_f64*>((uintptr_t)as_out);
+  nv = __builtin_amdgcn_readfirstlane(nv);  // (arguments arrive in vector registers: say that this one is wave-uniform)
   const bool rowv = lane < nv;
-  const bool a_r = rowv ? act[lane] != 0.0 : true;
+  const unsigned long long held = __ballot(rowv && act[rowv ? lane : 0] != 0.0);  // bit v: variable v sits at a bound
+  const bool a_r = !rowv || ((held >> lane) & 1ull);
   const int base = lane * (lane + 1) / 2;
+  const gen_lds_f64* Hr = H + base;
   double L[NV];
+  const double my_diag = a_r ? 1.0 : Hr[lane] + lam;
 #pragma unroll
   for (int c = 0; c < NV; ++c) {
     double v = 0.0;
-    if (c < nv && rowv && c <= lane) {
-      const bool au = a_r || act[c] != 0.0;
-      v = au ? (c == lane ? 1.0 : 0.0) : H[base + c] + (c == lane ? lam : 0.0);
+    if (8 * (c / 8) < nv) {  // wave-uniform, per group of eight columns
+      const bool keep = c < lane && !a_r && !((held >> c) & 1ull);  // (rows / columns of held variables: identity)
+      const double h = Hr[c];  // (beyond the lane's row for c > lane: read and dropped)
+      v = keep ? h : 0.0;
+      v = c == lane ? my_diag : v;
     }
     L[c] = v;
   }
   double rhs = (rowv && !a_r) ? -g[lane] : 0.0;
   double invd = 0.0;  // 1 / L[lane][lane]
   bool ok = true;
+  gen_lds_f64* my_row = Lt + base;
 #pragma unroll
   for (int c = 0; c < NV; ++c) {
     if (c < nv && ok) {  // wave-uniform
       double acc = L[c];
+      // row c of the factor so far: entries [0, nl) from the LDS copy (wave-uniform, contiguous: pairs where the address is
+      // 16-byte aligned), the last two -- written one and two columns ago -- from lane c's registers
+      constexpr int NEAR = 2;
+      const int nl = c > NEAR ? c - NEAR : 0;  // (c is the unrolled loop's constant: all of this folds)
+      const int rs = c * (c + 1) / 2;
+      const gen_lds_f64* row_c = Lt + rs;
+      int k = 0;
+      if ((rs & 1) && nl > 0) {
+        acc = fma(-L[0], row_c[0], acc);
+        k = 1;
+      }
 #pragma unroll
-      for (int k = 0; k < c; ++k) acc = fma(-L[k], gen_readlane(L[k], c), acc);  // L[k] of lane c = L[c][k]
+      for (; k + 1 < nl; k += 2) {
+        const gen_d2 p = *reinterpret_cast<const gen_lds_d2*>(row_c + k);
+        acc = fma(-L[k], p.x, acc);
+        acc = fma(-L[k + 1], p.y, acc);
+      }
+      if (k < nl) acc = fma(-L[k], row_c[k], acc);
+#pragma unroll
+      for (int k2 = nl; k2 < c; ++k2) acc = fma(-L[k2], gen_readlane(L[k2], c), acc);  // L[k2] of lane c = L[c][k2]
       const double d = gen_readlane(acc, c);
       if (!(d > 0.0)) {
         ok = false;
       } else {
         // 1 / sqrt(d): hardware estimate + two Newton steps (full double precision for the well-scaled pivots of a damped
-        // Hessian; a correctly rounded sqrt and a division cost three times the instructions, 38 times per solve)
+        // Hessian; a correctly rounded sqrt and a division cost three times the instructions, once per column)
         double ip = __builtin_amdgcn_rsq(d);
         ip = ip * fma(-0.5 * d * ip, ip, 1.5);
         ip = ip * fma(-0.5 * d * ip, ip, 1.5);
-        L[c] = lane == c ? d * ip : (lane > c ? acc * ip : 0.0);
-        if (lane == c) invd = ip;
+        const double lv = acc * ip;
+        if (rowv && lane >= c) my_row[c] = lv;  // (lane c's own entry is sqrt(d): the diagonal, which nothing reads)
+        L[c] = lane > c ? lv : 0.0;
+        invd = lane == c ? ip : invd;
+        gen_sync();
       }
     }
   }
   if (!ok) return false;
-  // L y = rhs: y_k is final on lane k once the columns before k have been subtracted
-  double y = 0.0;
+  // L y = rhs, column-wise: once the columns before k have been subtracted, lane k's value is final and is broadcast
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    if (k < nv) {
+    if (8 * (k / 8) < nv) {
       const double yk = gen_readlane(rhs * invd, k);
-      if (lane == k) y = yk;
-      if (lane > k) rhs = fma(-L[k], yk, rhs);
+      rhs = fma(-L[k], yk, rhs);  // (rows <= k hold 0 there)
     }
   }
-  // L^T s = y needs the COLUMNS of the factor, which no lane holds
-  double sv = 0.0;
-  bool in_regs = false;
-  if constexpr (NV <= 38) in_regs = Lt == nullptr;  // wave-uniform
-  if (in_regs) {
-    // (38-variable instantiation, chosen per model when it buys a resident wave: an arm + hand's wave needs 20 KB of LDS
-    // instead of 26 KB without the transposed copy -- 8 instead of 6 waves per CU, 29 -> 26 ms per 65 536 frames -- while
-    // small models, whose LDS was not the limit, lose 10 % to the extra instructions.)  Every lane carries the whole
-    // vector y as wave-uniform values (yv[k] = y_k read from lane k) and runs the substitution redundantly:
-    // s_k = yv[k] / L[k][k], then yv[j] -= L[k][j] s_k with row k's entries read from lane k -- 2 v_readlane + 1 FMA per
-    // entry like the factorisation, no LDS
-    constexpr int NY = NV <= 38 ? NV : 1;
-    double yv[NY];
+  double y = rhs * invd;
+  // L^T s = y the same way: lane c now holds column c (entries L[k][c], k > c), read from the row-major copy
 #pragma unroll
-    for (int k = 0; k < NY; ++k) yv[k] = k < nv ? gen_readlane(y, k) : 0.0;
-#pragma unroll
-    for (int k = NY - 1; k >= 0; --k) {
-      if (k < nv) {
-        const double sk = yv[k] * gen_readlane(invd, k);
-        if (lane == k) sv = sk;
-#pragma unroll
-        for (int j = 0; j < k; ++j) yv[j] = fma(-gen_readlane(L[j], k), sk, yv[j]);
-      }
+  for (int k = 0; k < NV; ++k) {
+    double v = 0.0;
+    if (8 * (k / 8) < nv) {
+      const double h = Lt[k * (k + 1) / 2 + lane];
+      v = (k > lane && k < nv) ? h : 0.0;
     }
-  } else {
-    // the factor is transposed once through LDS (`Lt`, a second packed triangle), lane c then holds column c (entries
-    // L[k][c], k >= c) and the substitution is column-wise like the forward one
-    if (rowv) {
+    L[k] = v;
+  }
 #pragma unroll
-      for (int c = 0; c < NV; ++c)
-        if (c < nv && c <= lane) Lt[base + c] = L[c];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NV; ++k) L[k] = (k < nv && rowv && k >= lane) ? Lt[k * (k + 1) / 2 + lane] : 0.0;  // column `lane`
-#pragma unroll
-    for (int k = NV - 1; k >= 0; --k) {
-      if (k < nv) {
-        const double sk = gen_readlane(y * invd, k);
-        if (lane == k) sv = sk;
-        if (lane < k) y = fma(-L[k], sk, y);
-      }
+  for (int k = NV - 1; k >= 0; --k) {
+    if (8 * (k / 8) < nv) {
+      const double sk = gen_readlane(y * invd, k);
+      y = fma(-L[k], sk, y);
     }
   }
-  if (rowv) s_out[lane] = sv;
+  gen_sync();
+  if (rowv) s_out[lane] = y * invd;
   return true;
 }
 
-template <int MODE, int NSLOT>
-__global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen_kernel(KernelParams kp, GenTab tb) {
-  extern __shared__ double gen_lds[];
+template <int MODE, int NI>
+__global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kernel(KernelParams kp, GenTab tb) {
+  extern __shared__ __align__(16) double gen_lds[];
+  constexpr int NSLOT = NI * (NI + 1) / 2;  // entries of the lower triangle a lane of the grid owns: tiles (i, j), j <= i
+  constexpr int NV = NI * 8;                // rows the register factorisation holds
   const int lane = threadIdx.x;
   const int nj = tb.nj, nf = tb.nf, nt = tb.nt, nv = tb.nv;
-  double* Tw = gen_lds;            // nj x 12: world transform of every joint frame AFTER its motion (R row-major | p)
-  double* aw = Tw + nj * 12;       // nj x 3: world axis
-  double* qj = aw + nj * 3;        // nj
-  double* P = qj + nj;             // nf x 3
-  double* tgt = P + nf * 3;        // nt x 3
-  double* wt = tgt + nt * 3;       // nt
-  double* tg = wt + nt;            // nt x 3: dF/d(vector or position) of term t
-  double* tc1 = tg + nt * 3;       // nt
-  double* tc2 = tc1 + nt;          // nt x 3
-  double* tu = tc2 + nt * 3;       // nt x 3
-  double* x = tu + nt * 3;         // nv each:
-  double* xl = x + nv;
-  double* xt = xl + nv;
+  // ---- scratch (dead once the model of a point has been assembled; the factor's copy lies over it) ------------------------
+  double* Tw = gen_lds;             // nj x 12: world transform of every joint frame AFTER its motion (R row-major | p)
+  double* colA = Tw + nj * 12;      // nv x 4: a term's column per variable | u . column   (16-byte aligned records)
+  double* colB = colA + nv * 4;     // nv x 4: the second term of a pair
+  double* rec = colB + nv * 4;      // nt x 16: per term  task pos (3) | origin pos (3) | force (3) | unit vector (3) | curvature (3 + 1)
+  double* P = rec + nt * 16;        // nf x 3
+  double* jcol = P + nf * 3;        // nj x 3
+  double* tmp = jcol + nj * 3;      // nj
+  double* Lt = gen_lds;             // row-major packed Cholesky factor (gen_factor_solve)
+  // ---- live --------------------------------------------------------------------------------------------------------------
+  double* x = gen_lds + gen_scratch_doubles(nj, nf, nt, nv);  // nv each:
+  double* xt = x + nv;
   double* g = xt + nv;
   double* s = g + nv;
   double* act = s + nv;
   const int ntri = nv * (nv + 1) / 2;
   double* H = act + nv;            // lower triangle, packed by rows: entry (r, c), c <= r, at r (r + 1) / 2 + c
-  double* Lt = H + ntri;           // (tb.lt_in_lds only: the transposed factor, see gen_factor_solve)
-  double* jcol = H + gen_tri_doubles(nv, tb.lt_in_lds != 0);  // nj x 3
-  double* vcol = jcol + nj * 3;         // nv x 3
-  double* tmp = vcol + nv * 3;          // nj
-  double* flag = tmp + nj;              // 8 scalars
-  // tables the inner loops index with data-dependent subscripts (families of a variable, parents along a chain,
-  // ancestor masks): read from global memory they cost two dependent ~1 us round trips per access -- the first version of
-  // this kernel spent ~90 % of a pass waiting for them -- so every wave keeps its own copy in LDS
-  double* l_jmul = flag + 8;                                                      // nj
+  // tables the loops index with data-dependent subscripts (families of a variable, ancestor masks): read from global memory
+  // they cost two dependent ~1 us round trips per access, so every wave keeps its own copy in LDS
+  double* l_jmul = H + ntri;                                                        // nj
   unsigned long long* l_fanc = reinterpret_cast<unsigned long long*>(l_jmul + nj);  // nf
   unsigned long long* l_janc = l_fanc + nf;                                       // nj
   int32_t* l_jtype = reinterpret_cast<int32_t*>(l_janc + nj);                     // nj
@@ -244,7 +293,6 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
   int32_t* l_fjoint = l_fam + tb.nfam;                                            // nf
   int32_t* l_ttask = l_fjoint + nf;                                               // nt
   int32_t* l_torigin = l_ttask + nt;                                              // nt
-  uint16_t* l_rc = reinterpret_cast<uint16_t*>(l_torigin + nt);                   // ntri: row | column << 8 of entry e
   for (int i = lane; i < nj; i += 64) {
     l_jmul[i] = tb.jmul[i];
     l_janc[i] = tb.joint_anc[i];
@@ -262,20 +310,17 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
     l_ttask[i] = tb.term_task[i];
     l_torigin[i] = tb.term_origin[i];
   }
-  for (int e = lane; e < nv * (nv + 1) / 2; e += 64) {  // entry e of the packed triangle: row r, column c
-    int r = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
-    while ((r + 1) * (r + 2) / 2 <= e) ++r;  // (guards the rounding of the square root)
-    while (r * (r + 1) / 2 > e) --r;
-    l_rc[e] = (uint16_t)(r | ((e - r * (r + 1) / 2) << 8));
-  }
   __syncthreads();
 
-  // Lane k IS joint k (and variable k, frame k) for the whole kernel: what the tables say about them is read ONCE, into
-  // registers.  (Round 3 re-read depth / placement / axis / offsets from global memory in every level of every forward
-  // kinematics -- two dependent ~1 us round trips per level, 19 levels for an arm + hand, twice per pass: most of a pass.)
-  const bool is_j = lane < nj, is_v = lane < nv, is_f = lane < nf;
+  // Lane k IS joint k (and variable k, link k, term k) for the whole kernel: what the tables say about them is read ONCE,
+  // into registers.
+  const bool is_j = lane < nj, is_v = lane < nv, is_f = lane < nf, is_t = lane < nt;
   const int my_depth = is_j ? tb.depth[lane] : -1;
   const int my_src = is_j ? tb.src_idx[lane] : 0;
+  const int my_var = is_j ? l_var[lane] : -1;
+  const int my_parent = is_j ? l_parent[lane] : -1;
+  const bool my_rev = is_j && l_jtype[lane] == DEXR_JOINT_REVOLUTE;
+  const double my_jmul = is_j ? l_jmul[lane] : 0.0;
   double myX[12], my_ax[3], my_fo[3];
 #pragma unroll
   for (int i = 0; i < 12; ++i) myX[i] = is_j ? tb.X[(size_t)lane * 12 + i] : 0.0;
@@ -284,11 +329,48 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
     my_ax[i] = is_j ? tb.axis[lane * 3 + i] : 0.0;
     my_fo[i] = is_f ? tb.frame_off[(size_t)lane * 3 + i] : 0.0;
   }
+  const int my_fjoint = is_f ? l_fjoint[lane] : -1;
   const double my_joff = is_j ? tb.joff[lane] : 0.0;
   const double my_lo = is_v ? tb.lo[lane] : 0.0, my_hi = is_v ? tb.hi[lane] : 0.0;
   const int my_api = is_v ? tb.var_api[lane] : 0;
-
+  const int my_ft = is_t ? l_ttask[lane] : 0, my_fo_t = is_t ? l_torigin[lane] : -1;  // lane t: frames of term t
+  // terms whose task / origin chain joint `lane` lies on (bit t): the column of joint k for term t needs nothing else
+  unsigned long long on_task = 0ull, on_origin = 0ull;
+  for (int t = 0; t < nt; ++t) {
+    const int ft = l_ttask[t], fo = l_torigin[t];
+    if (is_j && ((l_fanc[ft] >> lane) & 1ull)) on_task |= 1ull << t;
+    if (is_j && fo >= 0 && ((l_fanc[fo] >> lane) & 1ull)) on_origin |= 1ull << t;
+  }
+  const bool any_prismatic = __any(is_j && !my_rev);  // wave-uniform
   const bool no_mimic = tb.nfam == nv;  // every variable drives exactly one joint (families partition the driven joints)
+
+  // The lane's tiles of the lower triangle: lane (a, b) of the 8 x 8 grid owns entry (a + 8 i, b + 8 j) for j <= i (on the
+  // diagonal tiles only where b <= a); slot i (i + 1) / 2 + j.
+  const int ga = lane >> 3, gb = lane & 7;
+  int row_ld[NI], col_ld[NI];  // rows / columns to LOAD (clamped into the matrix: an out-of-range tile computes garbage it never stores)
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    row_ld[i] = min(ga + 8 * i, nv - 1);
+    col_ld[i] = min(gb + 8 * i, nv - 1);
+  }
+  unsigned long long slot_ok = 0ull, so_rc = 0ull, so_cr = 0ull;  // per slot: entry exists | second-order contributions (mimic-free models)
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      const int r = ga + 8 * i, c = gb + 8 * j, sl = i * (i + 1) / 2 + j;
+      if (r < nv && c <= r) {
+        slot_ok |= 1ull << sl;
+        if (no_mimic) {
+          const int jr = l_fam[l_famoff[r]], jc = l_fam[l_famoff[c]];
+          // joint of r moved, joint of c its revolute ancestor-or-self; and the other way round
+          if (((l_janc[jr] >> jc) & 1ull) && l_jtype[jc] == DEXR_JOINT_REVOLUTE) so_rc |= 1ull << sl;
+          if (jr != jc && ((l_janc[jc] >> jr) & 1ull) && l_jtype[jr] == DEXR_JOINT_REVOLUTE) so_cr |= 1ull << sl;
+        }
+      }
+    }
+  }
+
   GPROF_DECL
   const int64_t cnt = kp.bucket ? (int64_t)kp.bucket[1] : kp.B;
   const int64_t boff = kp.bucket ? (int64_t)kp.bucket[0] : 0;
@@ -296,11 +378,14 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
   const bool seq = kp.T > 0;
   const int n_frames = seq ? kp.T : 1;
   const bool dexpilot = kp.kind == DEXR_KIND_DEXPILOT;
+  const bool pos = kp.kind == DEXR_KIND_POSITION;
   const double beta = (double)kp.huber_delta, delta = (double)kp.norm_delta, inv_norm = (double)kp.inv_norm;
+  double my_o[3] = {0, 0, 0}, my_a[3] = {0, 0, 0};  // lane k: origin and world axis of joint k at the last evaluated point
 
   for (int64_t item = blockIdx.x; item < cnt; item += gridDim.x) {
     const int64_t r0 = kp.perm ? (int64_t)kp.perm[boff + item] : item;
     uint32_t st_carry = 0u;
+    double my_xl = 0.0;  // lane v: regularisation target of variable v
     for (int t_seq = 0; t_seq < n_frames; ++t_seq) {
       const int64_t it = seq ? (int64_t)t_seq * kp.seq_stride + r0 : r0;  // row of this frame's inputs / outputs
       const bool carry = seq && t_seq > 0;
@@ -329,9 +414,17 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
           v = l;
         }
         x[lane] = v;
-        xl[lane] = l;
+        my_xl = l;
+      }
+      // joints that follow a caller-fixed value: constant over the frame's passes
+      double my_qfix = 0.0;
+      if (MODE == MODE_FK) {
+        if (is_j) my_qfix = kp.xin[it * kp.n_q + my_src];
+      } else if (is_j && my_var < 0) {
+        my_qfix = my_jmul * (double)kp.fixed[it * kp.ldf + my_src] + my_joff;
       }
       uint32_t nst = 0;
+      double my_tgt[3] = {0, 0, 0}, my_wt = 1.0;  // lane t: target and weight of term t
       if (MODE != MODE_FK) {
         if (dexpilot) {  // optimizer.py:462-508 (every lane redundantly: wave-uniform)
           const int F = kp.num_fingers;
@@ -356,7 +449,7 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
               nst |= (b ? 1u : 0u) << idx;
               ++idx;
             }
-          if (lane < nt) {
+          if (is_t) {
             const int row = tb.term_ref[lane];
             float rv[3], tv[3], w;
             ref_row(row, rv);
@@ -374,291 +467,341 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
               for (int i = 0; i < 3; ++i) tv[i] = rv[i] * kp.scaling;
               w = (float)(n_pair + F);
             }
-            for (int i = 0; i < 3; ++i) tgt[lane * 3 + i] = (double)tv[i];
-            wt[lane] = (double)w;
+            for (int i = 0; i < 3; ++i) my_tgt[i] = (double)tv[i];
+            my_wt = (double)w;
           }
-        } else if (lane < nt) {
+        } else if (is_t) {
           const float sc = (kp.kind == DEXR_KIND_VECTOR) ? kp.scaling : 1.f;
           float rv[3];
           ref_row(tb.term_ref[lane], rv);
-          for (int i = 0; i < 3; ++i) tgt[lane * 3 + i] = (double)(rv[i] * sc);  // f32 multiply: optimizer.py:246
-          wt[lane] = 1.0;
+          for (int i = 0; i < 3; ++i) my_tgt[i] = (double)(rv[i] * sc);  // f32 multiply: optimizer.py:246
         }
       }
-      __syncthreads();
+      gen_sync();
 
       // ---- one evaluation at xs: kinematics, terms, value (eval_value); gradient + Hessian of the data term at the point
-      // whose kinematic state is in LDS (assemble_model) ------------------------------------------------------------------
+      // whose kinematic state is in LDS / the lanes' registers (assemble_model) ----------------------------------------------
       auto eval_value = [&](const double* xs) -> double {
         GPROF_START();
-        if (lane < nj) {
-          const int v = l_var[lane];
-          double q;
-          if (MODE == MODE_FK) q = kp.xin[it * kp.n_q + my_src];
-          else if (v >= 0) q = l_jmul[lane] * xs[v] + my_joff;
-          else q = l_jmul[lane] * (double)kp.fixed[it * kp.ldf + my_src] + my_joff;
-          qj[lane] = q;
+        // every joint's local transform X_k . motion(q_k) at once (sines / cosines of all joints in one go, not one level at
+        // a time): rotation about / translation along the joint's own axis
+        double Lc[12];
+        {
+          double q = my_qfix;
+          if (MODE != MODE_FK && my_var >= 0) q = my_jmul * xs[my_var] + my_joff;
+          const double ax = my_ax[0], ay = my_ax[1], az = my_ax[2];
+          double sn, cs;
+          sincos_f64(my_rev ? q : 0.0, &sn, &cs);  // (dexr_math.hpp: no slow path, unlike ocml's)
+          const double c1 = 1.0 - cs;
+          // Rodrigues about the local axis: I + sin K + (1 - cos) K^2 (the identity for a translation joint)
+          const double M[9] = {1 - c1 * (ay * ay + az * az), -sn * az + c1 * ax * ay, sn * ay + c1 * ax * az,
+                               sn * az + c1 * ax * ay, 1 - c1 * (ax * ax + az * az), -sn * ax + c1 * ay * az,
+                               -sn * ay + c1 * ax * az, sn * ax + c1 * ay * az, 1 - c1 * (ax * ax + ay * ay)};
+          const double tq = my_rev ? 0.0 : q;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Lc[3 * i + j] = myX[3 * i] * M[j] + myX[3 * i + 1] * M[3 + j] + myX[3 * i + 2] * M[6 + j];
+            Lc[9 + i] = myX[9 + i] + tq * (myX[3 * i] * ax + myX[3 * i + 1] * ay + myX[3 * i + 2] * az);
+          }
         }
-        __syncthreads();
+        double Tk[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) Tk[i] = Lc[i];  // (a root joint's world transform is its local one)
         for (int d = 0; d <= tb.max_depth; ++d) {
           if (my_depth == d) {
-            const int k = lane, pa = l_parent[k];
-            double Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pp[3] = {0, 0, 0};
-            if (pa >= 0) {
-              for (int i = 0; i < 9; ++i) Rp[i] = Tw[pa * 12 + i];
-              for (int i = 0; i < 3; ++i) pp[i] = Tw[pa * 12 + 9 + i];
+            if (my_parent >= 0) {
+              const gen_d2* Tp = reinterpret_cast<const gen_d2*>(Tw + my_parent * 12);
+              const gen_d2 p0 = Tp[0], p1 = Tp[1], p2 = Tp[2], p3 = Tp[3], p4 = Tp[4], p5 = Tp[5];
+              const double Rp[9] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, p3.x, p3.y, p4.x};
+              const double pp[3] = {p4.y, p5.x, p5.y};
+#pragma unroll
+              for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) Tk[3 * i + j] = Rp[3 * i] * Lc[j] + Rp[3 * i + 1] * Lc[3 + j] + Rp[3 * i + 2] * Lc[6 + j];
+                Tk[9 + i] = Rp[3 * i] * Lc[9] + Rp[3 * i + 1] * Lc[10] + Rp[3 * i + 2] * Lc[11] + pp[i];
+              }
             }
-            const double* Xk = myX;
-            double Ra[9], pa3[3];
-            for (int i = 0; i < 3; ++i) {
-              for (int j = 0; j < 3; ++j) Ra[3 * i + j] = Rp[3 * i] * Xk[j] + Rp[3 * i + 1] * Xk[3 + j] + Rp[3 * i + 2] * Xk[6 + j];
-              pa3[i] = Rp[3 * i] * Xk[9] + Rp[3 * i + 1] * Xk[10] + Rp[3 * i + 2] * Xk[11] + pp[i];
-            }
-            const double ax = my_ax[0], ay = my_ax[1], az = my_ax[2];
-            const double a0 = Ra[0] * ax + Ra[1] * ay + Ra[2] * az, a1 = Ra[3] * ax + Ra[4] * ay + Ra[5] * az,
-                         a2 = Ra[6] * ax + Ra[7] * ay + Ra[8] * az;
-            aw[k * 3] = a0; aw[k * 3 + 1] = a1; aw[k * 3 + 2] = a2;
-            const double q = qj[k];
-            if (l_jtype[k] == DEXR_JOINT_REVOLUTE) {  // Rodrigues about the local axis: I + sin K + (1 - cos) K^2
-              double sn, cs;
-              sincos_f64(q, &sn, &cs);  // (dexr_math.hpp: no slow path, unlike ocml's)
-              const double c1 = 1.0 - cs;
-              const double M[9] = {1 - c1 * (ay * ay + az * az), -sn * az + c1 * ax * ay, sn * ay + c1 * ax * az,
-                                   sn * az + c1 * ax * ay, 1 - c1 * (ax * ax + az * az), -sn * ax + c1 * ay * az,
-                                   -sn * ay + c1 * ax * az, sn * ax + c1 * ay * az, 1 - c1 * (ax * ax + ay * ay)};
-              for (int i = 0; i < 3; ++i)
-                for (int j = 0; j < 3; ++j)
-                  Tw[k * 12 + 3 * i + j] = Ra[3 * i] * M[j] + Ra[3 * i + 1] * M[3 + j] + Ra[3 * i + 2] * M[6 + j];
-              for (int i = 0; i < 3; ++i) Tw[k * 12 + 9 + i] = pa3[i];
-            } else {
-              for (int i = 0; i < 9; ++i) Tw[k * 12 + i] = Ra[i];
-              Tw[k * 12 + 9] = pa3[0] + a0 * q;
-              Tw[k * 12 + 10] = pa3[1] + a1 * q;
-              Tw[k * 12 + 11] = pa3[2] + a2 * q;
-            }
+            gen_d2* To = reinterpret_cast<gen_d2*>(Tw + lane * 12);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) To[i] = gen_d2{Tk[2 * i], Tk[2 * i + 1]};
           }
-          __syncthreads();
+          gen_sync();
         }
-        if (lane < nf) {
-          const int j = l_fjoint[lane];
-          const double* o = my_fo;
-          if (j < 0) {
-            for (int i = 0; i < 3; ++i) P[lane * 3 + i] = o[i];
+        // world axis (R . M leaves the axis where R put it) and origin of the joint frame: the lane's own registers
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          my_a[i] = Tk[3 * i] * my_ax[0] + Tk[3 * i + 1] * my_ax[1] + Tk[3 * i + 2] * my_ax[2];
+          my_o[i] = Tk[9 + i];
+        }
+        if (is_f) {
+          if (my_fjoint < 0) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) P[lane * 3 + i] = my_fo[i];
           } else {
-            const double* T = Tw + j * 12;
-            for (int i = 0; i < 3; ++i) P[lane * 3 + i] = T[3 * i] * o[0] + T[3 * i + 1] * o[1] + T[3 * i + 2] * o[2] + T[9 + i];
+            const double* T = Tw + my_fjoint * 12;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) P[lane * 3 + i] = T[3 * i] * my_fo[0] + T[3 * i + 1] * my_fo[1] + T[3 * i + 2] * my_fo[2] + T[9 + i];
           }
         }
-        __syncthreads();
+        gen_sync();
         GPROF_STAGE(0)  // forward kinematics + frames
         if (MODE == MODE_FK) return 0.0;
         double fpart = 0.0;
-        if (lane < nt) {
-          const int ft = l_ttask[lane], fo = l_torigin[lane];
-          double r[3];
-          for (int i = 0; i < 3; ++i) r[i] = P[ft * 3 + i] - (fo >= 0 ? P[fo * 3 + i] : 0.0) - tgt[lane * 3 + i];
-          if (kp.kind == DEXR_KIND_POSITION) {  // SmoothL1 per coordinate, mean over 3 P entries (optimizer.py:163-166)
+        if (is_t) {
+          double pt[3], po[3], r[3];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            pt[i] = P[my_ft * 3 + i];
+            po[i] = my_fo_t >= 0 ? P[my_fo_t * 3 + i] : 0.0;
+            r[i] = pt[i] - po[i] - my_tgt[i];
+          }
+          double tgv[3], tuv[3] = {0, 0, 0}, kk[3], kb = 0.0;
+          if (pos) {  // SmoothL1 per coordinate, mean over 3 P entries (optimizer.py:163-166)
+#pragma unroll
             for (int i = 0; i < 3; ++i) {
               const double ad = fabs(r[i]);
               const bool in = ad < beta;
               fpart += (in ? 0.5 * r[i] * r[i] / beta : ad - 0.5 * beta) * inv_norm;
-              tg[lane * 3 + i] = (in ? r[i] / beta : (r[i] > 0 ? 1.0 : (r[i] < 0 ? -1.0 : 0.0))) * inv_norm;
-              tc2[lane * 3 + i] = in ? inv_norm / beta : 0.0;
+              tgv[i] = (in ? r[i] / beta : (r[i] > 0 ? 1.0 : (r[i] < 0 ? -1.0 : 0.0))) * inv_norm;
+              kk[i] = in ? inv_norm / beta : 0.0;
             }
-            tc1[lane] = 0.0;
           } else {  // SmoothL1 of the vector norm, weighted, mean over the V vectors (optimizer.py:262-273, 523-546)
             const double d = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
             const bool in = d < beta;
-            const double w = wt[lane];
+            const double w = my_wt;
             fpart = w * (in ? 0.5 * d * d / beta : d - 0.5 * beta) * inv_norm;
-            const double psi = in ? d / beta : 1.0, kk = in ? 1.0 / beta : 0.0;
+            const double psi = in ? d / beta : 1.0, kq = in ? 1.0 / beta : 0.0;
             const double gc = d > 0 ? w * psi * inv_norm / d : 0.0;  // torch.norm backward: zero at 0
+#pragma unroll
             for (int i = 0; i < 3; ++i) {
-              tg[lane * 3 + i] = gc * r[i];
-              tu[lane * 3 + i] = d > 0 ? r[i] / d : 0.0;
+              tgv[i] = gc * r[i];
+              tuv[i] = d > 0 ? r[i] / d : 0.0;
+              kk[i] = gc;                // H_vec = c1 (I - u u^T) + c2 u u^T
             }
-            tc1[lane] = gc;                          // H_vec = c1 (I - u u^T) + c2 u u^T
-            tc2[lane * 3] = w * kk * inv_norm - gc;  // (c2 - c1)
+            kb = w * kq * inv_norm - gc;  // (c2 - c1)
           }
+          gen_d2* rc = reinterpret_cast<gen_d2*>(rec + lane * 16);
+          rc[0] = gen_d2{pt[0], pt[1]};
+          rc[1] = gen_d2{pt[2], po[0]};
+          rc[2] = gen_d2{po[1], po[2]};
+          rc[3] = gen_d2{tgv[0], tgv[1]};
+          rc[4] = gen_d2{tgv[2], tuv[0]};
+          rc[5] = gen_d2{tuv[1], tuv[2]};
+          rc[6] = gen_d2{kk[0], kk[1]};
+          rc[7] = gen_d2{kk[2], kb};
         }
         const double fval = gen_wave_sum(fpart);
+        gen_sync();
         GPROF_STAGE(1)  // terms
         return fval;
       };
       auto assemble_model = [&]() {
         GPROF_START();
-        if (lane < nv) g[lane] = 0.0;
-        __syncthreads();
-        double hacc[NSLOT];  // this lane's entries of H, accumulated over the terms (slot i: entry 64 i + lane)
+        double hacc[NSLOT];  // this lane's entries of H, accumulated over the terms
 #pragma unroll
         for (int i = 0; i < NSLOT; ++i) hacc[i] = 0.0;
         double cf[3] = {0.0, 0.0, 0.0};  // lane k: CF_k (see below)
-        int rc_[NSLOT];  // (row, column) of this lane's entries: read once per evaluation, not once per term
+        double gacc = 0.0;               // gradient entry of the variable this lane writes columns for
+        // Entries of H owned by this lane += the contributions of one term: columns (and u . column) of the variables in `cb`
+        // (nv x 4), curvatures in the term's record.  position: sum_i k_i v_r[i] v_c[i]; vector kinds:
+        // c1 (v_r . v_c) + (c2 - c1) (u . v_r) (u . v_c).  The rows' columns are loaded once, the columns' stream through.
+        auto add_entries = [&](const double* cb, const double* rc, auto POS) {
+          const gen_d2* cb2 = reinterpret_cast<const gen_d2*>(cb);
+          const gen_d2 k01 = *reinterpret_cast<const gen_d2*>(rc + 12), k2b = *reinterpret_cast<const gen_d2*>(rc + 14);
+          gen_d2 Ra[NI], Rb[NI];
 #pragma unroll
-        for (int i = 0; i < NSLOT; ++i) rc_[i] = (64 * i + lane < ntri) ? (int)l_rc[64 * i + lane] : 0;
-        const bool pos = kp.kind == DEXR_KIND_POSITION;
-        // entries of H owned by this lane += the contributions of term t (columns in vb, u . column in ub) and -- `two` -- of
-        // term t + 1 (vb2, ub2), formed in one body so that both terms' LDS reads are in flight together
-        auto add_entries = [&](int t, const double* vb, const double* ub, bool two, const double* vb2, const double* ub2) {
-          const int t2 = two ? t + 1 : t;
-          const double k0 = pos ? tc2[t * 3] : tc1[t], k1 = pos ? tc2[t * 3 + 1] : tc1[t], k2 = pos ? tc2[t * 3 + 2] : tc1[t];
-          const double kb = pos ? 0.0 : tc2[t * 3];
-          const double m0 = pos ? tc2[t2 * 3] : tc1[t2], m1 = pos ? tc2[t2 * 3 + 1] : tc1[t2], m2 = pos ? tc2[t2 * 3 + 2] : tc1[t2];
-          const double mb = pos ? 0.0 : tc2[t2 * 3];
+          for (int i = 0; i < NI; ++i) {
+            if (8 * i < nv) {  // wave-uniform
+              Ra[i] = cb2[2 * row_ld[i]];
+              Rb[i] = cb2[2 * row_ld[i] + 1];
+            }
+          }
 #pragma unroll
-          for (int i4 = 0; i4 < NSLOT; i4 += 4) {
-            if (64 * i4 < ntri) {  // wave-uniform, per group of four slots: the slots of a group overlap their LDS reads
+          for (int j = 0; j < NI; ++j) {
+            if (8 * j < nv) {
+              const gen_d2 ca = cb2[2 * col_ld[j]], cbv = cb2[2 * col_ld[j] + 1];
+              const double w0 = k01.x * ca.x, w1 = k01.y * ca.y, w2 = k2b.x * cbv.x, w3 = k2b.y * cbv.y;
 #pragma unroll
-              for (int i = i4; i < i4 + 4 && i < NSLOT; ++i) {
-                if (64 * i + lane < ntri) {
-                  const int r = rc_[i] & 0xFF, c = rc_[i] >> 8;
-                  // position: sum_i k_i v_r[i] v_c[i]  |  vector kinds: c1 (v_r . v_c) + (c2 - c1) (u . v_r) (u . v_c)
-                  double add = k0 * vb[r * 3] * vb[c * 3] + k1 * vb[r * 3 + 1] * vb[c * 3 + 1] + k2 * vb[r * 3 + 2] * vb[c * 3 + 2];
-                  if (!pos) add += kb * ub[r] * ub[c];  // (0 x uninitialised LDS is not 0)
-                  if (two) {
-                    add += m0 * vb2[r * 3] * vb2[c * 3] + m1 * vb2[r * 3 + 1] * vb2[c * 3 + 1] + m2 * vb2[r * 3 + 2] * vb2[c * 3 + 2];
-                    if (!pos) add += mb * ub2[r] * ub2[c];
-                  }
-                  hacc[i] += add;
+              for (int i = j; i < NI; ++i) {
+                if (8 * i < nv) {
+                  double add = fma(Ra[i].x, w0, fma(Ra[i].y, w1, Rb[i].x * w2));
+                  if (!POS.value) add = fma(Rb[i].y, w3, add);
+                  hacc[i * (i + 1) / 2 + j] += add;
                 }
               }
             }
           }
         };
-        // joint k's column of term t: a x (p - o) over the term's two frames (sign), or the axis (prismatic)
-        auto joint_column = [&](int t, double (&c)[3]) {
-          const int ft = l_ttask[t], fo = l_torigin[t];
-          const unsigned long long at = l_fanc[ft], ao = fo >= 0 ? l_fanc[fo] : 0ull;
-          const int k = lane;
-          c[0] = 0.0; c[1] = 0.0; c[2] = 0.0;
-          const bool rev = l_jtype[k] == DEXR_JOINT_REVOLUTE;
-          for (int side = 0; side < 2; ++side) {
-            const bool on = ((side ? ao : at) >> k) & 1ull;
-            if (!on) continue;
-            const int fr = side ? fo : ft;
-            const double sg = side ? -1.0 : 1.0;
-            if (rev) {
-              const double dx = P[fr * 3] - Tw[k * 12 + 9], dy = P[fr * 3 + 1] - Tw[k * 12 + 10], dz = P[fr * 3 + 2] - Tw[k * 12 + 11];
-              c[0] += sg * (aw[k * 3 + 1] * dz - aw[k * 3 + 2] * dy);
-              c[1] += sg * (aw[k * 3 + 2] * dx - aw[k * 3] * dz);
-              c[2] += sg * (aw[k * 3] * dy - aw[k * 3 + 1] * dx);
-            } else {
-              for (int i = 0; i < 3; ++i) c[i] += sg * aw[k * 3 + i];
-            }
+        // joint k's column of term t: a x (p - o) over the term's two frames (sign), or the axis (prismatic); p from the
+        // term's record, a / o / the chain masks from the lane's registers
+        auto joint_column = [&](int t, const double* rc, double (&c)[3]) {
+          const gen_d2* r2 = reinterpret_cast<const gen_d2*>(rc);
+          const gen_d2 q0 = r2[0], q1 = r2[1], q2 = r2[2], q3 = r2[3], q4 = r2[4];
+          const double pt[3] = {q0.x, q0.y, q1.x}, po[3] = {q1.y, q2.x, q2.y}, tgv[3] = {q3.x, q3.y, q4.x};
+          const bool onT = (on_task >> t) & 1ull, onO = (on_origin >> t) & 1ull;
+          double dv[3];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) dv[i] = (onT ? pt[i] - my_o[i] : 0.0) - (onO ? po[i] - my_o[i] : 0.0);
+          c[0] = my_a[1] * dv[2] - my_a[2] * dv[1];
+          c[1] = my_a[2] * dv[0] - my_a[0] * dv[2];
+          c[2] = my_a[0] * dv[1] - my_a[1] * dv[0];
+          if (any_prismatic) {  // wave-uniform
+            const double sg = (onT ? 1.0 : 0.0) - (onO ? 1.0 : 0.0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) c[i] = my_rev ? c[i] : sg * my_a[i];
           }
           // second-order kinematic term, first half: CF_k = sum over the terms of (column of joint k) x (force of the
           // term) -- the entry for a pair (joint k, revolute ancestor-or-self j) is m_j m_k a_j . CF_k, formed ONCE per
           // pass after the term loop (tg . (a_j x c) = a_j . (c x tg))
-          cf[0] += c[1] * tg[t * 3 + 2] - c[2] * tg[t * 3 + 1];
-          cf[1] += c[2] * tg[t * 3] - c[0] * tg[t * 3 + 2];
-          cf[2] += c[0] * tg[t * 3 + 1] - c[1] * tg[t * 3];
+          cf[0] += c[1] * tgv[2] - c[2] * tgv[1];
+          cf[1] += c[2] * tgv[0] - c[0] * tgv[2];
+          cf[2] += c[0] * tgv[1] - c[1] * tgv[0];
         };
-        if (no_mimic) {
-          // every variable drives exactly one joint: lane k writes its variable's column itself, the columns are
-          // double-buffered (vcol | jcol, tmp | act: both spare here) -- ONE barrier per term instead of three
-          const int v = lane < nj ? l_var[lane] : -1;
-          const double m = lane < nj ? l_jmul[lane] : 0.0;
-          // lane k: its variable's column of term t into the buffer pair (vb, ub), its gradient entry
-          auto own_column = [&](int t, double* vb, double* ub) {
-            double c[3];
-            joint_column(t, c);
-            if (v >= 0) {
-              const double c0 = m * c[0], c1 = m * c[1], c2 = m * c[2];
-              vb[v * 3] = c0; vb[v * 3 + 1] = c1; vb[v * 3 + 2] = c2;
-              g[v] += tg[t * 3] * c0 + tg[t * 3 + 1] * c1 + tg[t * 3 + 2] * c2;
-              if (!pos) ub[v] = tu[t * 3] * c0 + tu[t * 3 + 1] * c1 + tu[t * 3 + 2] * c2;
-            }
-          };
-          // terms in PAIRS: both terms' columns are formed and published before one barrier, both terms' entries are added
-          // before the next -- as many barriers per term as the double-buffered single-term loop had (one), but two
-          // independent chains of LDS round trips in flight in either phase
-          for (int t = 0; t < nt; t += 2) {
-            const bool two = t + 1 < nt;  // wave-uniform
-            if (lane < nj) {
-              own_column(t, vcol, tmp);
-              if (two) own_column(t + 1, jcol, act);
-            }
-            __syncthreads();
-            add_entries(t, vcol, tmp, two, jcol, act);
-            __syncthreads();
-          }
-        } else {
-          for (int t = 0; t < nt; ++t) {
-            if (lane < nj) {
+        auto term_loop = [&](auto POS) {
+          if (no_mimic) {
+            // every variable drives exactly one joint: lane k writes its variable's column record itself.  Terms in PAIRS:
+            // both terms' columns are published (colA, colB) before either is read
+            auto own_column = [&](int t, double* cb) {
+              const double* rc = rec + t * 16;
               double c[3];
-              joint_column(t, c);
-              for (int i = 0; i < 3; ++i) jcol[lane * 3 + i] = c[i];
-            }
-            __syncthreads();
-            if (lane < nv) {  // the variable's column: its joint family folded (kinematics_adaptor.py:102-113)
-              double c[3] = {0, 0, 0};
-              for (int e = l_famoff[lane]; e < l_famoff[lane + 1]; ++e) {
-                const int k = l_fam[e];
-                const double mk = l_jmul[k];
-                for (int i = 0; i < 3; ++i) c[i] += mk * jcol[k * 3 + i];
+              joint_column(t, rc, c);
+              if (my_var >= 0) {
+                const double c0 = my_jmul * c[0], c1 = my_jmul * c[1], c2 = my_jmul * c[2];
+                const gen_d2 q3 = *reinterpret_cast<const gen_d2*>(rc + 6), q4 = *reinterpret_cast<const gen_d2*>(rc + 8),
+                             q5 = *reinterpret_cast<const gen_d2*>(rc + 10);
+                gacc += q3.x * c0 + q3.y * c1 + q4.x * c2;
+                const double u = POS.value ? 0.0 : q4.y * c0 + q5.x * c1 + q5.y * c2;
+                gen_d2* o = reinterpret_cast<gen_d2*>(cb + my_var * 4);
+                o[0] = gen_d2{c0, c1};
+                o[1] = gen_d2{c2, u};
               }
-              for (int i = 0; i < 3; ++i) vcol[lane * 3 + i] = c[i];
-              g[lane] += tg[t * 3] * c[0] + tg[t * 3 + 1] * c[1] + tg[t * 3 + 2] * c[2];
-              // u . column (vector kinds only: the position objective has no unit vector, its tu block is never written)
-              if (!pos) tmp[lane] = tu[t * 3] * c[0] + tu[t * 3 + 1] * c[1] + tu[t * 3 + 2] * c[2];
+            };
+            for (int t = 0; t < nt; t += 2) {
+              const bool two = t + 1 < nt;  // wave-uniform
+              if (is_j) {
+                own_column(t, colA);
+                if (two) own_column(t + 1, colB);
+              }
+              gen_sync();
+              add_entries(colA, rec + t * 16, POS);
+              if (two) add_entries(colB, rec + (t + 1) * 16, POS);
+              gen_sync();
             }
-            __syncthreads();
-            add_entries(t, vcol, tmp, false, vcol, tmp);
-            __syncthreads();
+          } else {
+            for (int t = 0; t < nt; ++t) {
+              const double* rc = rec + t * 16;
+              if (is_j) {
+                double c[3];
+                joint_column(t, rc, c);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) jcol[lane * 3 + i] = c[i];
+              }
+              gen_sync();
+              if (is_v) {  // the variable's column: its joint family folded (kinematics_adaptor.py:102-113)
+                double c[3] = {0, 0, 0};
+                for (int e = l_famoff[lane]; e < l_famoff[lane + 1]; ++e) {
+                  const int k = l_fam[e];
+                  const double mk = l_jmul[k];
+                  for (int i = 0; i < 3; ++i) c[i] += mk * jcol[k * 3 + i];
+                }
+                gacc += rc[6] * c[0] + rc[7] * c[1] + rc[8] * c[2];
+                // u . column (vector kinds only: the position objective has no unit vector)
+                const double u = POS.value ? 0.0 : rc[9] * c[0] + rc[10] * c[1] + rc[11] * c[2];
+                gen_d2* o = reinterpret_cast<gen_d2*>(colA + lane * 4);
+                o[0] = gen_d2{c[0], c[1]};
+                o[1] = gen_d2{c[2], u};
+              }
+              gen_sync();
+              add_entries(colA, rc, POS);
+              gen_sync();
+            }
           }
+        };
+        if (pos) term_loop(std::true_type{});
+        else term_loop(std::false_type{});
+        // the gradient of the data term: one writer per variable
+        if (no_mimic) {
+          if (my_var >= 0) g[my_var] = gacc;
+        } else if (is_v) {
+          g[lane] = gacc;
         }
         GPROF_STAGE(2)  // term loop: columns, gradient, Hessian entries
         // second-order kinematic term, second half: for every joint k that moves with a variable and every revolute
         // ancestor-or-self j of k that does too,  H[var j][var k] += m_j m_k a_j . CF_k  (twice for j != k inside one
         // family: both orders of the unordered pair).
-        if (kp.newton) {
-          if (lane < nj) {
-            for (int i = 0; i < 3; ++i) jcol[lane * 3 + i] = cf[i];
-          }
-          __syncthreads();
-        }
         if (kp.newton && no_mimic) {
-          // one joint per variable: the owner of entry (r, c) forms its (at most two) contributions itself -- joint of r as
-          // the moved joint with the joint of c as its ancestor, and the other way round
+          // one joint per variable: lane k publishes m a_k and m CF_k under its variable, the owner of entry (r, c) forms its
+          // (at most two) contributions -- the joint of r moved with the joint of c as its ancestor, and the other way round
+          // (which of the two exist was worked out per slot when the kernel started)
+          if (my_var >= 0) {
+            gen_d2* oa = reinterpret_cast<gen_d2*>(colA + my_var * 4);
+            gen_d2* oc = reinterpret_cast<gen_d2*>(colB + my_var * 4);
+            oa[0] = gen_d2{my_jmul * my_a[0], my_jmul * my_a[1]};
+            oa[1] = gen_d2{my_jmul * my_a[2], 0.0};
+            oc[0] = gen_d2{my_jmul * cf[0], my_jmul * cf[1]};
+            oc[1] = gen_d2{my_jmul * cf[2], 0.0};
+          }
+          gen_sync();
+          const gen_d2* A2 = reinterpret_cast<const gen_d2*>(colA);
+          const gen_d2* C2 = reinterpret_cast<const gen_d2*>(colB);
+          gen_d2 Ara[NI], Arb[NI], Cra[NI], Crb[NI];
 #pragma unroll
-          for (int i = 0; i < NSLOT; ++i) {
-            if (64 * i < ntri) {
-              if (64 * i + lane < ntri) {
-                const int r = rc_[i] & 0xFF, c = rc_[i] >> 8;
-                const int jr = l_fam[l_famoff[r]], jc = l_fam[l_famoff[c]];
-                double val = 0.0;
-                if (((l_janc[jr] >> jc) & 1ull) && l_jtype[jc] == DEXR_JOINT_REVOLUTE)  // k = jr, j = jc
-                  val += l_jmul[jc] * l_jmul[jr] * (aw[jc * 3] * jcol[jr * 3] + aw[jc * 3 + 1] * jcol[jr * 3 + 1] + aw[jc * 3 + 2] * jcol[jr * 3 + 2]);
-                if (jr != jc && ((l_janc[jc] >> jr) & 1ull) && l_jtype[jr] == DEXR_JOINT_REVOLUTE)  // k = jc, j = jr
-                  val += l_jmul[jr] * l_jmul[jc] * (aw[jr * 3] * jcol[jc * 3] + aw[jr * 3 + 1] * jcol[jc * 3 + 1] + aw[jr * 3 + 2] * jcol[jc * 3 + 2]);
-                hacc[i] += val;
+          for (int i = 0; i < NI; ++i) {
+            if (8 * i < nv) {
+              Ara[i] = A2[2 * row_ld[i]]; Arb[i] = A2[2 * row_ld[i] + 1];
+              Cra[i] = C2[2 * row_ld[i]]; Crb[i] = C2[2 * row_ld[i] + 1];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            if (8 * j < nv) {
+              const gen_d2 Aca = A2[2 * col_ld[j]], Acb = A2[2 * col_ld[j] + 1], Cca = C2[2 * col_ld[j]], Ccb = C2[2 * col_ld[j] + 1];
+#pragma unroll
+              for (int i = j; i < NI; ++i) {
+                if (8 * i < nv) {
+                  const int sl = i * (i + 1) / 2 + j;
+                  const double v1 = Aca.x * Cra[i].x + Aca.y * Cra[i].y + Acb.x * Crb[i].x;  // a_c . CF_r
+                  const double v2 = Ara[i].x * Cca.x + Ara[i].y * Cca.y + Arb[i].x * Ccb.x;  // a_r . CF_c
+                  hacc[sl] += (((so_rc >> sl) & 1ull) ? v1 : 0.0) + (((so_cr >> sl) & 1ull) ? v2 : 0.0);
+                }
               }
             }
           }
         }
 #pragma unroll
-        for (int i = 0; i < NSLOT; ++i)
-          if (64 * i + lane < ntri) H[64 * i + lane] = hacc[i];
-        __syncthreads();
+        for (int i = 0; i < NI; ++i) {
+#pragma unroll
+          for (int j = 0; j <= i; ++j) {
+            const int sl = i * (i + 1) / 2 + j;
+            if (8 * i < nv && ((slot_ok >> sl) & 1ull)) H[GEN_TRI(ga + 8 * i, gb + 8 * j)] = hacc[sl];
+          }
+        }
+        gen_sync();
         if (kp.newton && !no_mimic) {
           // families of several joints: one sweep over the joints per PASS -- lane j forms the entry of pair (j, k), lane v
           // sums its variable's family and adds into its own entries.  (Round 3 walked the chains of every TERM instead --
           // terms x chain depth x 2 block barriers, ~1 500 per pass for an arm + hand: most of the ~300 us a pass took.)
+          if (is_j) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) jcol[lane * 3 + i] = cf[i];
+          }
+          gen_sync();
           for (int k = 0; k < nj; ++k) {  // wave-uniform
             const int vk = l_var[k];
             if (vk < 0) continue;
             const unsigned long long ak = l_janc[k];
-            if (lane < nj) {
+            if (is_j) {
               const int j = lane;
               double val = 0.0;
-              if (((ak >> j) & 1ull) && l_jtype[j] == DEXR_JOINT_REVOLUTE && l_var[j] >= 0) {
-                val = l_jmul[j] * l_jmul[k] * (aw[j * 3] * jcol[k * 3] + aw[j * 3 + 1] * jcol[k * 3 + 1] + aw[j * 3 + 2] * jcol[k * 3 + 2]);
-                if (j != k && l_var[j] == vk) val *= 2.0;
+              if (((ak >> j) & 1ull) && my_rev && my_var >= 0) {
+                val = my_jmul * l_jmul[k] * (my_a[0] * jcol[k * 3] + my_a[1] * jcol[k * 3 + 1] + my_a[2] * jcol[k * 3 + 2]);
+                if (j != k && my_var == vk) val *= 2.0;
               }
               tmp[j] = val;
             }
-            __syncthreads();
-            if (lane < nv) {
+            gen_sync();
+            if (is_v) {
               double sum = 0.0;
               for (int e = l_famoff[lane]; e < l_famoff[lane + 1]; ++e) sum += tmp[l_fam[e]];
               if (sum != 0.0) {
@@ -666,7 +809,7 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
                 H[GEN_TRI(hi_, lo_)] += sum;
               }
             }
-            __syncthreads();
+            gen_sync();
           }
         }
         GPROF_STAGE(3)  // second-order sweep
@@ -674,11 +817,11 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
 
       if (MODE == MODE_FK) {
         eval_value(x);
-        if (lane < nt) {
-          const int f = tb.term_task[lane], row = tb.term_ref[lane];
+        if (is_t) {
+          const int f = my_ft, row = tb.term_ref[lane];
           for (int i = 0; i < 3; ++i) kp.f64out[(it * kp.n_ref + row) * 3 + i] = P[f * 3 + i];
         }
-        __syncthreads();
+        gen_sync();
         continue;
       }
       if (MODE == MODE_EVAL) {  // objective(x, grad): value without, gradient with the regulariser (quirk Q1)
@@ -688,34 +831,33 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
           kp.f64out[r0] = f;
           if (dexpilot && kp.state) kp.state[r0] = nst;
         }
-        if (lane < nv) kp.g64out[r0 * kp.n_opt + my_api] = g[lane] + 2.0 * delta * (x[lane] - xl[lane]);
-        __syncthreads();
+        if (is_v) kp.g64out[r0 * kp.n_opt + my_api] = g[lane] + 2.0 * delta * (x[lane] - my_xl);
+        gen_sync();
         continue;
       }
 
       // ---- MODE_SOLVE ---------------------------------------------------------------------------------------------
       auto reg_at = [&](const double* xs) -> double {
         double p = 0.0;
-        if (lane < nv) p = (xs[lane] - xl[lane]) * (xs[lane] - xl[lane]);
+        if (is_v) p = (xs[lane] - my_xl) * (xs[lane] - my_xl);
         return delta * gen_wave_sum(p);
       };
       auto add_reg_model = [&](const double* xs) {
-        if (lane < nv) {
-          g[lane] += 2.0 * delta * (xs[lane] - xl[lane]);
+        if (is_v) {
+          g[lane] += 2.0 * delta * (xs[lane] - my_xl);
           H[GEN_TRI(lane, lane)] += 2.0 * delta;
         }
-        __syncthreads();
+        gen_sync();
       };
-      if (lane < nv) {
+      if (is_v) {
         x[lane] = fmin(fmax(x[lane], my_lo), my_hi);
         xt[lane] = x[lane];
       }
-      __syncthreads();
+      gen_sync();
       // ONE value evaluation per pass (through ONE call site: every F that is ever compared comes from the same code, so the
       // comparison is not one of two copies' rounding) and the model -- gradient + Hessian, most of a pass -- only at points
-      // that have been ACCEPTED: the kinematic state in LDS is the trial point's, so an accepted step goes straight on to
-      // assemble_model(), a rejected one costs the kinematics and the terms alone.  (Round 3: value at the trial point,
-      // then value + model again at the same point through a second inlined copy.)  The start point is "trial point 0".
+      // that have been ACCEPTED: the kinematic state is the trial point's, so an accepted step goes straight on to
+      // assemble_model(), a rejected one costs the kinematics and the terms alone.  The start point is "trial point 0".
       double F = 0.0, lam = (double)kp.lam0, nu = 2.0;
       int iters = 0, status = ST_MAXITER;
       const double tol = (double)kp.tol, cap = (double)kp.step_cap;
@@ -728,42 +870,45 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
           ++iters;
           GPROF_COUNT(11);
           // active set and damped system (lower triangle), lane = row
-          if (lane < nv) {
+          if (is_v) {
             const bool a = (x[lane] <= my_lo && g[lane] > 0) || (x[lane] >= my_hi && g[lane] < 0);
             act[lane] = a ? 1.0 : 0.0;
           }
-          __syncthreads();
+          gen_sync();
           GPROF_STAGE(4)  // active set
-          constexpr int NV = NSLOT == GEN_SLOTS_SMALL ? 38 : 64;  // rows the register factorisation holds
-          chol_ok = gen_factor_solve<NV>(lane, nv, H, g, act, lam, tb.lt_in_lds ? Lt : nullptr, s);
-          __syncthreads();
+          chol_ok = gen_factor_solve<NV>(lane, nv, gen_lds_addr(H), gen_lds_addr(g), gen_lds_addr(act), lam, gen_lds_addr(Lt), gen_lds_addr(s));
+          gen_sync();
           GPROF_STAGE(5)  // factorisation + triangular solves (registers)
           if (chol_ok) {
             GPROF_STAGE(6)
-            double sm = lane < nv ? fabs(s[lane]) : 0.0;
+            double sm = is_v ? fabs(s[lane]) : 0.0;
             sm = gen_wave_max(sm);
             const double scale = (cap > 0 && sm > cap) ? cap / sm : 1.0;
-            if (lane < nv) {
+            double my_s = 0.0;
+            if (is_v) {
               const double xn = fmin(fmax(x[lane] + scale * s[lane], my_lo), my_hi);
               xt[lane] = xn;
-              s[lane] = xn - x[lane];
+              my_s = xn - x[lane];
+              s[lane] = my_s;
             }
-            __syncthreads();
-            double pp = 0.0, am = 0.0;
-            if (lane < nv) {
+            gen_sync();
+            // predicted decrease -(g . s + s^T H s / 2) with the TAKEN (scaled, clipped) step: lane r sums its own row's
+            // strictly-lower part, s^T H s = sum_r s_r (2 sum_{u<r} H_ru s_u + H_rr s_r)
+            double pp = 0.0;
+            if (is_v) {
+              const double* Hr = H + GEN_TRI(lane, 0);
               double hs = 0.0;
-              for (int u = 0; u < nv; ++u) hs += (u <= lane ? H[GEN_TRI(lane, u)] : H[GEN_TRI(u, lane)]) * s[u];
-              pp = -(g[lane] * s[lane] + 0.5 * s[lane] * hs);
-              am = fabs(s[lane]);
+              for (int u = 0; u < lane; ++u) hs += Hr[u] * s[u];
+              pp = -(g[lane] * my_s + 0.5 * my_s * (2.0 * hs + Hr[lane] * my_s));
             }
             pred = gen_wave_sum(pp);
-            smax = gen_wave_max(am);
+            smax = gen_wave_max(fabs(my_s));
             GPROF_STAGE(7)  // step, predicted decrease
             if (lam <= (double)kp.lam0 && smax < (double)kp.blind_tol) {
               // an essentially undamped Newton step of a verified model shorter than blind_tol: its error is ~C s^2, far
               // below tol -- taken without a further evaluation (the rule of the specialised kernels)
-              if (lane < nv) x[lane] = xt[lane];
-              __syncthreads();
+              if (is_v) x[lane] = xt[lane];
+              gen_sync();
               status = ST_CONVERGED;
               break;
             }
@@ -788,8 +933,8 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
         if (accept) {
           const double rho = (F - Ft) / fmax(pred, 1e-300);
           const bool small = smax < tol || pred <= 1e-18 * fmax(F, 1e-30);
-          if (lane < nv) x[lane] = xt[lane];
-          __syncthreads();
+          if (is_v) x[lane] = xt[lane];
+          gen_sync();
           F = Ft;
           const double t3 = 2.0 * rho - 1.0;
           double shrink = fmax(1.0 / 3.0, 1.0 - t3 * t3 * t3);
@@ -800,7 +945,7 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
             status = ST_CONVERGED;
             break;
           }
-          assemble_model();  // the model of the point just accepted (its kinematics are still in LDS)
+          assemble_model();  // the model of the point just accepted (its kinematics are still in LDS / registers)
           add_reg_model(x);
         } else {
           lam *= nu;
@@ -814,11 +959,11 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
       }
       // ---- write the frame's answer ------------------------------------------------------------------------------------
       bool nonfinite = bad;
-      if (lane < nv) nonfinite = nonfinite || !(x[lane] == x[lane]) || fabs(x[lane]) > 1e30;
+      if (is_v) nonfinite = nonfinite || !(x[lane] == x[lane]) || fabs(x[lane]) > 1e30;
       nonfinite = __any(nonfinite);
       if (nonfinite) status = ST_FALLBACK;  // like optimizer.py:100-102: last_qpos is returned
-      if (lane < nv) {
-        const double v = nonfinite ? xl[lane] : x[lane];
+      if (is_v) {
+        const double v = nonfinite ? my_xl : x[lane];
         if (nonfinite) x[lane] = v;
         kp.qout[it * ld + my_api] = (float)v;
         if (kp.qout64) kp.qout64[it * ld + my_api] = v;
@@ -829,10 +974,10 @@ __global__ void __launch_bounds__(64, NSLOT == GEN_SLOTS_SMALL ? 2 : 1) dexr_gen
         if (kp.fval) kp.fval[it] = (float)F;
       }
       st_carry = nst;
-      __syncthreads();
+      gen_sync();
     }
     if (MODE == MODE_SOLVE && dexpilot && kp.state && lane == 0) kp.state[r0] = st_carry;
-    __syncthreads();
+    gen_sync();
   }
   GPROF_FLUSH()
 }

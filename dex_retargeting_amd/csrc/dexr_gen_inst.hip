@@ -4,22 +4,22 @@
 #include "dexr_launch.hpp"
 
 namespace dexr {
-size_t gen_lds_bytes(const GenTab& tb) { return gen_lds_doubles(tb.nj, tb.nf, tb.nt, tb.nv, tb.nfam, tb.lt_in_lds != 0) * sizeof(double); }
+size_t gen_lds_bytes(const GenTab& tb) { return gen_lds_doubles(tb.nj, tb.nf, tb.nt, tb.nv, tb.nfam) * sizeof(double); }
 
-template <int MODE, int NSLOT> static hipError_t launch_gen_mode(const KernelParams& kp, const GenTab& tb, dim3 grid, size_t lds, hipStream_t st) {
+template <int MODE, int NI> static hipError_t launch_gen_mode(const KernelParams& kp, const GenTab& tb, dim3 grid, size_t lds, hipStream_t st) {
   static DynLds dyn;
-  hipError_t e = dyn.ensure(reinterpret_cast<const void*>(&dexr_gen_kernel<MODE, NSLOT>), lds);
+  hipError_t e = dyn.ensure(reinterpret_cast<const void*>(&dexr_gen_kernel<MODE, NI>), lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((dexr_gen_kernel<MODE, NSLOT>), grid, dim3(64), lds, st, kp, tb);
+  hipLaunchKernelGGL((dexr_gen_kernel<MODE, NI>), grid, dim3(64), lds, st, kp, tb);
   return hipGetLastError();
 }
 
 hipError_t launch_gen(int mode, const KernelParams& kp, const GenTab& tb, dim3 grid, size_t lds, hipStream_t st) {
-  // the lower triangle of the Hessian is accumulated in registers, NSLOT entries per lane: 12 x 64 entries serve models of
-  // up to 38 variables at 2 waves per SIMD, the 33-slot instantiation the rest (up to 64 variables)
-  const bool small = tb.nv * (tb.nv + 1) / 2 <= GEN_SLOTS_SMALL * 64;
-  if (mode == MODE_SOLVE) return small ? launch_gen_mode<MODE_SOLVE, GEN_SLOTS_SMALL>(kp, tb, grid, lds, st) : launch_gen_mode<MODE_SOLVE, GEN_SLOTS_BIG>(kp, tb, grid, lds, st);
-  if (mode == MODE_EVAL) return small ? launch_gen_mode<MODE_EVAL, GEN_SLOTS_SMALL>(kp, tb, grid, lds, st) : launch_gen_mode<MODE_EVAL, GEN_SLOTS_BIG>(kp, tb, grid, lds, st);
-  return launch_gen_mode<MODE_FK, GEN_SLOTS_SMALL>(kp, tb, grid, lds, st);
+  // the lower triangle of the Hessian is tiled over an 8 x 8 lane grid, NI x NI tiles per lane: NI = 5 serves models of up to
+  // 40 variables at 2 waves per SIMD, the NI = 8 instantiation the rest (up to 64 variables)
+  const bool small = tb.nv <= 8 * GEN_NI_SMALL;
+  if (mode == MODE_SOLVE) return small ? launch_gen_mode<MODE_SOLVE, GEN_NI_SMALL>(kp, tb, grid, lds, st) : launch_gen_mode<MODE_SOLVE, GEN_NI_BIG>(kp, tb, grid, lds, st);
+  if (mode == MODE_EVAL) return small ? launch_gen_mode<MODE_EVAL, GEN_NI_SMALL>(kp, tb, grid, lds, st) : launch_gen_mode<MODE_EVAL, GEN_NI_BIG>(kp, tb, grid, lds, st);
+  return launch_gen_mode<MODE_FK, GEN_NI_SMALL>(kp, tb, grid, lds, st);
 }
 }  // namespace dexr
