@@ -131,8 +131,8 @@ typedef __attribute__((address_space(3))) double gen_lds_f64;
 typedef __attribute__((address_space(3))) gen_d2 gen_lds_d2;
 __device__ __forceinline__ unsigned gen_lds_addr(const double* p) {
   unsigned a = (unsigned)(uintptr_t)(const gen_lds_f64*)p;
-  asm volatile("" : "+s"(a));
-  return a;
+  asm volatile("" : "+v"(a));  // (opaque, then wave-uniform again: the idiom of tip_pin, dexr_tip.hpp)
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)a);
 }
 
 // Solve (H restricted to the free set + lam I) d = -g for the step d.  Lane r holds row r of the lower triangle in
@@ -180,7 +180,6 @@ __device__ __noinline__ bool gen_factor_solve(int lane, int nv, unsigned aH, uns
     L[c] = v;
   }
   double rhs = (rowv && !a_r) ? -g[lane] : 0.0;
-  double invd = 0.0;  // 1 / L[lane][lane]
   bool ok = true;
   gen_lds_f64* my_row = Lt + base;
 #pragma unroll
@@ -188,8 +187,10 @@ __device__ __noinline__ bool gen_factor_solve(int lane, int nv, unsigned aH, uns
     if (c < nv && ok) {  // wave-uniform
       double acc = L[c];
       // row c of the factor so far: entries [0, nl) from the LDS copy (wave-uniform, contiguous: pairs where the address is
-      // 16-byte aligned), the last two -- written one and two columns ago -- from lane c's registers
-      constexpr int NEAR = 2;
+      // 16-byte aligned).  In the first columns the last two entries -- written one and two columns ago -- come from lane
+      // c's registers (the LDS write -> read latency would sit on the column-to-column chain); from column 8 on the reads
+      // are issued a column's worth of multiply-adds before their values are due
+      const int NEAR = c < 8 ? 2 : 0;
       const int nl = c > NEAR ? c - NEAR : 0;  // (c is the unrolled loop's constant: all of this folds)
       const int rs = c * (c + 1) / 2;
       const gen_lds_f64* row_c = Lt + rs;
@@ -217,14 +218,22 @@ __device__ __noinline__ bool gen_factor_solve(int lane, int nv, unsigned aH, uns
         ip = ip * fma(-0.5 * d * ip, ip, 1.5);
         ip = ip * fma(-0.5 * d * ip, ip, 1.5);
         const double lv = acc * ip;
-        if (rowv && lane >= c) my_row[c] = lv;  // (lane c's own entry is sqrt(d): the diagonal, which nothing reads)
+        if (rowv && lane >= c) my_row[c] = lv;  // (lane c's own entry is sqrt(d), the diagonal)
         L[c] = lane > c ? lv : 0.0;
-        invd = lane == c ? ip : invd;
         gen_sync();
       }
     }
   }
   if (!ok) return false;
+  // 1 / L[lane][lane] from the diagonal the lane wrote (hardware estimate + two Newton steps)
+  double invd = 0.0;
+  if (rowv) {
+    const double dg = my_row[lane];
+    double r = __builtin_amdgcn_rcp(dg);
+    r = r * fma(-dg, r, 2.0);
+    r = r * fma(-dg, r, 2.0);
+    invd = r;
+  }
   // L y = rhs, column-wise: once the columns before k have been subtracted, lane k's value is final and is broadcast
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -271,6 +280,7 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
   double* P = rec + nt * 16;        // nf x 3
   double* jcol = P + nf * 3;        // nj x 3
   double* tmp = jcol + nj * 3;      // nj
+  int32_t* jptr = reinterpret_cast<int32_t*>(tmp);  // nj: the kinematics' ancestor pointers (tmp is the model assembly's)
   double* Lt = gen_lds;             // row-major packed Cholesky factor (gen_factor_solve)
   // ---- live --------------------------------------------------------------------------------------------------------------
   double* x = gen_lds + gen_scratch_doubles(nj, nf, nt, nv);  // nv each:
@@ -315,7 +325,6 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
   // Lane k IS joint k (and variable k, link k, term k) for the whole kernel: what the tables say about them is read ONCE,
   // into registers.
   const bool is_j = lane < nj, is_v = lane < nv, is_f = lane < nf, is_t = lane < nt;
-  const int my_depth = is_j ? tb.depth[lane] : -1;
   const int my_src = is_j ? tb.src_idx[lane] : 0;
   const int my_var = is_j ? l_var[lane] : -1;
   const int my_parent = is_j ? l_parent[lane] : -1;
@@ -342,16 +351,19 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
     if (is_j && fo >= 0 && ((l_fanc[fo] >> lane) & 1ull)) on_origin |= 1ull << t;
   }
   const bool any_prismatic = __any(is_j && !my_rev);  // wave-uniform
+  const int kin_rounds = tb.max_depth > 0 ? 32 - __builtin_clz((unsigned)tb.max_depth) : 0;  // 2^rounds - 1 >= depth of the deepest joint
   const bool no_mimic = tb.nfam == nv;  // every variable drives exactly one joint (families partition the driven joints)
 
   // The lane's tiles of the lower triangle: lane (a, b) of the 8 x 8 grid owns entry (a + 8 i, b + 8 j) for j <= i (on the
   // diagonal tiles only where b <= a); slot i (i + 1) / 2 + j.
   const int ga = lane >> 3, gb = lane & 7;
   int row_ld[NI], col_ld[NI];  // rows / columns to LOAD (clamped into the matrix: an out-of-range tile computes garbage it never stores)
+  int row_tri[NI];             // start of row ga + 8 i in the packed triangle
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     row_ld[i] = min(ga + 8 * i, nv - 1);
     col_ld[i] = min(gb + 8 * i, nv - 1);
+    row_tri[i] = (ga + 8 * i) * (ga + 8 * i + 1) / 2;
   }
   unsigned long long slot_ok = 0ull, so_rc = 0ull, so_cr = 0ull;  // per slot: entry exists | second-order contributions (mimic-free models)
 #pragma unroll
@@ -380,6 +392,7 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
   const bool dexpilot = kp.kind == DEXR_KIND_DEXPILOT;
   const bool pos = kp.kind == DEXR_KIND_POSITION;
   const double beta = (double)kp.huber_delta, delta = (double)kp.norm_delta, inv_norm = (double)kp.inv_norm;
+  const double ibeta = 1.0 / beta;
   double my_o[3] = {0, 0, 0}, my_a[3] = {0, 0, 0};  // lane k: origin and world axis of joint k at the last evaluated point
 
   for (int64_t item = blockIdx.x; item < cnt; item += gridDim.x) {
@@ -505,28 +518,50 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
             Lc[9 + i] = myX[9 + i] + tq * (myX[3 * i] * ax + myX[3 * i + 1] * ay + myX[3 * i + 2] * az);
           }
         }
+        // World transforms by POINTER JUMPING: every joint holds the product of the local transforms from below its current
+        // "pointer" ancestor down to itself; a round composes it with that ancestor's product and adopts the ancestor's
+        // pointer, which doubles the length of the covered path -- ceil(log2(depth + 1)) rounds with every lane busy,
+        // instead of one round per tree level with one or two lanes busy (19 levels for an arm + hand: a third of the
+        // kinematics' instructions and a quarter of its exposed LDS round trips).  A round's reads all precede its writes
+        // in the wave's instruction stream, so the old values are what is read.
         double Tk[12];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) Tk[i] = Lc[i];  // (a root joint's world transform is its local one)
-        for (int d = 0; d <= tb.max_depth; ++d) {
-          if (my_depth == d) {
-            if (my_parent >= 0) {
-              const gen_d2* Tp = reinterpret_cast<const gen_d2*>(Tw + my_parent * 12);
+        for (int i = 0; i < 12; ++i) Tk[i] = Lc[i];
+        {
+          int pj = my_parent;
+          gen_d2* To = reinterpret_cast<gen_d2*>(Tw + lane * 12);
+          if (is_j) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) To[i] = gen_d2{Tk[2 * i], Tk[2 * i + 1]};
+            jptr[lane] = pj;
+          }
+          gen_sync();
+          for (int r = 0; r < kin_rounds; ++r) {
+            const bool go = is_j && pj >= 0;
+            if (go) {
+              const gen_d2* Tp = reinterpret_cast<const gen_d2*>(Tw + pj * 12);
               const gen_d2 p0 = Tp[0], p1 = Tp[1], p2 = Tp[2], p3 = Tp[3], p4 = Tp[4], p5 = Tp[5];
+              pj = jptr[pj];
               const double Rp[9] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, p3.x, p3.y, p4.x};
               const double pp[3] = {p4.y, p5.x, p5.y};
+              double Tn[12];
 #pragma unroll
               for (int i = 0; i < 3; ++i) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) Tk[3 * i + j] = Rp[3 * i] * Lc[j] + Rp[3 * i + 1] * Lc[3 + j] + Rp[3 * i + 2] * Lc[6 + j];
-                Tk[9 + i] = Rp[3 * i] * Lc[9] + Rp[3 * i + 1] * Lc[10] + Rp[3 * i + 2] * Lc[11] + pp[i];
+                for (int j = 0; j < 3; ++j) Tn[3 * i + j] = Rp[3 * i] * Tk[j] + Rp[3 * i + 1] * Tk[3 + j] + Rp[3 * i + 2] * Tk[6 + j];
+                Tn[9 + i] = Rp[3 * i] * Tk[9] + Rp[3 * i + 1] * Tk[10] + Rp[3 * i + 2] * Tk[11] + pp[i];
               }
-            }
-            gen_d2* To = reinterpret_cast<gen_d2*>(Tw + lane * 12);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) To[i] = gen_d2{Tk[2 * i], Tk[2 * i + 1]};
+              for (int i = 0; i < 12; ++i) Tk[i] = Tn[i];
+            }
+            gen_sync();
+            if (go) {
+#pragma unroll
+              for (int i = 0; i < 6; ++i) To[i] = gen_d2{Tk[2 * i], Tk[2 * i + 1]};
+              jptr[lane] = pj;
+            }
+            gen_sync();
           }
-          gen_sync();
         }
         // world axis (R . M leaves the axis where R put it) and origin of the joint frame: the lane's own registers
 #pragma unroll
@@ -562,21 +597,22 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
             for (int i = 0; i < 3; ++i) {
               const double ad = fabs(r[i]);
               const bool in = ad < beta;
-              fpart += (in ? 0.5 * r[i] * r[i] / beta : ad - 0.5 * beta) * inv_norm;
-              tgv[i] = (in ? r[i] / beta : (r[i] > 0 ? 1.0 : (r[i] < 0 ? -1.0 : 0.0))) * inv_norm;
-              kk[i] = in ? inv_norm / beta : 0.0;
+              fpart += (in ? 0.5 * r[i] * r[i] * ibeta : ad - 0.5 * beta) * inv_norm;
+              tgv[i] = (in ? r[i] * ibeta : (r[i] > 0 ? 1.0 : (r[i] < 0 ? -1.0 : 0.0))) * inv_norm;
+              kk[i] = in ? inv_norm * ibeta : 0.0;
             }
           } else {  // SmoothL1 of the vector norm, weighted, mean over the V vectors (optimizer.py:262-273, 523-546)
             const double d = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
             const bool in = d < beta;
             const double w = my_wt;
-            fpart = w * (in ? 0.5 * d * d / beta : d - 0.5 * beta) * inv_norm;
-            const double psi = in ? d / beta : 1.0, kq = in ? 1.0 / beta : 0.0;
-            const double gc = d > 0 ? w * psi * inv_norm / d : 0.0;  // torch.norm backward: zero at 0
+            fpart = w * (in ? 0.5 * d * d * ibeta : d - 0.5 * beta) * inv_norm;
+            const double psi = in ? d * ibeta : 1.0, kq = in ? ibeta : 0.0;
+            const double id = d > 0 ? 1.0 / d : 0.0;
+            const double gc = w * psi * inv_norm * id;  // torch.norm backward: zero at 0
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
               tgv[i] = gc * r[i];
-              tuv[i] = d > 0 ? r[i] / d : 0.0;
+              tuv[i] = r[i] * id;
               kk[i] = gc;                // H_vec = c1 (I - u u^T) + c2 u u^T
             }
             kb = w * kq * inv_norm - gc;  // (c2 - c1)
@@ -603,51 +639,23 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
         for (int i = 0; i < NSLOT; ++i) hacc[i] = 0.0;
         double cf[3] = {0.0, 0.0, 0.0};  // lane k: CF_k (see below)
         double gacc = 0.0;               // gradient entry of the variable this lane writes columns for
-        // Entries of H owned by this lane += the contributions of one term: columns (and u . column) of the variables in `cb`
-        // (nv x 4), curvatures in the term's record.  position: sum_i k_i v_r[i] v_c[i]; vector kinds:
-        // c1 (v_r . v_c) + (c2 - c1) (u . v_r) (u . v_c).  The rows' columns are loaded once, the columns' stream through.
-        auto add_entries = [&](const double* cb, const double* rc, auto POS) {
-          const gen_d2* cb2 = reinterpret_cast<const gen_d2*>(cb);
-          const gen_d2 k01 = *reinterpret_cast<const gen_d2*>(rc + 12), k2b = *reinterpret_cast<const gen_d2*>(rc + 14);
-          gen_d2 Ra[NI], Rb[NI];
-#pragma unroll
-          for (int i = 0; i < NI; ++i) {
-            if (8 * i < nv) {  // wave-uniform
-              Ra[i] = cb2[2 * row_ld[i]];
-              Rb[i] = cb2[2 * row_ld[i] + 1];
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < NI; ++j) {
-            if (8 * j < nv) {
-              const gen_d2 ca = cb2[2 * col_ld[j]], cbv = cb2[2 * col_ld[j] + 1];
-              const double w0 = k01.x * ca.x, w1 = k01.y * ca.y, w2 = k2b.x * cbv.x, w3 = k2b.y * cbv.y;
-#pragma unroll
-              for (int i = j; i < NI; ++i) {
-                if (8 * i < nv) {
-                  double add = fma(Ra[i].x, w0, fma(Ra[i].y, w1, Rb[i].x * w2));
-                  if (!POS.value) add = fma(Rb[i].y, w3, add);
-                  hacc[i * (i + 1) / 2 + j] += add;
-                }
-              }
-            }
-          }
-        };
         // joint k's column of term t: a x (p - o) over the term's two frames (sign), or the axis (prismatic); p from the
         // term's record, a / o / the chain masks from the lane's registers
         auto joint_column = [&](int t, const double* rc, double (&c)[3]) {
           const gen_d2* r2 = reinterpret_cast<const gen_d2*>(rc);
           const gen_d2 q0 = r2[0], q1 = r2[1], q2 = r2[2], q3 = r2[3], q4 = r2[4];
           const double pt[3] = {q0.x, q0.y, q1.x}, po[3] = {q1.y, q2.x, q2.y}, tgv[3] = {q3.x, q3.y, q4.x};
-          const bool onT = (on_task >> t) & 1ull, onO = (on_origin >> t) & 1ull;
+          // on the task / origin chain of term t?  as 0.0 / 1.0 (t is wave-uniform: the half of the mask is picked with scalar code)
+          const unsigned wt_ = t < 32 ? (unsigned)on_task : (unsigned)(on_task >> 32), wo_ = t < 32 ? (unsigned)on_origin : (unsigned)(on_origin >> 32);
+          const double sT = (double)((wt_ >> (t & 31)) & 1u), sO = (double)((wo_ >> (t & 31)) & 1u);
           double dv[3];
 #pragma unroll
-          for (int i = 0; i < 3; ++i) dv[i] = (onT ? pt[i] - my_o[i] : 0.0) - (onO ? po[i] - my_o[i] : 0.0);
+          for (int i = 0; i < 3; ++i) dv[i] = sT * (pt[i] - my_o[i]) - sO * (po[i] - my_o[i]);
           c[0] = my_a[1] * dv[2] - my_a[2] * dv[1];
           c[1] = my_a[2] * dv[0] - my_a[0] * dv[2];
           c[2] = my_a[0] * dv[1] - my_a[1] * dv[0];
           if (any_prismatic) {  // wave-uniform
-            const double sg = (onT ? 1.0 : 0.0) - (onO ? 1.0 : 0.0);
+            const double sg = sT - sO;
 #pragma unroll
             for (int i = 0; i < 3; ++i) c[i] = my_rev ? c[i] : sg * my_a[i];
           }
@@ -658,7 +666,48 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
           cf[1] += c[2] * tgv[0] - c[0] * tgv[2];
           cf[2] += c[0] * tgv[1] - c[1] * tgv[0];
         };
-        auto term_loop = [&](auto POS) {
+        // Everything that touches the lane's tiles is instantiated for the number NA of tile rows the model has (ceil(nv / 8),
+        // rounded up to an instantiated value: tiles past the matrix load clamped rows and are never stored): no per-tile
+        // "is this row there" branches inside the term loop.
+        auto model = [&](auto POS, auto NA_) {
+          constexpr int NA = decltype(NA_)::value;
+          // The lane's tile bookkeeping is re-derived HERE from values the compiler cannot see through: left visible it
+          // hoists every per-slot address and "does this entry exist" mask out of the frame loop -- 45 values that do not
+          // fit, i.e. scratch reloads and v_readlane pairs on the write-out path of every assembly (measured: the stage
+          // doubled its time once eight waves shared a CU).
+          int gb_o = gb;
+          unsigned ok_lo = (unsigned)slot_ok, ok_hi = (unsigned)(slot_ok >> 32), rc_lo = (unsigned)so_rc, rc_hi = (unsigned)(so_rc >> 32),
+                   cr_lo = (unsigned)so_cr, cr_hi = (unsigned)(so_cr >> 32);
+          asm volatile("" : "+v"(gb_o), "+v"(ok_lo), "+v"(ok_hi), "+v"(rc_lo), "+v"(rc_hi), "+v"(cr_lo), "+v"(cr_hi));
+          const int dump_idx = min(lane, nj * 12 - 1);
+          auto slot_bit = [](unsigned lo, unsigned hi, int sl) -> unsigned { return ((sl < 32 ? lo : hi) >> (sl & 31)) & 1u; };
+          // Entries of H owned by this lane += the contributions of one term: columns (and u . column) of the variables in `cb`
+          // (nv x 4), curvatures in the term's record.  position: sum_i k_i v_r[i] v_c[i]; vector kinds:
+          // c1 (v_r . v_c) + (c2 - c1) (u . v_r) (u . v_c).  The rows' columns are loaded once, the columns' stream through.
+          auto add_entries = [&](const double* cb, const double* rc) {
+            const gen_d2* cb2 = reinterpret_cast<const gen_d2*>(cb);
+            const gen_d2 k01 = *reinterpret_cast<const gen_d2*>(rc + 12), k2b = *reinterpret_cast<const gen_d2*>(rc + 14);
+            gen_d2 Ra[NA], Rb[NA];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+              Ra[i] = cb2[2 * row_ld[i]];
+              Rb[i] = cb2[2 * row_ld[i] + 1];
+            }
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+              const gen_d2 ca = cb2[2 * col_ld[j]], cbv = cb2[2 * col_ld[j] + 1];
+              const double w0 = k01.x * ca.x, w1 = k01.y * ca.y, w2 = k2b.x * cbv.x, w3 = k2b.y * cbv.y;
+#pragma unroll
+              for (int i = j; i < NA; ++i) {
+                double h = hacc[i * (i + 1) / 2 + j];
+                h = fma(Ra[i].x, w0, h);
+                h = fma(Ra[i].y, w1, h);
+                h = fma(Rb[i].x, w2, h);
+                if (!POS.value) h = fma(Rb[i].y, w3, h);
+                hacc[i * (i + 1) / 2 + j] = h;
+              }
+            }
+          };
           if (no_mimic) {
             // every variable drives exactly one joint: lane k writes its variable's column record itself.  Terms in PAIRS:
             // both terms' columns are published (colA, colB) before either is read
@@ -684,8 +733,8 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
                 if (two) own_column(t + 1, colB);
               }
               gen_sync();
-              add_entries(colA, rec + t * 16, POS);
-              if (two) add_entries(colB, rec + (t + 1) * 16, POS);
+              add_entries(colA, rec + t * 16);
+              if (two) add_entries(colB, rec + (t + 1) * 16);
               gen_sync();
             }
           } else {
@@ -713,71 +762,78 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
                 o[1] = gen_d2{c[2], u};
               }
               gen_sync();
-              add_entries(colA, rc, POS);
+              add_entries(colA, rc);
               gen_sync();
             }
           }
-        };
-        if (pos) term_loop(std::true_type{});
-        else term_loop(std::false_type{});
-        // the gradient of the data term: one writer per variable
-        if (no_mimic) {
-          if (my_var >= 0) g[my_var] = gacc;
-        } else if (is_v) {
-          g[lane] = gacc;
-        }
-        GPROF_STAGE(2)  // term loop: columns, gradient, Hessian entries
-        // second-order kinematic term, second half: for every joint k that moves with a variable and every revolute
-        // ancestor-or-self j of k that does too,  H[var j][var k] += m_j m_k a_j . CF_k  (twice for j != k inside one
-        // family: both orders of the unordered pair).
-        if (kp.newton && no_mimic) {
-          // one joint per variable: lane k publishes m a_k and m CF_k under its variable, the owner of entry (r, c) forms its
-          // (at most two) contributions -- the joint of r moved with the joint of c as its ancestor, and the other way round
-          // (which of the two exist was worked out per slot when the kernel started)
-          if (my_var >= 0) {
-            gen_d2* oa = reinterpret_cast<gen_d2*>(colA + my_var * 4);
-            gen_d2* oc = reinterpret_cast<gen_d2*>(colB + my_var * 4);
-            oa[0] = gen_d2{my_jmul * my_a[0], my_jmul * my_a[1]};
-            oa[1] = gen_d2{my_jmul * my_a[2], 0.0};
-            oc[0] = gen_d2{my_jmul * cf[0], my_jmul * cf[1]};
-            oc[1] = gen_d2{my_jmul * cf[2], 0.0};
+          // the gradient of the data term: one writer per variable
+          if (no_mimic) {
+            if (my_var >= 0) g[my_var] = gacc;
+          } else if (is_v) {
+            g[lane] = gacc;
           }
-          gen_sync();
-          const gen_d2* A2 = reinterpret_cast<const gen_d2*>(colA);
-          const gen_d2* C2 = reinterpret_cast<const gen_d2*>(colB);
-          gen_d2 Ara[NI], Arb[NI], Cra[NI], Crb[NI];
+          GPROF_STAGE(2)  // term loop: columns, gradient, Hessian entries
+          // second-order kinematic term, second half: for every joint k that moves with a variable and every revolute
+          // ancestor-or-self j of k that does too,  H[var j][var k] += m_j m_k a_j . CF_k  (twice for j != k inside one
+          // family: both orders of the unordered pair).
+          if (kp.newton && no_mimic) {
+            // one joint per variable: lane k publishes m a_k and m CF_k under its variable, the owner of entry (r, c) forms
+            // its (at most two) contributions -- the joint of r moved with the joint of c as its ancestor, and the other way
+            // round (which of the two exist was worked out per slot when the kernel started)
+            if (my_var >= 0) {
+              gen_d2* oa = reinterpret_cast<gen_d2*>(colA + my_var * 4);
+              gen_d2* oc = reinterpret_cast<gen_d2*>(colB + my_var * 4);
+              oa[0] = gen_d2{my_jmul * my_a[0], my_jmul * my_a[1]};
+              oa[1] = gen_d2{my_jmul * my_a[2], 0.0};
+              oc[0] = gen_d2{my_jmul * cf[0], my_jmul * cf[1]};
+              oc[1] = gen_d2{my_jmul * cf[2], 0.0};
+            }
+            gen_sync();
+            const gen_d2* A2 = reinterpret_cast<const gen_d2*>(colA);
+            const gen_d2* C2 = reinterpret_cast<const gen_d2*>(colB);
+            gen_d2 Ara[NA], Arb[NA], Cra[NA], Crb[NA];
 #pragma unroll
-          for (int i = 0; i < NI; ++i) {
-            if (8 * i < nv) {
+            for (int i = 0; i < NA; ++i) {
               Ara[i] = A2[2 * row_ld[i]]; Arb[i] = A2[2 * row_ld[i] + 1];
               Cra[i] = C2[2 * row_ld[i]]; Crb[i] = C2[2 * row_ld[i] + 1];
             }
-          }
 #pragma unroll
-          for (int j = 0; j < NI; ++j) {
-            if (8 * j < nv) {
+            for (int j = 0; j < NA; ++j) {
               const gen_d2 Aca = A2[2 * col_ld[j]], Acb = A2[2 * col_ld[j] + 1], Cca = C2[2 * col_ld[j]], Ccb = C2[2 * col_ld[j] + 1];
 #pragma unroll
-              for (int i = j; i < NI; ++i) {
-                if (8 * i < nv) {
-                  const int sl = i * (i + 1) / 2 + j;
-                  const double v1 = Aca.x * Cra[i].x + Aca.y * Cra[i].y + Acb.x * Crb[i].x;  // a_c . CF_r
-                  const double v2 = Ara[i].x * Cca.x + Ara[i].y * Cca.y + Arb[i].x * Ccb.x;  // a_r . CF_c
-                  hacc[sl] += (((so_rc >> sl) & 1ull) ? v1 : 0.0) + (((so_cr >> sl) & 1ull) ? v2 : 0.0);
-                }
+              for (int i = j; i < NA; ++i) {
+                const int sl = i * (i + 1) / 2 + j;
+                const double v1 = Aca.x * Cra[i].x + Aca.y * Cra[i].y + Acb.x * Crb[i].x;  // a_c . CF_r
+                const double v2 = Ara[i].x * Cca.x + Ara[i].y * Cca.y + Arb[i].x * Ccb.x;  // a_r . CF_c
+                hacc[sl] = fma((double)slot_bit(rc_lo, rc_hi, sl), v1, fma((double)slot_bit(cr_lo, cr_hi, sl), v2, hacc[sl]));
               }
             }
           }
-        }
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
+          for (int i = 0; i < NA; ++i) {
 #pragma unroll
-          for (int j = 0; j <= i; ++j) {
-            const int sl = i * (i + 1) / 2 + j;
-            if (8 * i < nv && ((slot_ok >> sl) & 1ull)) H[GEN_TRI(ga + 8 * i, gb + 8 * j)] = hacc[sl];
+            for (int j = 0; j <= i; ++j) {
+              const int sl = i * (i + 1) / 2 + j;
+              // (entries that do not exist are dropped into the dead world transforms: an address select, no branch)
+              double* dst = slot_bit(ok_lo, ok_hi, sl) ? H + row_tri[i] + gb_o + 8 * j : Tw + dump_idx;
+              *dst = hacc[sl];
+            }
           }
-        }
-        gen_sync();
+          gen_sync();
+        };
+        auto with_rows = [&](auto POS) {
+          if constexpr (NI == GEN_NI_SMALL) {
+            if (nv <= 16) model(POS, std::integral_constant<int, 2>{});
+            else if (nv <= 32) model(POS, std::integral_constant<int, 4>{});
+            else model(POS, std::integral_constant<int, 5>{});
+          } else {
+            if (nv <= 48) model(POS, std::integral_constant<int, 6>{});
+            else if (nv <= 56) model(POS, std::integral_constant<int, 7>{});
+            else model(POS, std::integral_constant<int, 8>{});
+          }
+        };
+        if (pos) with_rows(std::true_type{});
+        else with_rows(std::false_type{});
         if (kp.newton && !no_mimic) {
           // families of several joints: one sweep over the joints per PASS -- lane j forms the entry of pair (j, k), lane v
           // sums its variable's family and adds into its own entries.  (Round 3 walked the chains of every TERM instead --
