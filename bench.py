@@ -761,14 +761,23 @@ def gather_records(timed_fn, comm, B, n_cols, dev, steps, warmup, world, graph_f
 
     # (1) the shards alone: no collective.  Its step time (maximum over the ranks: every rank derives the same k) decides how
     # many steps share one all-gather in the headline
-    e0, _ = timed_fn(None)
+    e0, kernel_ms0 = timed_fn(None)
     k = steps_per_gather_for(e0 / steps * 1e3, B * n_cols * 4, world)
     while steps % k:
         k -= 1  # whole groups inside the timed region
     # (2) headline: one all-gather per k steps on the second stream (k = 1 whenever the solve hides a per-step gather: every
-    # workload but the 47 us Allegro step at N >= 4; with one rank always 1)
-    elapsed, kernel_ms = timed_fn(NativeGather(comm, B, n_cols, dev, depth=depth if k == 1 else 2, overlap=True, steps_per_gather=k))
+    # workload but the 47 us Allegro step at N >= 4; with one rank always 1).  Under the watchdog as well: should the
+    # collective never complete across the ranks, the job ends with a line that carries the no-gather figure and says so
+    # -- labelled as what it is -- instead of the launcher's timeout and no line at all.
     rec = wd.done
+    if on_headline is not None:
+        fallback = on_headline(e0, kernel_ms0)
+        fallback["config"] = dict(fallback.get("config", {}), collective="NONE -- the all-gather did not complete (see multi_gpu.watchdog): "
+                                  "this line is the no-gather figure, not the metric's reassembled result")
+        wd.line = fallback
+    wd.arm("headline_all_gather")
+    elapsed, kernel_ms = timed_fn(NativeGather(comm, B, n_cols, dev, depth=depth if k == 1 else 2, overlap=True, steps_per_gather=k))
+    wd.disarm()
     rec.update({
         "collective": f"dexr_allgather (C-ABI of libdexr.so -> RCCL ncclAllGather, bound with dlopen): ONE per {k} step(s) "
                       f"({k} x {shard_mb:.2f} MB per rank), enqueued on a second HIP stream behind an event recorded after the "
