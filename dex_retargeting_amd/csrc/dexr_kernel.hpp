@@ -167,6 +167,7 @@ template <typename real> struct RealTraits;
 template <> struct RealTraits<float> {
   static __device__ __forceinline__ float rsqrt(float v) { return __frsqrt_rn(v); }
   static __device__ __forceinline__ float sqrt(float v) { return __fsqrt_rn(v); }
+  static __device__ __forceinline__ float div(float a, float b) { return a / b; }
   // sin/cos for joint angles (|a| <~ 1e3 rad): 2-term Cody-Waite reduction by pi/2 (the third term, 5.4e-15 k, is
   // below float32 resolution of the reduced argument here) + degree-7/8 minimax polynomials on [-pi/4, pi/4]; ~1 ulp,
   // no scratch, no slow path (ocml's sincosf carries a Payne-Hanek fallback that costs ~100 VGPRs and private memory
@@ -189,8 +190,22 @@ template <> struct RealTraits<float> {
   static __device__ __forceinline__ float clamp(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 };
 template <> struct RealTraits<double> {
-  static __device__ __forceinline__ double rsqrt(double v) { return 1.0 / ::sqrt(v); }
-  static __device__ __forceinline__ double sqrt(double v) { return ::sqrt(v); }
+  // 1 / sqrt(v), sqrt(v), a / b from the hardware estimates (v_rsq_f64 / v_rcp_f64, ~26 bits) + two Newton steps: full double
+  // precision to an ulp or two for the well-scaled arguments of the solver (pivots of a damped Hessian, residual norms,
+  // step lengths) in ~10 instructions, where a correctly rounded ::sqrt followed by an IEEE division is ~50 -- four times per
+  // pass in the Cholesky factorisation alone (round 4: the float64 tip pass spent a sixth of its instructions there)
+  static __device__ __forceinline__ double rsqrt(double v) {
+    double r = __builtin_amdgcn_rsq(v);
+    r = r * fma(-0.5 * v * r, r, 1.5);
+    return r * fma(-0.5 * v * r, r, 1.5);
+  }
+  static __device__ __forceinline__ double sqrt(double v) { return v > 0.0 ? v * rsqrt(v) : 0.0; }
+  static __device__ __forceinline__ double div(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = r * fma(-b, r, 2.0);
+    r = r * fma(-b, r, 2.0);
+    return a * r;
+  }
   static __device__ __forceinline__ void sincos(double a, double* s, double* c) { ::sincos(a, s, c); }
   static __device__ __forceinline__ double eps() { return 1.1102230246251565e-16; }
   static __device__ __forceinline__ double clamp(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
@@ -994,7 +1009,7 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
             dd += d[k] * d[k];
           }
         // (a step from a modified factorisation -- negative curvature -- is stretched (up to 8 x) towards the trust radius, see dexr_red.hpp)
-        const real alpha = (k_step_cap > 0 && (dmax > k_step_cap || (!ok && dmax > (real)0))) ? fmin(k_step_cap / dmax, (real)8) : (real)1;
+        const real alpha = (k_step_cap > 0 && (dmax > k_step_cap || (!ok && dmax > (real)0))) ? fmin(RT::div(k_step_cap, dmax), (real)8) : (real)1;
         // predicted decrease of the damped model along alpha*d:  alpha (1 - alpha/2) (-g.d) + alpha^2/2 lam d.d
         pred = alpha * ((real)1 - (real)0.5 * alpha) * gd + (real)0.5 * alpha * alpha * lam * dd;
 #pragma unroll
@@ -1068,7 +1083,7 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
           accept = finite && ((Ft <= F) || below_floor);  // (a modified-Cholesky step is judged by the decrease alone)
           ++my_iters;
           if (accept) {
-            const real rho = (F - Ft) / fmax(pred, (real)1e-30);
+            const real rho = RT::div(F - Ft, fmax(pred, (real)1e-30));
             const real t = (real)2 * rho - (real)1;
             real shrink = below_floor ? (real)(1.0 / 3.0) : fmax((real)(1.0 / 3.0), (real)1 - t * t * t);
             if (k_lam_fastdec > 0 && rho > (real)0.9)

@@ -197,14 +197,18 @@ static __device__ __forceinline__ R tip_eval(const TipTabT<R>& tt, const R (&x)[
   const RR r[3] = {pt[0] - t0, pt[1] - t1, pt[2] - t2};
   // SmoothL1 of the vector norm (optimizer.py:272-273); 1-ulp v_sqrt / v_rcp
   const RR d2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-  RR d;
-  if constexpr (sizeof(R) == 4) d = __builtin_amdgcn_sqrtf(d2);
-  else d = ::sqrt(d2);
+  RR d, rs = 0;  // (float64: 1 / d from the hardware estimate + two Newton steps, d = d2 / d; see RealTraits<double>)
+  if constexpr (sizeof(R) == 4) {
+    d = __builtin_amdgcn_sqrtf(d2);
+  } else {
+    rs = RealTraits<double>::rsqrt(d2);
+    d = d2 > 0 ? d2 * rs : (RR)0;
+  }
   const bool quad = d < beta;
   const RR F = w * (quad ? (RR)0.5 * d2 * ibeta : d - (RR)0.5 * beta);
   RR id;  // d >= beta > 0 in the linear branch
   if constexpr (sizeof(R) == 4) id = quad ? ibeta : __builtin_amdgcn_rcpf(d);
-  else id = quad ? ibeta : (RR)1 / d;
+  else id = quad ? ibeta : rs;
   const RR psi = w * id;
   const RR fvec[3] = {psi * r[0], psi * r[1], psi * r[2]};
   const RR kap = quad ? (RR)0 : psi * id * id;
