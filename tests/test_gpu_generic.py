@@ -179,23 +179,25 @@ def test_general_kernel_sequence_mode_equals_frame_by_frame():
 
 
 @pytest.mark.parametrize("kind", ["position", "vector"])
-def test_a_46_variable_model_runs_on_the_64_variable_instantiation(tmp_path, kind):
-    """A 4-joint wrist + six chains of seven revolute joints: 46 variables in one component -- the general kernel's second instantiation (33
-    Hessian entries per lane in registers, 64 rows for the register factorisation, the factor transposed through LDS for
-    the backward substitution).  Solved to the oracle's minimum from near starts; objective closure == the oracle's."""
-    urdf = comb_hand_urdf(str(tmp_path / "comb_hand.urdf"))
-    cfg = comb_hand_config(urdf, kind)
+@pytest.mark.parametrize("fingers,joints", [(6, 7), (7, 7), (8, 7), (10, 6)])
+def test_models_of_46_to_64_variables_run_on_the_64_variable_instantiation(tmp_path, kind, fingers, joints):
+    """A 4-joint wrist + `fingers` chains of `joints` revolute joints: 46 / 53 / 60 / 64 variables in one component -- the
+    general kernel's second instantiation (8 x 8 lane grid with 6, 7 or 8 tile rows: up to 36 Hessian entries per lane in
+    registers, 64 rows for the register factorisation).  Solved to the oracle's minimum from near starts; objective
+    closure == the oracle's."""
+    urdf = comb_hand_urdf(str(tmp_path / "comb_hand.urdf"), fingers=fingers, joints=joints)
+    cfg = comb_hand_config(urdf, kind, fingers=fingers, joints=joints)
     seq = RetargetingConfig.from_dict(cfg).build()
     opt = seq.optimizer
     r = OracleRobot(urdf)
     if kind == "position":
         prob = OracleProblem(r, "position", None, target_link_names=cfg["target_link_names"])
-        prob.target_link_human_indices = np.arange(12)
+        prob.target_link_human_indices = np.arange(2 * fingers)
     else:
         prob = OracleProblem(r, "vector", None, target_origin_link_names=cfg["target_origin_link_names"],
                              target_task_link_names=cfg["target_task_link_names"], scaling=cfg["scaling_factor"])
         prob.target_link_human_indices = np.array(cfg["target_link_human_indices"])
-    assert opt.device_model().kernel()[0] == _lib.KERNEL_GENERAL and opt.opt_dof == 46
+    assert opt.device_model().kernel()[0] == _lib.KERNEL_GENERAL and opt.opt_dof == 4 + fingers * joints
     B = 64
     d = cases.reachable_set(prob, B, 0.03)
     q, info = opt.device_model().retarget(d["ref"], None, d["last"], want_info=True)
