@@ -977,7 +977,9 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
 #pragma unroll
         for (int k = 0; k < NMAX; ++k) {
           const bool isopt = (optmask >> k) & 1u;
-          const bool act = (S.x[k] <= (real)tbl.lo[k] && gs[k] > 0) || (S.x[k] >= (real)tbl.hi[k] && gs[k] < 0);
+          // (bitwise, not short-circuit: `&&` / `||` on lane-varying conditions compile to nested exec-mask branches -- 18
+          // scalar / branch instructions per joint here -- where four compares and three mask operations do)
+          const bool act = (bool)(((int)(S.x[k] <= (real)tbl.lo[k]) & (int)(gs[k] > 0)) | ((int)(S.x[k] >= (real)tbl.hi[k]) & (int)(gs[k] < 0)));
           if (isopt && !act) freemask |= 1u << k;
           S.g[k] = (isopt && !act) ? gs[k] : (real)0;
         }
@@ -1009,7 +1011,8 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
             dd += d[k] * d[k];
           }
         // (a step from a modified factorisation -- negative curvature -- is stretched (up to 8 x) towards the trust radius, see dexr_red.hpp)
-        const real alpha = (k_step_cap > 0 && (dmax > k_step_cap || (!ok && dmax > (real)0))) ? fmin(RT::div(k_step_cap, dmax), (real)8) : (real)1;
+        const bool cut = (bool)((int)(k_step_cap > 0) & ((int)(dmax > k_step_cap) | ((int)!ok & (int)(dmax > (real)0))));
+        const real alpha = cut ? fmin(RT::div(k_step_cap, dmax), (real)8) : (real)1;
         // predicted decrease of the damped model along alpha*d:  alpha (1 - alpha/2) (-g.d) + alpha^2/2 lam d.d
         pred = alpha * ((real)1 - (real)0.5 * alpha) * gd + (real)0.5 * alpha * alpha * lam * dd;
 #pragma unroll
@@ -1026,8 +1029,8 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
         // confirm it.  Take it and retire the frame one pass earlier.
         // Beyond 10 tol this is only trusted on the fast (quadratic) tail of a Newton iteration: the step must be at most a
         // tenth of the previous accepted one -- in a nearly flat valley steps shrink slowly and C s^2 is not small.
-        last_step = stepping && ok && smax < k_blind_tol && lam <= k_lam0 &&
-                    (smax < (real)10 * k_tol || smax < (real)0.1 * sprev);
+        last_step = (bool)((int)stepping & (int)ok & (int)(smax < k_blind_tol) & (int)(lam <= k_lam0) &
+                           ((int)(smax < (real)10 * k_tol) | (int)(smax < (real)0.1 * sprev)));
       }
 
       // (3) forward kinematics + fused value / gradient / Hessian at S.x
@@ -1058,7 +1061,7 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
       bool accept = false, finished = false;
       int status = ST_MAXITER;
       if (has) {
-        const bool finite = (Ft == Ft) && (smax == smax) && (fabs(Ft) < (real)1e30);
+        const bool finite = (bool)((int)(Ft == Ft) & (int)(smax == smax) & (int)(fabs(Ft) < (real)1e30));
         if (fresh) {
           accept = true;  // start point: adopt its model unconditionally
           fresh = false;
@@ -1079,24 +1082,24 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
           // below that cannot be verified, only trusted)
           const real noise = (real)16 * RT::eps() * fmax(fabs(F), (real)2e-3);
           // below the rounding floor of F the decrease test is meaningless: trust the (small) Newton step
-          const bool below_floor = ok && finite && (pred <= noise) && (smax < (real)1e-2);
-          accept = finite && ((Ft <= F) || below_floor);  // (a modified-Cholesky step is judged by the decrease alone)
+          const bool below_floor = (bool)((int)ok & (int)finite & (int)(pred <= noise) & (int)(smax < (real)1e-2));
+          accept = (bool)((int)finite & ((int)(Ft <= F) | (int)below_floor));  // (a modified-Cholesky step is judged by the decrease alone)
           ++my_iters;
           if (accept) {
             const real rho = RT::div(F - Ft, fmax(pred, (real)1e-30));
             const real t = (real)2 * rho - (real)1;
             real shrink = below_floor ? (real)(1.0 / 3.0) : fmax((real)(1.0 / 3.0), (real)1 - t * t * t);
-            if (k_lam_fastdec > 0 && rho > (real)0.9)
-              shrink = (k_lam_recover > 0 && nrej <= 2 && lam > (real)10 * k_lam0) ? k_lam_recover : k_lam_fastdec;
+            if ((bool)((int)(k_lam_fastdec > 0) & (int)(rho > (real)0.9)))
+              shrink = (bool)((int)(k_lam_recover > 0) & (int)(nrej <= 2) & (int)(lam > (real)10 * k_lam0)) ? k_lam_recover : k_lam_fastdec;
             lam = fmax(lam * shrink, (real)1e-9);
             nu = 2;
             F = Ft;
-            const bool stalled = below_floor && blind >= k_stall_from && smax > k_stall_ratio * sprev && smax < k_stall_cap * k_tol;
+            const bool stalled = (bool)((int)below_floor & (int)(blind >= k_stall_from) & (int)(smax > k_stall_ratio * sprev) & (int)(smax < k_stall_cap * k_tol));
             blind = below_floor ? blind + 1 : 0;
             sprev = smax;
             // a step below tol only means convergence when the damping is not what made it small (see dexr_big.hpp)
             const real lam_ok = fmax((real)2 * k_delta, (real)10 * k_lam0);
-            if ((smax < k_tol && lam <= lam_ok) || stalled || blind >= k_max_blind) {
+            if ((bool)(((int)(smax < k_tol) & (int)(lam <= lam_ok)) | (int)stalled | (int)(blind >= k_max_blind))) {
               finished = true;
               status = ST_CONVERGED;
             } else if (smax < k_tol) {
@@ -1121,12 +1124,12 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
               finished = true;
               status = finite ? ST_CONVERGED : ST_FALLBACK;
             }
-            if (finite && smax < k_tol) {  // rejected step below tol: converged at the rounding floor of F
+            if ((bool)((int)finite & (int)(smax < k_tol))) {  // rejected step below tol: converged at the rounding floor of F
               finished = true;
               status = ST_CONVERGED;
             }
           }
-          if (!finished && my_iters >= k_max_iter) finished = true;  // status stays ST_MAXITER
+          finished = (bool)((int)finished | (int)(my_iters >= k_max_iter));  // status stays ST_MAXITER
         }
       }
       WTRACE_PASS()

@@ -1236,9 +1236,10 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         take = true;
       } else {
         const double noise = (double)kp.floor_scale * fabs(F);
-        const bool finite = (Fe == Fe) && (smax == smax) && (fabs(Fe) < 1e30);
-        const bool below_floor = ok && finite && ((double)pred <= noise) && (smax < 1e-2f);
-        const bool accept = (ok || MODCHOL) && finite && ((Fe <= F) || below_floor);
+        // (bitwise, not short-circuit: `&&` / `||` on lane-varying conditions compile to nested exec-mask branches)
+        const bool finite = (bool)((int)(Fe == Fe) & (int)(smax == smax) & (int)(fabs(Fe) < 1e30));
+        const bool below_floor = (bool)((int)ok & (int)finite & (int)((double)pred <= noise) & (int)(smax < 1e-2f));
+        const bool accept = (bool)((int)(ok || MODCHOL) & (int)finite & ((int)(Fe <= F) | (int)below_floor));
         ++my_iters;
         pending = false;
         if (accept) {
@@ -1247,16 +1248,16 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
           float shrink = below_floor ? (1.f / 3.f) : fmaxf(1.f / 3.f, 1.f - tt * tt * tt);
           // (fast decay: the quick way back after a damping jump -- but only for the first few rejections of a solve: a frame
           // that keeps being rejected is cycling between a too small and a too large lambda, and the 1/3 rule damps that)
-          if (kp.lam_fastdec > 0 && rho > 0.9f && nrej <= kp.fastdec_max_rej) shrink = kp.lam_fastdec;
+          if ((bool)((int)(kp.lam_fastdec > 0) & (int)(rho > 0.9f) & (int)(nrej <= kp.fastdec_max_rej))) shrink = kp.lam_fastdec;
           lam = fmaxf(lam * shrink, 1e-9f);
           nu = 2.f;
           F = Fe;
           take = true;
-          const bool stalled = below_floor && blind >= kp.stall_from && smax > kp.stall_ratio * sprev && smax < kp.stall_cap * kp.tol;
+          const bool stalled = (bool)((int)below_floor & (int)(blind >= kp.stall_from) & (int)(smax > kp.stall_ratio * sprev) & (int)(smax < kp.stall_cap * kp.tol));
           blind = below_floor ? blind + 1 : 0;
           sprev = smax;
           const float lam_ok = fmaxf(2.f * delta, 10.f * kp.lam0);  // see dexr_quad.hpp
-          if ((smax < kp.tol && lam <= lam_ok) || stalled || blind >= kp.max_blind) {
+          if ((bool)(((int)(smax < kp.tol) & (int)(lam <= lam_ok)) | (int)stalled | (int)(blind >= kp.max_blind))) {
             done = true;
             status = ST_CONVERGED;
           } else if (smax < kp.tol) {
@@ -1274,12 +1275,12 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
             done = true;
             status = finite ? ST_CONVERGED : ST_FALLBACK;
           }
-          if ((ok || MODCHOL) && finite && smax < kp.tol) {
+          if ((bool)((int)(ok || MODCHOL) & (int)finite & (int)(smax < kp.tol))) {
             done = true;
             status = ST_CONVERGED;
           }
         }
-        if (!done && my_iters >= kp.max_iter) done = true;
+        done = (bool)((int)done | (int)(my_iters >= kp.max_iter));
       }
       if (take) {  // the evaluated point becomes the accepted point: keep its gradient and Hessian
 #pragma unroll
@@ -1301,8 +1302,8 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       for (int s = 0; s < NJ2; ++s) {
         const float2 bx = *reinterpret_cast<const float2*>(BOXw + 2 * (jin[s] ? jo_[s] : 0));
         const float ga = GVl[jin[s] ? jo_[s] : 0];
-        const bool act = (xacc[s] <= bx.x && ga > 0) || (xacc[s] >= bx.y && ga < 0);
-        fr[s] = jopt[s] && !act;
+        const bool act = (bool)(((int)(xacc[s] <= bx.x) & (int)(ga > 0)) | ((int)(xacc[s] >= bx.y) & (int)(ga < 0)));
+        fr[s] = (bool)((int)jopt[s] & (int)!act);
       }
       const unsigned long long b0 = __ballot(fr[0]);
       freemask = (uint32_t)((b0 >> (16 * slot)) & 0xFFFFull);
@@ -1331,11 +1332,12 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       if (retry) {
         float gdl = 0.f, ddl = 0.f;
 #pragma unroll
-        for (int s = 0; s < NJ2; ++s)
-          if (jin[s] && ((freemask >> jo_[s]) & 1u)) {
-            gdl -= GVl[jo_[s]] * dstep[s];
-            ddl += dstep[s] * dstep[s];
-          }
+        for (int s = 0; s < NJ2; ++s) {  // (selects, not branches: a joint slot that is not free contributes a zero step)
+          const int jg = jin[s] ? jo_[s] : 0;
+          const float ds = (bool)((int)jin[s] & (int)((freemask >> jg) & 1u)) ? dstep[s] : 0.f;
+          gdl -= GVl[jg] * ds;
+          ddl += ds * ds;
+        }
         const float gd = row_sum(gdl), dd = row_sum(ddl);
         keff = gd / fmaxf(dd, 1e-30f);
         ++my_iters;
@@ -1356,34 +1358,37 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     if (stepping) {
       ok = okf;
       float dmaxl = 0.f, gdl = 0.f, ddl = 0.f;
+      bool son[NJ2];
+      int sjg[NJ2];
 #pragma unroll
-      for (int s = 0; s < NJ2; ++s)
-        if (jin[s] && ((freemask >> jo_[s]) & 1u)) {
-          dmaxl = fmaxf(dmaxl, fabsf(dstep[s]));
-          gdl -= GVl[jo_[s]] * dstep[s];
-          ddl += dstep[s] * dstep[s];
-        }
+      for (int s = 0; s < NJ2; ++s) {
+        sjg[s] = jin[s] ? jo_[s] : 0;
+        son[s] = (bool)((int)jin[s] & (int)((freemask >> sjg[s]) & 1u));
+        const float ds = son[s] ? dstep[s] : 0.f;
+        dmaxl = fmaxf(dmaxl, fabsf(ds));
+        gdl -= GVl[sjg[s]] * ds;
+        ddl += ds * ds;
+      }
       const float dmax = row_max(dmaxl), gd = row_sum(gdl), dd = row_sum(ddl);
       // (MODCHOL: a step from a modified factorisation is stretched towards the trust radius, at most 8 x)
-      const float alpha = (kp.step_cap > 0 && (dmax > kp.step_cap || (MODCHOL && !okf && dmax > 0.f)))
+      const float alpha = (bool)((int)(kp.step_cap > 0) & ((int)(dmax > kp.step_cap) | ((int)MODCHOL & (int)!okf & (int)(dmax > 0.f))))
                               ? fminf(kp.step_cap / dmax, MODCHOL ? 8.f : 1e30f) : 1.f;
       WDIAG(if (alpha < 1.f) ++d_ncap;)
       pred = alpha * (1.f - 0.5f * alpha) * gd + 0.5f * alpha * alpha * lam * dd;
       keff = gd / fmaxf(dd, 1e-30f);
       float sl = 0.f;
 #pragma unroll
-      for (int s = 0; s < NJ2; ++s)
-        if (jin[s] && ((freemask >> jo_[s]) & 1u)) {
-          const float2 bx = *reinterpret_cast<const float2*>(BOXw + 2 * jo_[s]);
-          const float xt = fminf(fmaxf(xacc[s] + alpha * dstep[s], bx.x), bx.y);
-          sl = fmaxf(sl, fabsf(xt - xacc[s]));
-          xj[s] = xt;
-        }
+      for (int s = 0; s < NJ2; ++s) {
+        const float2 bx = *reinterpret_cast<const float2*>(BOXw + 2 * sjg[s]);
+        const float xt = fminf(fmaxf(xacc[s] + alpha * dstep[s], bx.x), bx.y);
+        sl = fmaxf(sl, son[s] ? fabsf(xt - xacc[s]) : 0.f);
+        xj[s] = son[s] ? xt : xj[s];
+      }
       smax = row_max(sl);
       pending = true;
       // (see dexr_quad.hpp: verified undamped model, tiny Newton step; beyond 10 tol only on the quadratic tail of the
       // iteration -- the step must be at most a tenth of the previous accepted one, as in the small-component kernel)
-      if (okf && smax < kp.blind_tol && lam <= kp.lam0 && (smax < 10.f * kp.tol || smax < 0.1f * sprev)) {
+      if ((bool)((int)okf & (int)(smax < kp.blind_tol) & (int)(lam <= kp.lam0) & ((int)(smax < 10.f * kp.tol) | (int)(smax < 0.1f * sprev)))) {
         ++my_iters;
         pending = false;
         done = true;
