@@ -1033,27 +1033,33 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
                            ((int)(smax < (real)10 * k_tol) | (int)(smax < (real)0.1 * sprev)));
       }
 
-      // (3) forward kinematics + fused value / gradient / Hessian at S.x
+      // (3) forward kinematics + fused value / gradient / Hessian at S.x -- unless every lane that still holds a frame is
+      // taking its blind last step: those lanes retire on the step alone (the objective there "could only confirm it"), so the
+      // wave's last pass, typically, needs no evaluation at all (skipped only when the caller did not ask for the final
+      // objective values, which would otherwise be those of the point before)
       SPROF_STAGE(1)
-      real Ft;
-      if constexpr (TIP) {
-        Ft = tip_eval<real>(tbl, S.x, T[lane], T[64 + lane], T[128 + lane], tip_beta, tip_ibeta, tip_w, tip_nw, S.g, S.H);
-        SPROF_STAGE(2)
-      } else {
-        S.fk(tb, nj, P, lane);
-        SPROF_STAGE(2)
-        Ft = S.template residuals<2>(tb, kp, nt, vmask, P, T, W, lane);
-        S.template fold_mimic<true>(tb, nj);
-      }
-      SPROF_STAGE(3)
-#pragma unroll
-      for (int k = 0; k < NMAX; ++k) {
-        if ((optmask >> k) & 1u) {
-          const real dx = S.x[k] - S.xl[k];
-          Ft += k_delta * dx * dx;
-          S.g[k] += (real)2 * k_delta * dx;
+      real Ft = F;
+      const bool need_eval = kp.fval != nullptr || __any(has && !last_step);  // wave-uniform
+      if (need_eval) {
+        if constexpr (TIP) {
+          Ft = tip_eval<real>(tbl, S.x, T[lane], T[64 + lane], T[128 + lane], tip_beta, tip_ibeta, tip_w, tip_nw, S.g, S.H);
+          SPROF_STAGE(2)
         } else {
-          S.g[k] = 0;
+          S.fk(tb, nj, P, lane);
+          SPROF_STAGE(2)
+          Ft = S.template residuals<2>(tb, kp, nt, vmask, P, T, W, lane);
+          S.template fold_mimic<true>(tb, nj);
+        }
+        SPROF_STAGE(3)
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k) {
+          if ((optmask >> k) & 1u) {
+            const real dx = S.x[k] - S.xl[k];
+            Ft += k_delta * dx * dx;
+            S.g[k] += (real)2 * k_delta * dx;
+          } else {
+            S.g[k] = 0;
+          }
         }
       }
 
