@@ -10,7 +10,7 @@ _TUNE = {"persist_from": int, "persist_occ": int, "qchunk": int, "resident_waves
          "floor_scale": float, "step_cap": float, "blind_tol_scale": float, "chain": int, "pivot_rule": int, "longest_first": int}
 _KERNEL = {"auto": _lib.KERNEL_AUTO, "register": _lib.KERNEL_REGISTER, "quad": _lib.KERNEL_QUAD, "lds": _lib.KERNEL_LDS,
            "reduced": _lib.KERNEL_REDUCED, "wide": _lib.KERNEL_WIDE}
-_OPTS = ("max_iter", "tol", "lambda0", "newton", "polish", "strict")
+_OPTS = {"max_iter": int, "tol": float, "lambda0": float, "newton": int, "polish": int, "strict": int}
 
 
 def apply(model, knobs: dict):
@@ -19,7 +19,7 @@ def apply(model, knobs: dict):
     if "kernel" in knobs:
         tk["kernel"] = _KERNEL[knobs["kernel"]]
     t = model.tune(**tk)
-    ok = {k: v for k, v in knobs.items() if k in _OPTS}
+    ok = {k: _OPTS[k](v) for k, v in knobs.items() if k in _OPTS}
     unknown = set(knobs) - set(tk) - set(ok) - {"kernel"}
     if unknown:
         raise KeyError(f"unknown knobs {sorted(unknown)}")

@@ -43,7 +43,9 @@ for path in sorted(glob.glob(os.path.join(cases.CONFIG_DIR, "*", "*.yml"))):
                            "reduced": _lib.KERNEL_REDUCED, "wide": _lib.KERNEL_WIDE}[KERNEL])
     if os.environ.get("DEXR_TOOL_KNOBS"):  # e.g. DEXR_TOOL_KNOBS="blind_tol_scale=100,step_cap=0.2": developer knobs (tools/_tune.py)
         import _tune
-        _tune.apply(model, dict(kv.split("=") for kv in os.environ["DEXR_TOOL_KNOBS"].split(",")))
+        _, OPTS = _tune.apply(model, dict(kv.split("=") for kv in os.environ["DEXR_TOOL_KNOBS"].split(",")))
+    else:
+        OPTS = None
     dex = prob.kind == "dexpilot"
     mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
     st = (lambda: np.zeros(B, np.uint32)) if dex else (lambda: None)
@@ -61,7 +63,7 @@ for path in sorted(glob.glob(os.path.join(cases.CONFIG_DIR, "*", "*.yml"))):
             t_st.zero_()
         model.retarget_dev(B, t_kp.data_ptr(), 0, t_last.data_ptr(), t_st.data_ptr() if dex else 0, t_q.data_ptr(),
                            status_ptr=t_status.data_ptr() if diag else 0, iters_ptr=t_it.data_ptr() if diag else 0,
-                           stream=s.cuda_stream, keypoints=True)
+                           stream=s.cuda_stream, keypoints=True, opts=OPTS)
 
     for _ in range(2):
         go()
