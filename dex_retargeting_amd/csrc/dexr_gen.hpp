@@ -164,7 +164,7 @@ __device__ __noinline__ bool gen_factor_solve(int lane, int nv, unsigned aH, uns
   const bool rowv = lane < nv;
   const unsigned long long held = __ballot(rowv && act[rowv ? lane : 0] != 0.0);  // bit v: variable v sits at a bound
   const bool a_r = !rowv || ((held >> lane) & 1ull);
-  const int base = lane * (lane + 1) / 2;
+  const int base = rowv ? lane * (lane + 1) / 2 : 0;  // (lanes beyond the matrix read row 0 and keep nothing)
   const gen_lds_f64* Hr = H + base;
   double L[NV];
   const double my_diag = a_r ? 1.0 : Hr[lane] + lam;
@@ -180,11 +180,10 @@ __device__ __noinline__ bool gen_factor_solve(int lane, int nv, unsigned aH, uns
     L[c] = v;
   }
   double rhs = (rowv && !a_r) ? -g[lane] : 0.0;
-  bool ok = true;
   gen_lds_f64* my_row = Lt + base;
 #pragma unroll
   for (int c = 0; c < NV; ++c) {
-    if (c < nv && ok) {  // wave-uniform
+    if (c < nv) {  // wave-uniform
       double acc = L[c];
       // row c of the factor so far: entries [0, nl) from the LDS copy (wave-uniform, contiguous: pairs where the address is
       // 16-byte aligned).  In the first columns the last two entries -- written one and two columns ago -- come from lane
@@ -209,9 +208,8 @@ __device__ __noinline__ bool gen_factor_solve(int lane, int nv, unsigned aH, uns
 #pragma unroll
       for (int k2 = nl; k2 < c; ++k2) acc = fma(-L[k2], gen_readlane(L[k2], c), acc);  // L[k2] of lane c = L[c][k2]
       const double d = gen_readlane(acc, c);
-      if (!(d > 0.0)) {
-        ok = false;
-      } else {
+      if (!(d > 0.0)) return false;  // (wave-uniform: d comes out of a scalar register)
+      {
         // 1 / sqrt(d): hardware estimate + two Newton steps (full double precision for the well-scaled pivots of a damped
         // Hessian; a correctly rounded sqrt and a division cost three times the instructions, once per column)
         double ip = __builtin_amdgcn_rsq(d);
@@ -224,7 +222,6 @@ __device__ __noinline__ bool gen_factor_solve(int lane, int nv, unsigned aH, uns
       }
     }
   }
-  if (!ok) return false;
   // 1 / L[lane][lane] from the diagonal the lane wrote (hardware estimate + two Newton steps)
   double invd = 0.0;
   if (rowv) {
@@ -602,12 +599,14 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
               kk[i] = in ? inv_norm * ibeta : 0.0;
             }
           } else {  // SmoothL1 of the vector norm, weighted, mean over the V vectors (optimizer.py:262-273, 523-546)
-            const double d = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+            // (norm, its reciprocal and the solver's divisions from v_rsq_f64 / v_rcp_f64 + two Newton steps: RealTraits<double>)
+            const double d2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+            const double id = d2 > 0 ? RealTraits<double>::rsqrt(d2) : 0.0;
+            const double d = d2 * id;
             const bool in = d < beta;
             const double w = my_wt;
             fpart = w * (in ? 0.5 * d * d * ibeta : d - 0.5 * beta) * inv_norm;
             const double psi = in ? d * ibeta : 1.0, kq = in ? ibeta : 0.0;
-            const double id = d > 0 ? 1.0 / d : 0.0;
             const double gc = w * psi * inv_norm * id;  // torch.norm backward: zero at 0
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -939,7 +938,7 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
             GPROF_STAGE(6)
             double sm = is_v ? fabs(s[lane]) : 0.0;
             sm = gen_wave_max(sm);
-            const double scale = (cap > 0 && sm > cap) ? cap / sm : 1.0;
+            const double scale = (cap > 0 && sm > cap) ? RealTraits<double>::div(cap, sm) : 1.0;
             double my_s = 0.0;
             if (is_v) {
               const double xn = fmin(fmax(x[lane] + scale * s[lane], my_lo), my_hi);
@@ -987,7 +986,7 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
           continue;
         }
         if (accept) {
-          const double rho = (F - Ft) / fmax(pred, 1e-300);
+          const double rho = RealTraits<double>::div(F - Ft, fmax(pred, 1e-300));
           const bool small = smax < tol || pred <= 1e-18 * fmax(F, 1e-30);
           if (is_v) x[lane] = xt[lane];
           gen_sync();
