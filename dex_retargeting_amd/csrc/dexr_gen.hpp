@@ -939,24 +939,35 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
             double sm = is_v ? fabs(s[lane]) : 0.0;
             sm = gen_wave_max(sm);
             const double scale = (cap > 0 && sm > cap) ? RealTraits<double>::div(cap, sm) : 1.0;
-            double my_s = 0.0;
+            double my_s = 0.0, my_d = 0.0;
+            bool clipped = false;
             if (is_v) {
-              const double xn = fmin(fmax(x[lane] + scale * s[lane], my_lo), my_hi);
+              my_d = s[lane];
+              const double xu = x[lane] + scale * my_d;
+              const double xn = fmin(fmax(xu, my_lo), my_hi);
+              clipped = xn != xu;
               xt[lane] = xn;
               my_s = xn - x[lane];
               s[lane] = my_s;
             }
             gen_sync();
-            // predicted decrease -(g . s + s^T H s / 2) with the TAKEN (scaled, clipped) step: lane r sums its own row's
-            // strictly-lower part, s^T H s = sum_r s_r (2 sum_{u<r} H_ru s_u + H_rr s_r)
+            // predicted decrease -(g . s + s^T H s / 2) of the TAKEN step s
             double pp = 0.0;
-            if (is_v) {
-              const double* Hr = H + GEN_TRI(lane, 0);
-              double hs = 0.0;
-              for (int u = 0; u < lane; ++u) hs += Hr[u] * s[u];
-              pp = -(g[lane] * my_s + 0.5 * my_s * (2.0 * hs + Hr[lane] * my_s));
+            if (!__any(clipped)) {  // wave-uniform
+              // no variable ran into its box: s = a d with (H_ff + lam I) d = -g_f, so the decrease follows from two sums --
+              // a (1 - a / 2) (-g . d) + a^2 lam |d|^2 / 2 (variables held at a bound have d = 0) -- without touching H
+              const double gd = gen_wave_sum(is_v ? -g[lane] * my_d : 0.0), dd = gen_wave_sum(my_d * my_d);
+              pred = scale * (1.0 - 0.5 * scale) * gd + 0.5 * scale * scale * lam * dd;
+            } else {
+              // clipped: lane r sums its own row's strictly-lower part, s^T H s = sum_r s_r (2 sum_{u<r} H_ru s_u + H_rr s_r)
+              if (is_v) {
+                const double* Hr = H + GEN_TRI(lane, 0);
+                double hs = 0.0;
+                for (int u = 0; u < lane; ++u) hs += Hr[u] * s[u];
+                pp = -(g[lane] * my_s + 0.5 * my_s * (2.0 * hs + Hr[lane] * my_s));
+              }
+              pred = gen_wave_sum(pp);
             }
-            pred = gen_wave_sum(pp);
             smax = gen_wave_max(fabs(my_s));
             GPROF_STAGE(7)  // step, predicted decrease
             if (lam <= (double)kp.lam0 && smax < (double)kp.blind_tol) {
