@@ -1359,6 +1359,36 @@ def test_tip_pass_agrees_with_the_table_driven_kernels(rel):
     assert np.percentile(e_tip, 99) < 2e-5 and np.percentile(e_tip, 99) < 2 * np.percentile(e_tab, 99) + 1e-6
 
 
+@pytest.mark.parametrize("rel", ["teleop/allegro_hand_right.yml", "teleop/ability_hand_right.yml"])
+def test_skipped_evaluation_of_an_all_blind_pass_is_invisible(rel):
+    """A pass of the small-component kernels in which every lane that still holds a frame takes its blind last step runs
+    no evaluation -- unless the caller asked for the final objective values.  Both ways: the same answers, statuses and
+    iteration counts, bit for bit (65 536 tracking frames: every wave ends on such a pass)."""
+    torch = pytest.importorskip("torch")
+    seq, prob = build(rel)
+    model = seq.optimizer.device_model()
+    B = 65536
+    kp = np.ascontiguousarray(cases.human_keypoints(B + 1, seed=cases.SEED))
+    mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
+    last = model.retarget(kp[:-1], None, mid, keypoints=True)
+    dev = torch.device("cuda:0")
+    t_kp, t_last = torch.from_numpy(kp[1:].copy()).to(dev), torch.from_numpy(last).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    got = []
+    for with_fval in (False, True):
+        q = torch.empty_like(t_last)
+        status = torch.zeros(B, dtype=torch.int32, device=dev)
+        iters = torch.zeros(B, dtype=torch.int32, device=dev)
+        fval = torch.zeros(B, dtype=torch.float32, device=dev)
+        model.retarget_dev(B, t_kp.data_ptr(), 0, t_last.data_ptr(), 0, q.data_ptr(), status_ptr=status.data_ptr(),
+                           iters_ptr=iters.data_ptr(), fval_ptr=fval.data_ptr() if with_fval else 0, stream=st, keypoints=True)
+        torch.cuda.synchronize()
+        got.append((q.cpu().numpy(), status.cpu().numpy(), iters.cpu().numpy()))
+    for a, b in zip(got[0], got[1]):
+        assert np.array_equal(a, b)
+    assert (got[0][1] == 0).all()
+
+
 @pytest.mark.parametrize("rel", ["teleop/allegro_hand_right.yml", "teleop/leap_hand_left.yml"])
 def test_float64_tip_pass_agrees_with_the_table_driven_float64_kernel_and_the_oracle(rel):
     """Round 4: float64 launches of the per-finger vector models (dexr_solve_options.precision = 1 -- the reference's own
