@@ -25,7 +25,9 @@ last_qpos = the solver's own answer for the neighbouring frame (b-1), i.e. the w
 * "multi_gpu":  (launched by torch.distributed.run) the same steps with the gather on the solve stream and replayed
                 from one captured HIP graph, RCCL version, an xGMI estimate;
 * "also":       the other two single-GPU BASELINE configs (Shadow DexPilot, LEAP position), each with its own
-                roofline / HBM traffic / parity block;
+                roofline / HBM traffic / parity block, and the mixed fleet;
+* "general_kernel": a model beyond the fixed-size tables (arm + Shadow hand URDF, 37 variables in one component, 21 rows)
+                on the general kernel, with its parity block;
 * "parity":     max |dq| against the float64 oracle on a subset, and the distance to the reference-as-configured
                 SLSQP answers (oracle/, checker only -- imported after every timed region).
 
@@ -571,6 +573,77 @@ def offline_multi_robot_check(rec, ctx, n_par=1024):
     return rec
 
 
+def general_kernel_measure(torch, dev, steps, warmup, B=65536):
+    """Sub-record `general_kernel`: a model beyond the fixed-size tables -- an arm + Shadow hand URDF with 6 dummy free
+    joints, position objective, 37 variables in one component, 21 reference rows (the reference accepts any URDF and any
+    number of links, optimizer.py:18-52) -- on the general kernel (csrc/dexr_gen.hpp: one wavefront per frame, float64).
+    Tracking workload like the headline's (human keypoints, warm start = the previous frame's solution).  Returns (record,
+    checker context); touches nothing under oracle/."""
+    import bench_data
+    from dex_retargeting_amd import _lib
+    from dex_retargeting_amd.retargeting_config import RetargetingConfig
+
+    seq = RetargetingConfig.from_dict(bench_data.arm_hand_position_config()).build()
+    model = seq.optimizer.device_model()
+    assert model.kernel()[0] == _lib.KERNEL_GENERAL
+    kp = bench_data.human_keypoints(B + 1)
+    mid = np.repeat(seq.joint_limits.mean(1)[None], B, 0).astype(np.float32)
+    last = model.retarget(np.ascontiguousarray(kp[:-1]), None, mid, keypoints=True)  # (untimed: the previous frame's answers)
+    t_kp, t_last = torch.from_numpy(np.ascontiguousarray(kp[1:])).to(dev), torch.from_numpy(last).to(dev)
+    out = torch.empty_like(t_last)
+    it = torch.zeros(B, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def go(diag=False):
+        model.retarget_dev(B, t_kp.data_ptr(), 0, t_last.data_ptr(), 0, out.data_ptr(), iters_ptr=it.data_ptr() if diag else 0,
+                           stream=stream.cuda_stream, keypoints=True)
+
+    for _ in range(max(1, warmup)):
+        go()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record(stream)
+    for _ in range(steps):
+        go()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms = float(e0.elapsed_time(e1)) / steps
+    go(diag=True)
+    torch.cuda.synchronize()
+    iters = it.cpu().numpy()
+    rec = {"workload": "arm + Shadow hand URDF (tests/urdf/arm_shadow_hand_right.urdf) + 6 dummy free joints, PositionOptimizer, "
+                       "21 reference rows: 37 variables in one component (generic tables)", "batch": B, "dtype": "f64",
+           "kernel": "dexr_gen_kernel (one wavefront per frame)", "value": B / (ms * 1e-3), "unit": "frames/s", "n_gpus": 1,
+           "ms_per_step": ms, "steps": steps, "solver": {"iters_mean": float(iters.mean()), "iters_max": int(iters.max())}}
+    n = 128
+    return rec, dict(kp=kp[1:n + 1], last=last[:n], q=out[:n].cpu().numpy())
+
+
+def general_kernel_check(rec, ctx):
+    """Checker: the first frames against the float64 oracle's minimiser from the same start (a frame that ends in another
+    local minimum is counted, with the objective comparison, like everywhere else)."""
+    import bench_data
+    from oracle import cases, solvers
+    from oracle.kin import OracleRobot
+    from oracle.objectives import OracleProblem
+
+    cfg = bench_data.arm_hand_position_config()
+    prob = OracleProblem(OracleRobot(bench_data.ARM_HAND_URDF, add_dummy_free_joints=True), "position", None,
+                         target_link_names=cfg["target_link_names"])
+    prob.target_link_human_indices = np.arange(21)
+    ref = np.ascontiguousarray(cases.ref_from_keypoints(prob, ctx["kp"]), dtype=np.float32)
+    want = solvers.solve_lm_batched(prob, ref, None, ctx["last"], newton=True, max_iter=100)
+    got, l64 = ctx["q"].astype(np.float64), ctx["last"].astype(np.float64)
+    dq = np.abs(got - want).max(1)
+    far = dq >= 1e-4
+    Fg, Fw = prob.total(got, ref, None, l64), prob.total(want, ref, None, l64)
+    rec["parity"] = {"subset": int(len(dq)), "max_abs_dq_rad_same_minimum": float(dq[~far].max()) if (~far).any() else None,
+                     "frac_within_1e-4": float((~far).mean()),
+                     "other_minimum": {"frames": int(far.sum()), "worse": int((Fg[far] > Fw[far] + 1e-9).sum())},
+                     "oracle": "float64 projected LM/Newton on F (oracle/solvers.py), same start"}
+    return rec
+
+
 def parity_block(wl, batch, q_gpu, n_par, n_slsqp):
     """Checker (oracle) section: max |dq| against the float64 oracle minimiser of F on the first n_par frames of
     `batch`, and the distance to the reference-as-configured SLSQP answers on the first n_slsqp."""
@@ -954,7 +1027,7 @@ def run_single(args):
                            "unit": "frames/s", "n_gpus": 1, "ms_per_step": e2 / args.steps * 1e3, "solver": d2,
                            "roofline": w2.roofline(k2, d2["iters_mean"]), "two_streams": ts2})
 
-    fleet_m, offline_m = None, None
+    fleet_m, offline_m, gen_m = None, None, None
     if rank == 0 and not args.headline_only and args.workload == "allegro_vector":
         try:  # BASELINE configs[4], the per-GPU slice: 1 048 576 / 8 frames of four robots in one batch
             import bench_fleet
@@ -966,6 +1039,10 @@ def run_single(args):
             offline_m = offline_multi_robot_measure(torch, dev)
         except Exception as e:
             offline_m = repr(e)
+        try:
+            gen_m = general_kernel_measure(torch, dev, min(args.steps, 5), min(args.warmup, 2))
+        except Exception as e:
+            gen_m = repr(e)
 
     if rank != 0:
         comm.close()
@@ -1016,6 +1093,11 @@ def run_single(args):
             out["offline_multi_robot"] = {"error": offline_m} if isinstance(offline_m, str) else offline_multi_robot_check(*offline_m)
         except Exception as e:
             out["offline_multi_robot"] = {"error": repr(e)}
+    if gen_m is not None:
+        try:
+            out["general_kernel"] = {"error": gen_m} if isinstance(gen_m, str) else general_kernel_check(*gen_m)
+        except Exception as e:
+            out["general_kernel"] = {"error": repr(e)}
 
     # ---- CPU baseline: the reference path as configured, on the host cores (oracle = checker code only) -------------
     if world == 1 and not args.no_cpu_baseline:

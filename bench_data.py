@@ -75,3 +75,19 @@ def world_tracks(B: int, T: int, seed: int = 5):
     hand = fixture[idx]                                                        # (T, B, 21, 3)
     kp = np.einsum("tbkj,bij->tbki", hand, Rw) + (p0[None] + vel[None] * np.arange(T)[:, None, None])[:, :, None, :]
     return kp.astype(np.float32), p0, q
+
+
+ARM_HAND_URDF = os.path.join(REPO, "tests", "urdf", "arm_shadow_hand_right.urdf")
+
+
+def arm_hand_position_config() -> dict:
+    """An arm + Shadow hand URDF with 6 dummy free joints under the position objective: 37 movable joints in ONE component,
+    21 reference rows (every MANO keypoint matched to a link) -- beyond the fixed-size tables (32 joints, 16 rows), served by
+    the general kernel (the same problem as tests/test_generic_tables.arm_hand_config("position"))."""
+    tips = ["thtip", "fftip", "mftip", "rftip", "lftip"]
+    mid = ["thmiddle", "ffmiddle", "mfmiddle", "rfmiddle", "lfmiddle"]
+    prox = ["thproximal", "ffproximal", "mfproximal", "rfproximal", "lfproximal"]
+    dist = ["thdistal", "ffdistal", "mfdistal", "rfdistal", "lfdistal"]
+    links = ["palm"] + [l for f in range(5) for l in (prox[f], mid[f], dist[f], tips[f])]
+    return dict(type="position", urdf_path=ARM_HAND_URDF, add_dummy_free_joint=True, target_link_names=links,
+                target_link_human_indices=list(range(21)), low_pass_alpha=1.0)
