@@ -256,7 +256,7 @@ int launch_quad(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
   if (qe != hipSuccess) return fail(DEXR_ERR_HIP, "queue reset failed: %s", hipGetErrorString(qe));
   dexr::launch_fn fn = dexr::find_quad_launcher(m->bucket);
   if (!fn) return fail(DEXR_ERR_UNSUPPORTED, "no quad kernel for bucket %d", m->bucket);
-  hipError_t e = fn(kp, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb + stage_bytes, st);
+  hipError_t e = fn(kp, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, st);
   if (e != hipSuccess) return fail(DEXR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
   return DEXR_OK;
 }
@@ -562,22 +562,6 @@ int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStr
   }
   const int64_t blocks = (waves + wpb - 1) / wpb;
   if (blocks > 0x7fffffffLL) return fail(DEXR_ERR_INVALID, "batch too large for one launch");
-  // Full-chip tile launches of the float32 tip kernel on raw keypoints: a tile's keypoint and last_qpos rows go through the
-  // block's LDS (KernelParams::stage_tile_bytes).  4 096 waves that each fetch 12 + 12 + 16 bytes per lane put ~190 cache-line
-  // requests per wave into the L1s in the launch's first microseconds -- that phase is bound by the number of requests, not
-  // by latency (touching the lines earlier made it slower) -- while the rows of a tile are 20 KB of contiguous memory.
-  size_t stage_bytes = 0;
-  if (tip_kernel && !f64 && !ext && kp.kpts && kp.qchunk == 0 && waves >= 4096 && kp.B % 64 == 0 && wpb % kp.n_comp == 0 &&
-      waves % wpb == 0 && kp.n_kp > 0) {
-    const size_t tile_bytes = (size_t)64 * ((size_t)kp.n_kp * 12 + (size_t)kp.n_opt * 4);
-    const bool aligned = (reinterpret_cast<uintptr_t>(kp.kpts) % 16 == 0) && (reinterpret_cast<uintptr_t>(kp.last) % 16 == 0) &&
-                         ((size_t)64 * kp.n_kp * 12) % 16 == 0 && tile_bytes % 16 == 0;
-    const size_t tiles_per_block = (size_t)(wpb / kp.n_comp);
-    if (aligned && tile_bytes / 16 <= (size_t)kp.n_comp * 64 * 5 && per_wave * wpb + tiles_per_block * tile_bytes <= 64 * 1024) {
-      kp.stage_tile_bytes = (int32_t)tile_bytes;
-      stage_bytes = tiles_per_block * tile_bytes;
-    }
-  }
   dexr::launch_fn fn = dexr::find_launcher(m->bucket, f64, mode, m->chain, ext, m->tip);
   if (!fn) return fail(DEXR_ERR_UNSUPPORTED, "no kernel for bucket %d / f64=%d / mode=%d", m->bucket, f64, mode);
 #ifdef DEXR_SMALL_PROF
@@ -605,7 +589,7 @@ int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStr
     kp.g64out = wtrace;
   }
 #endif
-  hipError_t e = fn(kp, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb + stage_bytes, st);
+  hipError_t e = fn(kp, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, st);
   if (e != hipSuccess) return fail(DEXR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
 #ifdef DEXR_WAVE_TRACE
   if (wtrace_on) {

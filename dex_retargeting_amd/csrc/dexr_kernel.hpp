@@ -98,10 +98,6 @@ struct KernelParams {
   int32_t T;                           // frames per sequence; 0 = independent frames (no clipping of `last`)
   int64_t seq_stride;                  // rows between consecutive frames of one sequence
   float clip_eps;
-  // Tip kernel, full-chip tile launches (dexr_api.hip sets it): the n_comp waves of a 64-frame tile copy the tile's keypoint
-  // and last_qpos rows into the block's LDS together (coalesced 16-byte loads) instead of each lane fetching its own 12 / 16
-  // bytes: a fifth of the L1 requests of the launch's first microseconds.  Bytes of LDS per tile, 0 = off.
-  int32_t stage_tile_bytes;
 };
 
 // Per-component side table of the sixteen-lanes-per-frame kernel (dexr_wide.hpp), derived from the component's table by
@@ -678,15 +674,6 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
   real* P = reinterpret_cast<real*>(lds_raw) + (size_t)wave_in_block * per_wave;
   real* T = P + 64 * 3 * kp.lds_frames;
   real* W = T + 64 * 3 * kp.lds_terms;
-  // (tip kernel, full-chip tile launches: the tile's keypoint and last_qpos rows staged in LDS, see KernelParams)
-  constexpr bool CAN_STAGE = TIP && sizeof(real) == 4 && !EXT;
-  const bool staged = CAN_STAGE && kp.stage_tile_bytes > 0;  // wave-uniform
-  // (address-space-3 pointers: through generic ones the compiler merges the staged and the global path into flat loads)
-  typedef __attribute__((address_space(3))) float lds_f32;
-  typedef __attribute__((address_space(3))) float4 lds_f32x4;
-  lds_f32* stage_kp = (lds_f32*)(lds_raw + (size_t)waves_per_block * per_wave * sizeof(real)) +
-                      (size_t)(CAN_STAGE && staged ? wave_in_block / kp.n_comp : 0) * (size_t)(kp.stage_tile_bytes / 4);
-  lds_f32* stage_last = stage_kp + 64 * kp.n_kp * 3;
 
   // `comps` is a separate __restrict__ kernel argument (not a struct member) so that the compiler may treat the
   // tables as invariant and read them with scalar loads
@@ -719,18 +706,7 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
   // one row of ref_value for frame `it`: either handed in directly or formed from raw hand keypoints as the callers
   // of the reference do (joint_pos[task] - joint_pos[origin] / joint_pos[idx], profile_online_retargeting.py:24-30)
   auto ref_row = [&](int64_t it, int row, float (&rv)[3]) {  // `it`: row of the input arrays
-    if (CAN_STAGE && staged) {
-      const lds_f32* a = stage_kp + ((it - tile * 64) * kp.n_kp + kp.h_task[row]) * 3;
-      const int o = kp.h_origin[row];
-      if (o >= 0) {
-        const lds_f32* b = stage_kp + ((it - tile * 64) * kp.n_kp + o) * 3;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) rv[i] = a[i] - b[i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) rv[i] = a[i];
-      }
-    } else if (kp.kpts) {
+    if (kp.kpts) {
       const float* a = kp.kpts + (it * kp.n_kp + kp.h_task[row]) * 3;
       const int o = kp.h_origin[row];
       if (o >= 0) {
@@ -776,9 +752,8 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
           if (MODE == MODE_EVAL) v = (real)kp.xin[it * kp.n_opt + api_of(k)];
           else if (carry) v = (real)(float)prev;  // the reference carries the float32 result (optimizer.py:99)
           else if (!TIP32 && kp.x0) v = (real)kp.x0[r0 * ld + api_of(k)];  // (float64 polish launches only)
-          else if (CAN_STAGE && staged) v = (real)stage_last[(r0 - tile * 64) * ld + api_of(k)];
           else v = (real)kp.last[r0 * ld + api_of(k)];
-          real l = carry ? v : (CAN_STAGE && staged) ? v : (real)kp.last[r0 * ld + api_of(k)];
+          real l = carry ? v : (real)kp.last[r0 * ld + api_of(k)];
           if (seq) {  // seq_retarget.py:118-120: last_qpos clipped to the joint limits before every solve
             const real lo_s = (real)tb.lo[k] + (real)kp.clip_eps, hi_s = (real)tb.hi[k] - (real)kp.clip_eps;
             l = fmin(fmax(l, lo_s), hi_s);
@@ -1238,34 +1213,9 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
         const int o = kp.h_origin[row];
         touch2 = kp.kpts[(r0 * kp.n_kp + (o >= 0 ? o : 0)) * 3];
       }
-      // Full-chip tile launches: the n_comp waves of a tile fetch its keypoint rows (64 x n_kp x 12 B, contiguous) and its
-      // last_qpos rows (64 x ld x 4 B) together with 16-byte loads -- issued here, written to LDS after the table set-up.
-      constexpr int STAGE_F4 = 5;  // 16-byte loads per lane: 64 frames x (21 x 12 + 64) B over 4 x 64 lanes = 4.94
-      float4 st4[STAGE_F4];
-      int st_n4k = 0, st_n4 = 0;
-      if (CAN_STAGE && staged) {
-        st_n4k = 64 * kp.n_kp * 3 / 4;       // float4s of the tile's keypoint rows
-        st_n4 = st_n4k + 64 * ld / 4;         // + of its last_qpos rows (stage_last follows stage_kp)
-        const float4* srck = reinterpret_cast<const float4*>(kp.kpts + tile * 64 * kp.n_kp * 3);
-        const float4* srcl = reinterpret_cast<const float4*>(kp.last + tile * 64 * ld);
-#pragma unroll
-        for (int j = 0; j < STAGE_F4; ++j) {
-          const int i = (j * kp.n_comp + comp) * 64 + lane;
-          st4[j] = i < st_n4k ? srck[i] : (i < st_n4 ? srcl[i - st_n4k] : make_float4(0.f, 0.f, 0.f, 0.f));
-        }
-      }
       TipTabT<real> tt;  // float32: every constant of the pass pinned in SGPRs (dexr_tip.hpp)
       tt.load(tb, tb.term_task[0], tb.term_origin[0], W + 64 * kp.lds_terms, lane);
       if (touch) asm volatile("" ::"v"(touch0), "v"(touch1), "v"(touch2));
-      if (CAN_STAGE && staged) {
-        lds_f32x4* dst = (lds_f32x4*)stage_kp;
-#pragma unroll
-        for (int j = 0; j < STAGE_F4; ++j) {
-          const int i = (j * kp.n_comp + comp) * 64 + lane;
-          if (i < st_n4) dst[i] = st4[j];
-        }
-        __syncthreads();
-      }
       run(tt);
     } else if constexpr (CHAIN) {
       LocalTab<NMAX> lt;  // tables in registers for the whole kernel (see LocalTab)

@@ -1359,34 +1359,6 @@ def test_tip_pass_agrees_with_the_table_driven_kernels(rel):
     assert np.percentile(e_tip, 99) < 2e-5 and np.percentile(e_tip, 99) < 2 * np.percentile(e_tab, 99) + 1e-6
 
 
-def test_staged_keypoint_rows_equal_per_lane_loads():
-    """Full-chip tile launches of the tip kernel copy a tile's keypoint and last_qpos rows into LDS with coalesced 16-byte
-    loads (KernelParams::stage_tile_bytes); a keypoint array that is not 16-byte aligned takes the per-lane loads instead.
-    Same frames through both: bitwise the same answers."""
-    torch = pytest.importorskip("torch")
-    seq, prob = build("teleop/allegro_hand_right.yml")
-    model = seq.optimizer.device_model()
-    B = 65536
-    kp = np.ascontiguousarray(cases.human_keypoints(B + 1, seed=cases.SEED))
-    mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
-    last = model.retarget(kp[:-1], None, mid, keypoints=True)
-    dev = torch.device("cuda:0")
-    flat = torch.zeros(B * 63 + 4, dtype=torch.float32, device=dev)
-    t_last = torch.from_numpy(last).to(dev)
-    st = torch.cuda.current_stream().cuda_stream
-    got = []
-    for shift in (0, 1):  # element offset of the keypoint array inside a 16-byte aligned allocation
-        flat[shift:shift + B * 63] = torch.from_numpy(kp[1:].reshape(-1)).to(dev)
-        assert (flat.data_ptr() + 4 * shift) % 16 == 4 * shift
-        q = torch.empty_like(t_last)
-        model.retarget_dev(B, flat.data_ptr() + 4 * shift, 0, t_last.data_ptr(), 0, q.data_ptr(), stream=st, keypoints=True)
-        torch.cuda.synchronize()
-        got.append(q.cpu().numpy())
-    assert np.array_equal(got[0], got[1])
-    ref = np.ascontiguousarray(cases.ref_from_keypoints(prob, kp[1:]), dtype=np.float32)
-    assert np.array_equal(got[0], model.retarget(ref, None, last))  # == the ref_value entry point (no keypoints at all)
-
-
 @pytest.mark.parametrize("rel", ["teleop/allegro_hand_right.yml", "teleop/ability_hand_right.yml"])
 def test_skipped_evaluation_of_an_all_blind_pass_is_invisible(rel):
     """A pass of the small-component kernels in which every lane that still holds a frame takes its blind last step runs
