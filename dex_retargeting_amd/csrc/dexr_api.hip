@@ -264,6 +264,9 @@ int launch_quad(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
 }  // namespace
 size_t dexr_fleet_ws_ints();
 hipError_t dexr_lpt_order_launch(int64_t B, const float* f0, const float* sum, float ratio, int32_t* key, int32_t* ws, hipStream_t st);
+hipError_t dexr_dexpilot_order_launch(int64_t B, const float* kpts, const float* ref, const uint32_t* state, int n_kp, int n_ref,
+                                      const int32_t* h_task, const int32_t* h_origin, int F, float project_dist, float escape_dist,
+                                      int32_t* key, int32_t* ws, hipStream_t st);
 namespace {
 
 // sixteen lanes per frame: four frames per wave, two waves per SIMD resident; persistent rows fed like the quads
@@ -327,12 +330,20 @@ int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st)
 // Shadow 1.91 -> 2.04 ms, LEAP 1.23 -> 1.53 ms at ratio 2.  Hence opt-in (dexr_tuning.longest_first = 1), off by default;
 // position models have no usable predictor at all (F(x0), |g|, first step, curvature: <= 45 % of the slow frames in the
 // top 20 %).
+// Round 4, second session: for DexPilot models the PROJECTION STATE predicts the slow frames better than F(x0) and costs
+// no screening launch (dexr_aux.hip: dexpilot_key_kernel -- "a projection bit changes in this frame": 3 % of the frames, 94 %
+// of those with >= 24 passes; "a projection is active": 14 % / 99.8 %): one elementwise kernel + the bucketing kernels
+// (~25 us) put those frames at the front of the index list.  That IS the default for DexPilot batches large enough for the
+// tail to matter (longest_first = -1: automatic; 0: never; 1: the F(x0) screening above; 2: the state keys at any size).
 int launch_wide(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
   const int want = m->tune.longest_first;
-  const int64_t in_flight = (int64_t)m->n_cu * 4 * 2 * 4;
   const bool plain = !kp.perm && !kp.bucket && kp.T == 0 && kp.n_comp == 1;
-  (void)in_flight;
-  const bool on = plain && want > 0;  // measured: not a win by default (see below), opt-in only
+  // (automatic: from 9 variables on -- measured on all 13 DexPilot configs, 65 536 frames: Shadow 1.35 -> 1.11 / 1.28 -> 1.07 ms,
+  // LEAP 0.90 -> 0.78 / 0.87 -> 0.78, Allegro 0.71 -> 0.60 / 0.63 -> 0.62, SVH 0.93 -> 0.77 / 1.13 -> 1.07; the six-variable
+  // Ability / Inspire hands lose 2-7 % to the ~25 us of ordering, their launches are not tail-bound)
+  const bool by_state = plain && kp.kind == DEXR_KIND_DEXPILOT &&
+                        (want == 2 || (want < 0 && kp.n_opt >= 9 && kp.B >= 4 * (int64_t)m->n_cu * 4 * 2 * 4));
+  const bool on = plain && (want == 1 || by_state);
   if (!on) return launch_wide_once(m, kp, st);
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
@@ -358,14 +369,21 @@ int launch_wide(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
   float* f0 = reinterpret_cast<float*>(base + 256);
   int32_t* key = reinterpret_cast<int32_t*>(base + 256 + B * sizeof(float));
   int32_t* ws = key + B;
-  HIP_TRY(hipMemsetAsync(sum, 0, 256, st));
-  dexr::KernelParams ks = kp;
-  ks.screen = f0;
-  ks.screen_sum = sum;
-  int rc = launch_wide_once(m, ks, st);
-  if (rc != DEXR_OK) return rc;
-  hipError_t e = dexr_lpt_order_launch(kp.B, f0, sum, 1.3f, key, ws, st);
-  if (e != hipSuccess) return fail(DEXR_ERR_HIP, "ordering kernels failed: %s", hipGetErrorString(e));
+  int rc = DEXR_OK;
+  if (by_state && want != 1) {
+    hipError_t e = dexr_dexpilot_order_launch(kp.B, kp.kpts, kp.ref, kp.state, kp.n_kp, kp.n_ref, kp.h_task, kp.h_origin, kp.num_fingers,
+                                              kp.project_dist, kp.escape_dist, key, ws, st);
+    if (e != hipSuccess) return fail(DEXR_ERR_HIP, "ordering kernels failed: %s", hipGetErrorString(e));
+  } else {
+    HIP_TRY(hipMemsetAsync(sum, 0, 256, st));
+    dexr::KernelParams ks = kp;
+    ks.screen = f0;
+    ks.screen_sum = sum;
+    rc = launch_wide_once(m, ks, st);
+    if (rc != DEXR_OK) return rc;
+    hipError_t e = dexr_lpt_order_launch(kp.B, f0, sum, 1.3f, key, ws, st);
+    if (e != hipSuccess) return fail(DEXR_ERR_HIP, "ordering kernels failed: %s", hipGetErrorString(e));
+  }
   kp.perm = ws + dexr_fleet_ws_ints();
   rc = launch_wide_once(m, kp, st);
   HIP_TRY(hipEventRecord(sl.done, st));
@@ -892,6 +910,9 @@ int dexr_prep_launch(int64_t B, const float* kp, const float* op9, float* out, f
 size_t dexr_fleet_ws_ints();
 hipError_t dexr_fleet_bucket_launch(int n_models, int64_t B, const int32_t* model_id, int32_t* ws, hipStream_t st);
 hipError_t dexr_lpt_order_launch(int64_t B, const float* f0, const float* sum, float ratio, int32_t* key, int32_t* ws, hipStream_t st);
+hipError_t dexr_dexpilot_order_launch(int64_t B, const float* kpts, const float* ref, const uint32_t* state, int n_kp, int n_ref,
+                                      const int32_t* h_task, const int32_t* h_origin, int F, float project_dist, float escape_dist,
+                                      int32_t* key, int32_t* ws, hipStream_t st);
 hipError_t dexr_seq_compose_launch(int64_t B, int T, int n_q, int n_opt, int n_fixed, const int32_t* kind,
                                    const int32_t* idx, const double* mult, const double* off, const float* qraw,
                                    const float* fixed, double alpha, int use_filter, int first_frame_initialises,
@@ -1074,7 +1095,7 @@ int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning) {
   if (t.kernel < DEXR_KERNEL_AUTO || t.kernel > DEXR_KERNEL_WIDE) return fail(DEXR_ERR_INVALID, "unknown kernel family %d", t.kernel);
   if (t.pivot_rule < -1 || t.pivot_rule > 1) return fail(DEXR_ERR_INVALID, "unknown pivot rule %d", t.pivot_rule);
   if (t.chain < 0 || t.chain > 2) return fail(DEXR_ERR_INVALID, "chain must be 0 (never), 1 (serial-chain kernel + tip pass) or 2 (serial-chain kernel)");
-  if (t.longest_first < -1 || t.longest_first > 1) return fail(DEXR_ERR_INVALID, "longest_first must be -1, 0 or 1");
+  if (t.longest_first < -1 || t.longest_first > 2) return fail(DEXR_ERR_INVALID, "longest_first must be -1, 0, 1 or 2");
   if (t.fork_streams < -1 || t.fork_streams > 1) return fail(DEXR_ERR_INVALID, "fork_streams must be -1, 0 or 1");
   if (t.persist_from < 0 || t.qchunk < 0 || t.persist_occ < 0 || t.resident_waves < 0 || t.max_blind < 0)
     return fail(DEXR_ERR_INVALID, "negative launch parameter");

@@ -114,6 +114,54 @@ __global__ void __launch_bounds__(256) lpt_key_kernel(const float* __restrict__ 
     key[b] = f0[b] > thr ? 0 : 1;
 }
 
+// Hard-frames-first keys of a DexPilot batch WITHOUT a screening launch (dexr_api.hip: launch_wide).  What makes a DexPilot
+// frame slow is the pinch projection (/root/reference/src/dex_retargeting/optimizer.py:462-508): a pair vector that is
+// projected carries a 200-400 x weight and a target of fixed length, and the frame in which a projection switches on or off
+// jumps to a different objective.  Measured on the tracking workload (tools/probe_pred.py, 65 536 frames): "a projection bit
+// changed in this frame" flags 3 % of the frames and holds 94 % of those that need >= 24 solver passes (87 % of >= 16); "any
+// projection active" flags 14 % and holds 99.8 % (94 %).  Both follow from the keypoints and the incoming state alone --
+// the pre-amble restated on one thread per frame, ~20 loads, no kinematics.  key 0: a bit changed; 1: some projection
+// active; 2: neither.
+struct DexKeyMap {
+  int32_t h_task[16], h_origin[16];  // keypoint indices of the first 16 reference rows (-1: the row is kp[h_task])
+};
+__global__ void __launch_bounds__(256) dexpilot_key_kernel(const float* __restrict__ kpts, const float* __restrict__ ref,
+                                                           const uint32_t* __restrict__ state, int64_t B, int n_kp, int n_ref,
+                                                           DexKeyMap map, int F, float project_dist, float escape_dist,
+                                                           int32_t* __restrict__ key) {
+  const int len_s1 = F - 1;
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x) {
+    auto dist_of = [&](int row) -> float {
+      float v[3];
+      if (kpts) {
+        const float* a = kpts + (b * n_kp + map.h_task[row]) * 3;
+        const int o = map.h_origin[row];
+        for (int i = 0; i < 3; ++i) v[i] = o >= 0 ? a[i] - kpts[(b * n_kp + o) * 3 + i] : a[i];
+      } else {
+        for (int i = 0; i < 3; ++i) v[i] = ref[(b * n_ref + row) * 3 + i];
+      }
+      return sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    };
+    const uint32_t st = state ? state[b] : 0u;
+    uint32_t nst = 0;
+    for (int i = 0; i < len_s1; ++i) {
+      const float d = dist_of(i);
+      bool on = (st >> i) & 1u;
+      if (d < project_dist) on = true;
+      if (d > escape_dist) on = false;
+      nst |= (on ? 1u : 0u) << i;
+    }
+    int idx = len_s1;
+    for (int a = 0; a < F - 2; ++a)
+      for (int b2 = a + 1; b2 < F - 1; ++b2) {
+        const bool on = ((nst >> b2) & 1u) && ((nst >> a) & 1u) && (dist_of(idx) <= 0.03f);
+        nst |= (on ? 1u : 0u) << idx;
+        ++idx;
+      }
+    key[b] = nst != st ? 0 : (nst != 0u ? 1 : 2);
+  }
+}
+
 struct ComposeMap {
   int32_t kind[DEXR_MAX_DOF];  // 0 target joint, 1 fixed joint, 2 mimic joint
   int32_t idx[DEXR_MAX_DOF];   // column of qpos_raw / column of fixed / source dof
@@ -192,6 +240,24 @@ hipError_t dexr_lpt_order_launch(int64_t B, const float* f0, const float* sum, f
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return dexr_fleet_bucket_launch(2, B, key, ws, st);
+}
+
+// DexPilot batches: keys from the projection state (dexpilot_key_kernel), then the index list through the bucketing kernels
+hipError_t dexr_dexpilot_order_launch(int64_t B, const float* kpts, const float* ref, const uint32_t* state, int n_kp, int n_ref,
+                                      const int32_t* h_task, const int32_t* h_origin, int F, float project_dist, float escape_dist,
+                                      int32_t* key, int32_t* ws, hipStream_t st) {
+  DexKeyMap map;
+  for (int i = 0; i < 16; ++i) {
+    map.h_task[i] = h_task[i];
+    map.h_origin[i] = h_origin[i];
+  }
+  const int64_t want = (B + 255) / 256;
+  const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  hipLaunchKernelGGL(dexpilot_key_kernel, dim3(blocks), dim3(256), 0, st, kpts, ref, state, B, n_kp, n_ref, map, F, project_dist,
+                     escape_dist, key);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return dexr_fleet_bucket_launch(3, B, key, ws, st);
 }
 
 hipError_t dexr_seq_compose_launch(int64_t B, int T, int n_q, int n_opt, int n_fixed, const int32_t* kind,

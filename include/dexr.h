@@ -90,10 +90,12 @@ typedef struct dexr_tuning {
                            the Rayleigh quotient of the failed step), 1 modified Cholesky (the pivot is reflected, the
                            step judged by the decrease and stretched to the trust radius; lam_jump scales mean diag H),
                            -1 measured policy (1 for DexPilot models with mimic joints)                             */
-  int32_t longest_first; /* sixteen-lane kernel, plain batches: a screening launch evaluates F at the start points, frames
-                           above 1.3 x the batch mean are solved first (a launch is otherwise bound by slow frames the
-                           queue hands out late).  1 on, 0 off, -1 measured policy (currently off: the screening costs
-                           more than the ordering gains with this predictor, see dexr_api.hip launch_wide)            */
+  int32_t longest_first; /* sixteen-lane kernel, plain batches: hard frames first (a launch is otherwise bound by slow frames
+                           the queue hands out late).  2: DexPilot models, keys from the projection state -- a projection
+                           bit changes in this frame / a projection is active / neither -- one elementwise kernel, no
+                           screening launch; 1: a screening launch evaluates F at the start points, frames above 1.3 x the
+                           batch mean are solved first (costs more than it gains, see dexr_api.hip launch_wide); 0 off;
+                           -1 measured policy: the state keys for DexPilot batches of >= 32 768 frames, else off      */
   float lam_recover;    /* small components: accepted step with rho > 0.9 while lambda > 10 lambda0 and at most two steps of
                            the solve were rejected (the damping a rejection raised is being taken back): lambda *=
                            lam_recover.  0 (default): lam_fastdec there too.  Measured at 0.003 (65 536 tracking frames):

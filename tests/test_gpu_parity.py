@@ -990,24 +990,28 @@ def test_sixteen_lane_variable_grid_agrees_with_the_reduced_variable_kernel(rel)
 
 
 def test_longest_first_ordering_changes_the_schedule_not_the_answers():
-    """dexr_tuning.longest_first: screening launch + device-side index list, hard frames first.  Every frame's
-    arithmetic is the same, so the answers are bitwise those of the plain launch."""
+    """dexr_tuning.longest_first: a device-side index list, hard frames first -- keys from a screening launch (1) or, for
+    DexPilot models, from the projection state (2; the default policy for batches of >= 32 768 frames).  Every frame's
+    arithmetic is the same, so answers, states and iteration counts are bitwise those of the plain launch."""
     seq, prob = build("teleop/shadow_hand_right_dexpilot.yml")
     model = seq.optimizer.device_model()
-    B = 20000
+    B = 40000
     kp = np.ascontiguousarray(cases.human_keypoints(B + 1, seed=cases.SEED))
     mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
-    last = model.retarget(kp[:-1], None, mid, state=np.zeros(B, np.uint32), keypoints=True)
+    st_prev = np.zeros(B, np.uint32)
+    last = model.retarget(kp[:-1], None, mid, state=st_prev, keypoints=True)  # (st_prev: the projection bits after frame t - 1)
     out = {}
-    for lf in (0, 1, 1):
+    for lf in (0, 1, 1, 2, 2, -1):
         model.tune(longest_first=lf)
-        st = np.zeros(B, np.uint32)
+        st = st_prev.copy()
         q, info = model.retarget(kp[1:], None, last, state=st, keypoints=True, want_info=True)
         assert (info["status"] == 0).all()
         out.setdefault(lf, []).append((q, st.copy(), info["iters"].copy()))
     model.tune(longest_first=-1)
-    for q, st, it in out[1]:
-        assert np.array_equal(q, out[0][0][0]) and np.array_equal(st, out[0][0][1]) and np.array_equal(it, out[0][0][2])
+    assert (out[0][0][1] != st_prev).any()  # (some projection bits do change in this frame: the keys are not all alike)
+    for lf in (1, 2, -1):
+        for q, st, it in out[lf]:
+            assert np.array_equal(q, out[0][0][0]) and np.array_equal(st, out[0][0][1]) and np.array_equal(it, out[0][0][2])
 
 
 @pytest.mark.parametrize("rel", ["teleop/allegro_hand_right.yml", "teleop/shadow_hand_right_dexpilot.yml"])
@@ -1050,7 +1054,7 @@ def test_launches_on_two_streams_do_not_interfere(rel):
 def test_tuning_rejects_unknown_values():
     seq, _ = build("teleop/shadow_hand_right_dexpilot.yml")
     model = seq.optimizer.device_model()
-    for bad in (dict(kernel=7), dict(pivot_rule=3), dict(longest_first=2), dict(lam_jump=-1.0), dict(chain=3)):
+    for bad in (dict(kernel=7), dict(pivot_rule=3), dict(longest_first=3), dict(lam_jump=-1.0), dict(chain=3)):
         with pytest.raises(_lib.DexrError):
             model.tune(**bad)
     model.tune(kernel=_lib.KERNEL_AUTO)
