@@ -263,6 +263,11 @@ int launch_quad(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
 
 }  // namespace
 size_t dexr_fleet_ws_ints();
+size_t dexr_fleet_order_ws_ints(int64_t B);
+hipError_t dexr_fleet_dexpilot_order_launch(int64_t B, const float* kpts, const uint32_t* state, const int32_t* perm, const int32_t* seg,
+                                            int n_kp, const int32_t* h_task, const int32_t* h_origin, int F, float project_dist,
+                                            float escape_dist, int32_t* xws, const int32_t** out_perm, const int32_t** out_seg,
+                                            hipStream_t st);
 hipError_t dexr_lpt_order_launch(int64_t B, const float* f0, const float* sum, float ratio, int32_t* key, int32_t* ws, hipStream_t st);
 hipError_t dexr_dexpilot_order_launch(int64_t B, const float* kpts, const float* ref, const uint32_t* state, int n_kp, int n_ref,
                                       const int32_t* h_task, const int32_t* h_origin, int F, float project_dist, float escape_dist,
@@ -1407,7 +1412,10 @@ ForkPool* fork_pool() {
 }
 }  // namespace
 
-size_t dexr_fleet_workspace_bytes(int64_t B) { return (dexr_fleet_ws_ints() + (size_t)(B > 0 ? B : 0)) * sizeof(int32_t); }
+// (the bucketing workspace + the index list + what ordering ONE DexPilot model's bucket hard-frames-first needs)
+size_t dexr_fleet_workspace_bytes(int64_t B) {
+  return (dexr_fleet_ws_ints() + (size_t)(B > 0 ? B : 0) + dexr_fleet_order_ws_ints(B)) * sizeof(int32_t);
+}
 
 int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, int64_t B, const int32_t* model_id,
                             const float* keypoints, const float* fixed, int32_t ld_fixed, const float* last, int32_t ld,
@@ -1464,7 +1472,7 @@ int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, i
   int n_heavy = 0;
   for (int i = 0; i < n_models; ++i) n_heavy += selected_family(models[i]) != FAM_REGISTER || models[i]->gen;
   const int light_slot = 0;  // stream slot 0 of the pool serves the light models (model 0's own slot is free: see below)
-  bool first_heavy_placed = false;
+  bool first_heavy_placed = false, ordered_one = false;
   for (int pass = 0; pass < 2 && rc_all == DEXR_OK; ++pass) {
     for (int i = 0; i < n_models; ++i) {
       const dexr_model* m = models[i];
@@ -1501,7 +1509,22 @@ int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, i
       kp.ld = ld;
       kp.perm = perm;
       kp.bucket = bucket + 2 * i;
-      int rc = launch(m, dexr::MODE_SOLVE, 0, kp, si);
+      int rc = DEXR_OK;
+      // The first heavy DexPilot model's bucket is walked hard frames first (keys from the projection state, like
+      // launch_wide's plain batches): its launch is the step's critical path and ends in the tail of exactly those frames.
+      if (!ordered_one && heavy && !m->gen && selected_family(m) == FAM_WIDE && m->h.kind == DEXR_KIND_DEXPILOT && m->h.n_opt >= 9 &&
+          m->tune.longest_first != 0 && B >= 4 * (int64_t)m->n_cu * 4 * 2 * 4) {
+        ordered_one = true;
+        const int32_t* operm = nullptr;
+        const int32_t* oseg = nullptr;
+        const hipError_t oe = dexr_fleet_dexpilot_order_launch(B, keypoints, state, perm, bucket + 2 * i, kp.n_kp, kp.h_task, kp.h_origin,
+                                                               kp.num_fingers, kp.project_dist, kp.escape_dist,
+                                                               ws + dexr_fleet_ws_ints() + B, &operm, &oseg, si);
+        if (oe != hipSuccess) rc = fail(DEXR_ERR_HIP, "fleet ordering kernels failed: %s", hipGetErrorString(oe));
+        kp.perm = operm;
+        kp.bucket = oseg;
+      }
+      if (rc == DEXR_OK) rc = launch(m, dexr::MODE_SOLVE, 0, kp, si);
       if (rc == DEXR_OK) rc = polish_launch(m, kp, opt, si);
       if (rc != DEXR_OK) {  // still join what has been forked, then report
         rc_all = rc;

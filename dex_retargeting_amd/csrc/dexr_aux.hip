@@ -162,6 +162,60 @@ __global__ void __launch_bounds__(256) dexpilot_key_kernel(const float* __restri
   }
 }
 
+// The same keys for ONE MODEL'S BUCKET of a fleet batch (positions [0, count) of its index-list segment; offset and count
+// are read from device memory, entries beyond the count get the "not a model" id the bucketing kernels skip), and the gather
+// that turns the partition of the POSITIONS into the model's hard-frames-first index list.
+__global__ void __launch_bounds__(256) fleet_segment_key_kernel(const float* __restrict__ kpts, const uint32_t* __restrict__ state,
+                                                                const int32_t* __restrict__ perm, const int32_t* __restrict__ seg,
+                                                                int64_t B, int n_kp, DexKeyMap map, int F, float project_dist,
+                                                                float escape_dist, int32_t* __restrict__ key) {
+  const int64_t off = seg[0], cnt = seg[1];
+  const int len_s1 = F - 1;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < B; p += (int64_t)gridDim.x * blockDim.x) {
+    if (p >= cnt) {
+      key[p] = -1;
+      continue;
+    }
+    const int64_t b = perm[off + p];
+    auto dist_of = [&](int row) -> float {
+      const float* a = kpts + (b * n_kp + map.h_task[row]) * 3;
+      const int o = map.h_origin[row];
+      float v[3];
+      for (int i = 0; i < 3; ++i) v[i] = o >= 0 ? a[i] - kpts[(b * n_kp + o) * 3 + i] : a[i];
+      return sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    };
+    const uint32_t st = state[b];
+    uint32_t nst = 0;
+    for (int i = 0; i < len_s1; ++i) {
+      const float d = dist_of(i);
+      bool on = (st >> i) & 1u;
+      if (d < project_dist) on = true;
+      if (d > escape_dist) on = false;
+      nst |= (on ? 1u : 0u) << i;
+    }
+    int idx = len_s1;
+    for (int a = 0; a < F - 2; ++a)
+      for (int b2 = a + 1; b2 < F - 1; ++b2) {
+        const bool on = ((nst >> b2) & 1u) && ((nst >> a) & 1u) && (dist_of(idx) <= 0.03f);
+        nst |= (on ? 1u : 0u) << idx;
+        ++idx;
+      }
+    key[p] = nst != st ? 0 : (nst != 0u ? 1 : 2);
+  }
+}
+
+__global__ void __launch_bounds__(256) fleet_segment_gather_kernel(const int32_t* __restrict__ perm, const int32_t* __restrict__ seg,
+                                                                   const int32_t* __restrict__ pos_sorted, int64_t B,
+                                                                   int32_t* __restrict__ out_perm, int32_t* __restrict__ out_seg) {
+  const int64_t off = seg[0], cnt = seg[1];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B && i < cnt; i += (int64_t)gridDim.x * blockDim.x)
+    out_perm[i] = perm[off + pos_sorted[i]];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out_seg[0] = 0;
+    out_seg[1] = (int32_t)cnt;
+  }
+}
+
 struct ComposeMap {
   int32_t kind[DEXR_MAX_DOF];  // 0 target joint, 1 fixed joint, 2 mimic joint
   int32_t idx[DEXR_MAX_DOF];   // column of qpos_raw / column of fixed / source dof
@@ -258,6 +312,37 @@ hipError_t dexr_dexpilot_order_launch(int64_t B, const float* kpts, const float*
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return dexr_fleet_bucket_launch(3, B, key, ws, st);
+}
+
+// One DexPilot model's bucket of a fleet batch, hard frames first: extra workspace (int32) = key[B] | bucketing workspace
+// (dexr_fleet_ws_ints() + B) | out_perm[B] | out_seg[2] -- dexr_fleet_order_ws_ints(B) in all
+size_t dexr_fleet_order_ws_ints(int64_t B) { return 3 * (size_t)(B > 0 ? B : 0) + dexr_fleet_ws_ints() + 4; }
+
+hipError_t dexr_fleet_dexpilot_order_launch(int64_t B, const float* kpts, const uint32_t* state, const int32_t* perm, const int32_t* seg,
+                                            int n_kp, const int32_t* h_task, const int32_t* h_origin, int F, float project_dist,
+                                            float escape_dist, int32_t* xws, const int32_t** out_perm, const int32_t** out_seg,
+                                            hipStream_t st) {
+  DexKeyMap map;
+  for (int i = 0; i < 16; ++i) {
+    map.h_task[i] = h_task[i];
+    map.h_origin[i] = h_origin[i];
+  }
+  int32_t* key = xws;
+  int32_t* ws2 = key + B;
+  int32_t* operm = ws2 + dexr_fleet_ws_ints() + B;
+  int32_t* oseg = operm + B;
+  const int64_t want = (B + 255) / 256;
+  const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  hipLaunchKernelGGL(fleet_segment_key_kernel, dim3(blocks), dim3(256), 0, st, kpts, state, perm, seg, B, n_kp, map, F, project_dist,
+                     escape_dist, key);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  e = dexr_fleet_bucket_launch(3, B, key, ws2, st);  // (positions beyond the bucket carry id -1: skipped)
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fleet_segment_gather_kernel, dim3(blocks), dim3(256), 0, st, perm, seg, ws2 + dexr_fleet_ws_ints(), B, operm, oseg);
+  *out_perm = operm;
+  *out_seg = oseg;
+  return hipGetLastError();
 }
 
 hipError_t dexr_seq_compose_launch(int64_t B, int T, int n_q, int n_opt, int n_fixed, const int32_t* kind,
