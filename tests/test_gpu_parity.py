@@ -692,8 +692,11 @@ def test_warm_start_places_the_wrist(require_gpu):
     assert pv.shape == (B, 6) and np.allclose(pv[:, :3], pos)
 
 
-def test_mixed_fleet_equals_per_model_calls():
-    """BASELINE.json config 5: Allegro + Shadow + LEAP + Ability frames interleaved in one batch."""
+@pytest.mark.parametrize("B", [2048, 40000])
+def test_mixed_fleet_equals_per_model_calls(B):
+    """BASELINE.json config 5: Allegro + Shadow + LEAP + Ability frames interleaved in one batch.  (From 32 768 frames on
+    the Shadow DexPilot bucket is walked hard frames first -- projection-state keys over its index-list segment: another
+    schedule, the same answers.)"""
     torch = pytest.importorskip("torch")
     from dex_retargeting_amd.fleet import MixedFleet
 
@@ -702,7 +705,6 @@ def test_mixed_fleet_equals_per_model_calls():
     builds = [build(r) for r in rels]
     opts = [b[0].optimizer for b in builds]
     fleet = MixedFleet(opts)
-    B = 2048
     rng = np.random.default_rng(3)
     mid = rng.integers(0, 4, B)
     kp = cases.human_keypoints(B, seed=9)
