@@ -30,13 +30,20 @@ res = pos[:, prob.target_idx] - ref.astype(np.float64) if hasattr(prob, "target_
 if res is None:  # the computed links are the target links, in order
     res = pos[:, : ref.shape[1]] - ref.astype(np.float64)
 ares = np.abs(res).reshape(B, -1)
-cands = {"F(x0)": f0, "max |residual|": ares.max(1), "coords in the linear zone": (ares > prob.huber_delta).sum(1).astype(float),
+lo, hi = prob.joint_limits[:, 0], prob.joint_limits[:, 1]
+at_bound = ((last <= lo + 2e-3) | (last >= hi - 2e-3)).sum(1).astype(float)
+tips = kp[1:, [4, 8, 12, 16, 20]]
+pair_min = np.min([np.linalg.norm(tips[:, i] - tips[:, j], axis=1) for i in range(5) for j in range(i)], axis=0)
+cands = {"joints of last_qpos at a limit (free)": at_bound, "-(min fingertip distance) (free)": -pair_min,
+         "hand openness: sum |tip| (free)": np.linalg.norm(tips, axis=2).sum(1), "-(hand openness) (free)": -np.linalg.norm(tips, axis=2).sum(1),
+         "|last - mid| (free)": np.abs(last - prob.joint_limits.mean(1)).sum(1),
+         "F(x0)": f0, "max |residual|": ares.max(1), "coords in the linear zone": (ares > prob.huber_delta).sum(1).astype(float),
          "|grad|": np.linalg.norm(g0, axis=1), "sum |residual|": ares.sum(1),
          "keypoint spread change": np.abs(np.linalg.norm(kp[1:], axis=2) - np.linalg.norm(kp[:-1], axis=2)).max(1)}
 print(f"# {rel}: B={B} iters mean {it.mean():.2f} max {it.max()}; it>=10: {(it >= 10).mean():.4f}, it>=14: {(it >= 14).mean():.4f}, it>=18: {(it >= 18).mean():.4f}")
 for name, v in cands.items():
     order = np.argsort(-v)
-    line = f"  {name:28s}"
+    line = f"  {name:40s}"
     for frac in (0.05, 0.15, 0.30):
         top = np.zeros(B, bool)
         top[order[: int(B * frac)]] = True
