@@ -49,3 +49,30 @@ for name, v in cands.items():
         top[order[: int(B * frac)]] = True
         line += f" | top {int(frac * 100):2d} %: " + " ".join(f"{((top & (it >= thr)).sum() / max(1, (it >= thr).sum())):.2f}" for thr in (10, 14, 18))
     print(line + "   (share of it>=10 / 14 / 18 caught)")
+
+# ---- what an ordering would buy: list scheduling of the frames on the kernel's resident rows (B / 8 rows, as 65 536 frames have
+# 8 192), a frame costs iters + 1 passes, a launch ends with its last row
+import heapq
+
+
+def makespan(order, rows):
+    h = [0] * rows
+    heapq.heapify(h)
+    end = 0
+    for b in order:
+        t = heapq.heappop(h) + int(it[b]) + 1
+        end = max(end, t)
+        heapq.heappush(h, t)
+    return end
+
+
+rows = max(64, B // 8)
+base = makespan(np.arange(B), rows)
+print(f"# list scheduling on {rows} rows, passes: natural order {base}; lower bound {max(int(np.ceil((it + 1).sum() / rows)), int(it.max()) + 1)}")
+for name in ("coords in the linear zone", "|grad|", "sum |residual|", "F(x0)"):
+    v = cands[name]
+    for frac in (0.05, 0.15):
+        first = np.argsort(-v)[: int(B * frac)]
+        rest = np.setdiff1d(np.arange(B), first, assume_unique=False)
+        print(f"   {name:28s} top {int(frac * 100):2d} % first: {makespan(np.concatenate([np.sort(first), rest]), rows)} passes ({makespan(np.concatenate([np.sort(first), rest]), rows) / base:.3f} x)")
+print(f"   perfect (longest first): {makespan(np.argsort(-it), rows)} passes")
