@@ -6,7 +6,7 @@ from dex_retargeting_amd.constants import DEFAULT_URDF_DIR
 from dex_retargeting_amd.retargeting_config import RetargetingConfig
 from oracle import cases
 RetargetingConfig.set_default_urdf_dir(str(DEFAULT_URDF_DIR))
-for rel in ("teleop/shadow_hand_right_dexpilot.yml", "teleop/leap_hand_left_dexpilot.yml", "teleop/allegro_hand_right_dexpilot.yml"):
+for rel in ("teleop/leap_hand_left_dexpilot.yml", "teleop/shadow_hand_right_dexpilot.yml"):
     B = 65536
     prob = cases.problem_from_config(rel)
     seq = RetargetingConfig.load_from_file(os.path.join(cases.CONFIG_DIR, rel)).build()
@@ -35,3 +35,16 @@ for rel in ("teleop/shadow_hand_right_dexpilot.yml", "teleop/leap_hand_left_dexp
     for thr in (16, 24):
         slow = it >= thr
         print(f"   top 5% by motion catches {((top & slow).sum() / max(1, slow.sum())):.3f} of it>={thr}")
+
+# ---- the slow frames the state keys MISS (last model of the loop above): what do they look like?
+tips = kp[1:, [4, 8, 12, 16, 20]].astype(np.float64)
+d_th = np.stack([np.linalg.norm(tips[:, 0] - tips[:, j], axis=1) for j in range(1, 5)], 1)  # thumb - finger distances
+d_min = d_th.min(1)
+d_prev = np.stack([np.linalg.norm(kp[:-1, 4] - kp[:-1, j], axis=1) for j in (8, 12, 16, 20)], 1).min(1)
+missed = (~anyproj) & (it >= 16)
+print(f"## missed by 'any projection active': {missed.sum()} frames with it>=16; their min thumb-finger distance: "
+      f"p10 {np.percentile(d_min[missed], 10):.3f} p50 {np.percentile(d_min[missed], 50):.3f} p90 {np.percentile(d_min[missed], 90):.3f} m "
+      f"(all frames: p10 {np.percentile(d_min, 10):.3f} p50 {np.percentile(d_min, 50):.3f})")
+for thr in (0.04, 0.05, 0.06, 0.08):
+    pred = anyproj | (d_min < thr)
+    print(f"   any projection | min distance < {thr:.2f}: flags {pred.mean():.3f}, catches {((pred & (it >= 16)).sum() / (it >= 16).sum()):.3f} of it>=16, {((pred & (it >= 24)).sum() / max(1, (it >= 24).sum())):.3f} of it>=24")
