@@ -750,6 +750,22 @@ def cgroup_cpu_max():
     return None
 
 
+def usable_cpus():
+    """CPUs this process can actually use together: min(affinity mask, cgroup quota / period) -- BASELINE.md section 3
+    asks for the core count usable, not the host's."""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cm = cgroup_cpu_max()
+    try:
+        parts = (cm or "").split()
+        if len(parts) == 2 and parts[0] != "max":
+            avail = max(1, min(avail, int(int(parts[0]) // int(parts[1]))))
+        elif len(parts) == 1 and int(parts[0]) > 0:  # cgroup v1 cfs_quota_us, period 100 ms by default
+            avail = max(1, min(avail, int(parts[0]) // 100000))
+    except ValueError:
+        pass
+    return avail
+
+
 def job_env(args):
     """(rank, local_rank, world, launched): read from the environment torch.distributed.run sets."""
     rank = int(os.environ.get("RANK", "0"))
@@ -794,7 +810,9 @@ class Watchdog:
                     line = dict(self.line)
                     line["multi_gpu"] = dict(self.done, watchdog=f"'{stage}' did not finish within {self.seconds:g} s; the "
                                                                  f"figures measured before it are reported, the job was ended")
-                    print(json.dumps(line), flush=True)
+                    import bench_line
+
+                    bench_line.emit(line)
                 os._exit(0)
 
 
@@ -1147,7 +1165,7 @@ def run_single(args):
                                                     f"(oracle/objectives.py): the figure rounds 1-2 reported"}
         # the same solve fanned over host processes (frames are independent): what the reference could do on this box
         avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        procs = int(os.environ.get("DEXR_CPU_PROCS", min(avail, 64)))
+        procs = int(os.environ.get("DEXR_CPU_PROCS", min(usable_cpus(), 64)))
         if procs > 1:
             from oracle import cases, cpu_worker
 
@@ -1156,12 +1174,15 @@ def run_single(args):
             res = cpu_worker.run_all_cores(wl.rel, full_ref, last_batch["host_last"], procs, per_proc)
             if res is not None:
                 out["cpu_baseline_all_cores"] = {
-                    "value": res[0] / res[1], "unit": "frames/s", "cores": res[2], "kind": "port",
+                    "value": res[0] / res[1], "unit": "frames/s", "cores": min(res[2], usable_cpus()), "processes": res[2],
+                    "kind": "port",
                     "sample": f"{res[0]} frames = {res[2]} processes x {per_proc} frames of the same workload (frame i mod "
                               f"{B} once the batch is exhausted), started together, same solver as cpu_baseline; "
                               f"{avail} CPUs in the process's affinity mask, cgroup cpu.max = {cgroup_cpu_max()!r} (a quota "
                               f"below the process count caps what the workers can use together)"}
-    print(json.dumps(out))
+    import bench_line
+
+    bench_line.emit(out)  # DETAIL lines + bench_detail.json, then the compact (<= 4 KB) contract line LAST
     if comm is not None:
         comm.close()
 

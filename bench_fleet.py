@@ -22,7 +22,9 @@ from bench import FLEET, HBM_PEAK_GBPS, N_BATCHES, WORKLOADS  # noqa: E402
 def run(args):
     m = fleet_measure(args)
     if m is not None:
-        print(json.dumps(fleet_check(*m, args)))
+        import bench_line
+
+        bench_line.emit(fleet_check(*m, args))
 
 
 def fleet_measure(args, batch=None, standalone=True):
