@@ -24,13 +24,7 @@ def pytest_sessionstart(session):
         _build.build_library(verbose=False)
 
 
-def gpu_available() -> bool:
-    try:
-        from dex_retargeting_amd import _lib
-
-        return _lib.load().dexr_device_count() > 0
-    except Exception:
-        return False
+from testutil import gpu_available  # noqa: E402,F401
 
 
 @pytest.fixture(scope="session")

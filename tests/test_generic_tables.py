@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import gen_interp as gi
-from conftest import REPO
+from testutil import REPO
 from dex_retargeting_amd import model_compiler as mc
 from dex_retargeting_amd.constants import DEFAULT_URDF_DIR
 from dex_retargeting_amd.retargeting_config import RetargetingConfig

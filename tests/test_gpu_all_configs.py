@@ -27,7 +27,7 @@ import numpy as np
 import pytest
 
 import oracle_jobs
-from conftest import REPO
+from testutil import REPO
 from dex_retargeting_amd.constants import DEFAULT_URDF_DIR
 from dex_retargeting_amd.retargeting_config import RetargetingConfig
 from oracle import cases

@@ -13,7 +13,7 @@ import tempfile
 import numpy as np
 import pytest
 
-from conftest import REPO
+from testutil import REPO
 from dex_retargeting_amd import model_compiler as mc
 from dex_retargeting_amd.constants import DEFAULT_URDF_DIR, HandType
 from dex_retargeting_amd.retargeting_config import RetargetingConfig
@@ -189,7 +189,7 @@ def test_warm_start_equals_reference(key, monkeypatch):
         T, _ = self.kin.frame_pose_and_local_jacobian(self._qpos[0], self.kin.body_of_frame_id(link_id))
         return T
 
-    from conftest import gpu_available
+    from testutil import gpu_available
     if not gpu_available():
         monkeypatch.setattr(robot_wrapper.RobotWrapper, "get_link_pose", host_pose)
     rel = key.replace("__", "/") + ".yml"
