@@ -1238,6 +1238,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=20000, help="frames of the workload timed on the host CPU")
     ap.add_argument("--nccl-algo", default=None, help="sets NCCL_ALGO before the RCCL communicator exists (e.g. Ring, Tree, Direct)")
     ap.add_argument("--nccl-proto", default=None, help="sets NCCL_PROTO (e.g. Simple, LL, LL128)")
+    ap.add_argument("--fleet-order", default="iid", choices=("iid", "sorted"),
+                    help="mixed_fleet: order of the global batch (sorted = by robot; ranks take 1/N of every robot either way)")
     ap.add_argument("--dry-run-launch", action="store_true",
                     help="launch + rendezvous plumbing only (no GPU work): used by the CPU tests of the N > 1 launcher")
     args = ap.parse_args()

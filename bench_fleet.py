@@ -39,6 +39,7 @@ def fleet_measure(args, batch=None, standalone=True):
     from dex_retargeting_amd.retargeting_config import RetargetingConfig
 
     from bench import gather_records, job_env  # noqa: F401
+    from dex_retargeting_amd.distributed import shard_by_model
 
     rank, local_rank, world, launched = job_env(args) if standalone else (0, int(os.environ.get("LOCAL_RANK", "0")), 1, False)
     torch.cuda.set_device(local_rank)
@@ -56,8 +57,16 @@ def fleet_measure(args, batch=None, standalone=True):
     seed = bench_data.SEED + 1000 * rank
     batches = []
     for j in range(N_BATCHES):
-        rng = np.random.default_rng(seed + 7 * j)
-        mid = rng.integers(0, len(FLEET), B).astype(np.int32)
+        # the GLOBAL batch of world x B frames (same ids on every rank); this rank's frames are its share under
+        # distributed.shard_by_model: 1/N of EVERY robot's frames, so a batch that arrives sorted by robot
+        # (--fleet-order sorted) loads the ranks exactly like an interleaved one.  world = 1: the identity.
+        rng = np.random.default_rng(bench_data.SEED + 7 * j)
+        mid_global = rng.integers(0, len(FLEET), world * B).astype(np.int32)
+        if getattr(args, "fleet_order", "iid") == "sorted":
+            mid_global = np.sort(mid_global)
+        mine = shard_by_model(mid_global, world, len(FLEET))[rank]
+        assert mine.size == B
+        mid = np.ascontiguousarray(mid_global[mine])
         kp = bench_data.human_keypoints(B + 1, seed=seed + 17 * j, offset=155 * j)
         t_mid = torch.from_numpy(mid).to(dev)
         start = np.zeros((B, fleet.n_max), np.float32)
@@ -135,9 +144,11 @@ def fleet_measure(args, batch=None, standalone=True):
         "value": world * B * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{WORKLOADS['mixed_fleet'][1]}; {B} frames/GPU, model id uniform at random per frame, "
-                               f"human-keypoint refs, warm start = previous frame's solution; {N_BATCHES} staged batches rotated",
-                   "models": FLEET, "batch_per_gpu": B,
+        "config": {"workload": f"{WORKLOADS['mixed_fleet'][1]}; {B} frames/GPU, model id uniform at random per frame"
+                               f"{' (global batch sorted by robot)' if getattr(args, 'fleet_order', 'iid') == 'sorted' else ''}, "
+                               f"ranks take 1/N of every robot's frames (shard_by_model), human-keypoint refs, warm start = previous frame's solution; {N_BATCHES} staged batches rotated",
+                   "models": FLEET, "batch_per_gpu": B, "fleet_order": getattr(args, "fleet_order", "iid"),
+                   "frames_per_model_this_rank": np.bincount(mid, minlength=len(FLEET)).tolist(),
                    "collective": "none" if coll is None else coll["collective"],
                    "rccl_world_size": None if coll is None else coll["rccl_world_size"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

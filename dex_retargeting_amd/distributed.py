@@ -28,6 +28,95 @@ def shard_bounds(B: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def shard_by_model(model_id, world: int, n_models: Optional[int] = None):
+    """Skew-proof partition of a mixed-fleet batch ("bucket by model id first, then slice each bucket
+    N ways"): every rank receives 1/N of EVERY model's frames, whatever the order of the batch.
+
+    A contiguous B/N slice (``shard_bounds``) is balanced only while model ids are spread evenly over the batch; a batch
+    sorted by robot would put all frames of the 24-DoF DexPilot model (10-20x the per-frame cost of a per-finger vector
+    model) on one or two ranks.  Here the frames of model m, in batch order, are cut into `world` contiguous balanced
+    runs; the rank that receives the first run rotates from model to model by the remainders handed out so far, so the
+    TOTAL number of frames per rank also differs by at most one.
+
+    Returns a list of `world` int64 index arrays (ascending batch positions; disjoint; their union is range(B)).  Pure
+    index arithmetic -- every rank computes the same partition from the same ids, nothing is exchanged."""
+    mid = np.asarray(model_id).astype(np.int64).ravel()
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    if mid.size and mid.min() < 0:
+        raise ValueError("model ids must be >= 0")
+    M = int(n_models) if n_models is not None else (int(mid.max()) + 1 if mid.size else 0)
+    if mid.size and mid.max() >= M:
+        raise ValueError(f"model id {int(mid.max())} outside [0, {M})")
+    parts = [[] for _ in range(world)]
+    rot = 0
+    order = np.argsort(mid, kind="stable")
+    counts = np.bincount(mid, minlength=M) if mid.size else np.zeros(M, np.int64)
+    start = 0
+    for m in range(M):
+        idx = order[start:start + int(counts[m])]  # positions of model m, ascending
+        start += int(counts[m])
+        for r in range(world):
+            lo, hi = shard_bounds(idx.size, r, world)
+            parts[(r + rot) % world].append(idx[lo:hi])
+        rot = (rot + idx.size % world) % world
+    return [np.sort(np.concatenate(p)) if p else np.zeros(0, np.int64) for p in parts]
+
+
+def unshard_by_model(full: np.ndarray, shards, B: int) -> np.ndarray:
+    """Inverse of the partition after an equal-slot all-gather: `full` is (world, per, ...) with rank r's rows in
+    full[r, :len(shards[r])] (the rest padding); returns the (B, ...) array in batch order."""
+    out = np.empty((B,) + tuple(full.shape[2:]), dtype=full.dtype)
+    seen = 0
+    for r, idx in enumerate(shards):
+        out[idx] = full[r, : idx.size]
+        seen += idx.size
+    if seen != B:
+        raise ValueError(f"shards cover {seen} of {B} frames")
+    return out
+
+
+class ShardedFleet:
+    """Mixed-fleet batch over N ranks: rank r solves ``shard_by_model(model_id, N)[r]`` (an equal share of every robot's
+    frames) and ONE all-gather reassembles the (B, n_max) rows and the DexPilot state words on every rank.
+
+    `solve(model_id, keypoints, last, state) -> (b, n_max) float32` is the per-shard fleet call (``MixedFleet.retarget``
+    on the GPU; the world-size-2 gloo tests inject a CPU interpreter of the same tables); `state` (uint32) is updated in
+    place.  `work(model_id) -> float` (optional) is recorded per call in ``last_work`` so a test / a bench can show the
+    solve work each rank received."""
+
+    def __init__(self, solve: Callable, n_max: int, device: str = "cpu", group=None, n_models: Optional[int] = None):
+        import torch.distributed as dist
+
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.dist, self.group, self.device, self.solve, self.n_max, self.n_models = dist, group, device, solve, n_max, n_models
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.last_shards = None
+
+    def retarget(self, model_id: np.ndarray, keypoints: np.ndarray, last: np.ndarray, state: Optional[np.ndarray] = None) -> np.ndarray:
+        import torch
+
+        B = int(model_id.shape[0])
+        shards = shard_by_model(model_id, self.world, self.n_models)
+        self.last_shards = shards
+        idx = shards[self.rank]
+        st = None if state is None else np.ascontiguousarray(state[idx])
+        q = self.solve(np.ascontiguousarray(model_id[idx]), np.ascontiguousarray(keypoints[idx]), np.ascontiguousarray(last[idx]), st)
+        per = max(1, -(-B // self.world))
+        mine = torch.zeros((per, self.n_max + 1), dtype=torch.float64, device=self.device)  # last column: the state word
+        if idx.size:
+            mine[: idx.size, : self.n_max] = torch.from_numpy(np.asarray(q, dtype=np.float64)).to(self.device)
+            if st is not None:
+                mine[: idx.size, self.n_max] = torch.from_numpy(st.astype(np.float64)).to(self.device)
+        full = torch.empty((self.world * per, self.n_max + 1), dtype=torch.float64, device=self.device)
+        self.dist.all_gather_into_tensor(full, mine, group=self.group)
+        full = unshard_by_model(full.cpu().numpy().reshape(self.world, per, self.n_max + 1), shards, B)
+        if state is not None:
+            state[:] = full[:, self.n_max].astype(np.uint32)
+        return full[:, : self.n_max].astype(np.float32)
+
+
 class ShardedRetargeter:
     """retarget(ref, fixed, last[, state]) -> full (B, n_opt) float32 on every rank.
 

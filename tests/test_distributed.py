@@ -350,3 +350,143 @@ def test_committed_bench_lines_follow_the_driver_contract():
         assert k in c
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
     assert lines["r03_bench_1rank_native_rccl.json"]["config"].get("rccl_world_size") == 1
+
+
+# ---- skew-proof fleet sharding ----------------------------------------------------
+FLEET_RELS = ("teleop/allegro_hand_right.yml", "teleop/leap_hand_right.yml")
+FLEET_COST = np.array([1.0, 20.0])  # relative per-frame solve cost used as "work" (a per-finger vector model vs a heavy one)
+
+
+def _fleet_tables():
+    if "fleet" not in _compiled:
+        from dex_retargeting_amd.constants import DEFAULT_URDF_DIR
+        from dex_retargeting_amd.retargeting_config import RetargetingConfig
+        from oracle import cases
+
+        RetargetingConfig.set_default_urdf_dir(str(DEFAULT_URDF_DIR))
+        out = []
+        for rel in FLEET_RELS:
+            seq = RetargetingConfig.load_from_file(os.path.join(cases.CONFIG_DIR, rel)).build()
+            out.append((seq.optimizer.compiled_model(), seq.joint_limits, np.asarray(seq.optimizer.target_link_human_indices)))
+        _compiled["fleet"] = out
+    return _compiled["fleet"]
+
+
+def _fleet_inputs(B, order):
+    from oracle import cases
+
+    tabs = _fleet_tables()
+    rng = np.random.default_rng(5)
+    mid = rng.integers(0, len(tabs), B).astype(np.int32)
+    if order == "sorted":
+        mid = np.sort(mid)  # a batch sorted by robot: contiguous slices would give rank 0 only model 0
+    kp = cases.human_keypoints(B, seed=3).astype(np.float32)
+    n_max = max(t[1].shape[0] for t in tabs)
+    last = np.zeros((B, n_max), np.float32)
+    for m, (_, lim, _) in enumerate(tabs):
+        sel = mid == m
+        last[sel, : lim.shape[0]] = rng.uniform(lim[:, 0], lim[:, 1], (int(sel.sum()), lim.shape[0]))
+    return mid, kp, last
+
+
+def _fleet_solve(mid, kp, last, state):
+    """Per-shard fleet solver on the CPU: every frame goes through the table interpreter of ITS model."""
+    import table_interp
+
+    tabs = _fleet_tables()
+    out = np.zeros_like(last, dtype=np.float32)
+    for m, (compiled, lim, hidx) in enumerate(tabs):
+        sel = np.nonzero(mid == m)[0]
+        if sel.size == 0:
+            continue
+        ref = (kp[sel][:, hidx[1]] - kp[sel][:, hidx[0]]).astype(np.float32)
+        out[sel, : lim.shape[0]] = table_interp.solve_vector(compiled, ref, last[sel, : lim.shape[0]], iters=2)
+    if state is not None:
+        state[:] = state * 2 + mid.astype(np.uint32)
+    return out
+
+
+def _fleet_worker(rank, world, port, B, order, out_dir):
+    import torch.distributed as dist
+
+    from dex_retargeting_amd.distributed import ShardedFleet
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    mid, kp, last = _fleet_inputs(B, order)
+    state = np.arange(B, dtype=np.uint32)
+    sf = ShardedFleet(_fleet_solve, last.shape[1], device="cpu", n_models=len(FLEET_RELS))
+    q = sf.retarget(mid, kp, last, state)
+    work = float(FLEET_COST[mid[sf.last_shards[rank]]].sum())
+    np.savez(os.path.join(out_dir, f"f{rank}.npz"), q=q, state=state, work=work, n=sf.last_shards[rank].size)
+    dist.destroy_process_group()
+
+
+def test_shard_by_model_balances_every_model_whatever_the_batch_order():
+    from dex_retargeting_amd.distributed import shard_by_model, unshard_by_model
+
+    rng = np.random.default_rng(0)
+    for B in (0, 1, 7, 1000, 131072):
+        for world in (1, 2, 3, 8):
+            for order in ("iid", "sorted", "one_model"):
+                mid = rng.integers(0, 4, B)
+                if order == "sorted":
+                    mid = np.sort(mid)
+                if order == "one_model":
+                    mid[:] = 2
+                sh = shard_by_model(mid, world, 4)
+                assert len(sh) == world
+                cat = np.concatenate(sh) if B else np.zeros(0, np.int64)
+                assert np.array_equal(np.sort(cat), np.arange(B))            # disjoint cover
+                assert all(np.all(np.diff(x) > 0) for x in sh if x.size > 1)  # ascending batch positions
+                sizes = [x.size for x in sh]
+                assert max(sizes) - min(sizes) <= 1                           # equal slots for the all-gather
+                for m in range(4):
+                    c = [int((mid[x] == m).sum()) for x in sh]
+                    assert max(c) - min(c) <= 1, (B, world, order, m, c)      # 1/N of EVERY model's frames
+                # reassembly is exact
+                per = max(1, -(-B // world))
+                full = np.full((world, per, 3), -1.0)
+                for r, x in enumerate(sh):
+                    full[r, : x.size] = np.stack([x, x * 2, mid[x]], 1) if x.size else np.zeros((0, 3))
+                back = unshard_by_model(full, sh, B)
+                assert np.array_equal(back[:, 0], np.arange(B)) and np.array_equal(back[:, 2], mid)
+    with pytest.raises(ValueError):
+        shard_by_model(np.array([0, 5]), 2, 4)
+    with pytest.raises(ValueError):
+        shard_by_model(np.array([0, -1]), 2)
+    # the contiguous split this replaces, on the same sorted batch: one rank gets all of the heavy model
+    mid = np.sort(rng.integers(0, 2, 4000))
+    lo, hi = shard_bounds(4000, 0, 2)
+    heavy_contig = [int((mid[a:b] == 1).sum()) for a, b in (shard_bounds(4000, r, 2) for r in range(2))]
+    heavy_by_model = [int((mid[x] == 1).sum()) for x in shard_by_model(mid, 2, 2)]
+    assert min(heavy_contig) == 0 and abs(heavy_by_model[0] - heavy_by_model[1]) <= 1
+
+
+@pytest.mark.parametrize("order", ["sorted", "iid"])
+def test_two_rank_gloo_fleet_sorted_by_robot_is_balanced_and_reassembled_exactly(tmp_path, order):
+    """A mixed-fleet batch SORTED BY ROBOT over two ranks: both ranks receive the same solve work (per-model frame counts
+    within one frame of each other, hence cost-weighted work within one heavy frame) and the all-gather reassembles,
+    in batch order, exactly the rows and state words a single process computes."""
+    import torch.multiprocessing as mp
+
+    B = 203
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_fleet_worker, args=(2, port, B, order, str(tmp_path)), nprocs=2, join=True)
+    mid, kp, last = _fleet_inputs(B, order)
+    st = np.arange(B, dtype=np.uint32)
+    want = _fleet_solve(mid, kp, last, st)
+    assert np.abs(want - last).max() > 1e-2  # real per-frame work was sharded
+    got = [np.load(os.path.join(str(tmp_path), f"f{r}.npz")) for r in range(2)]
+    for g in got:
+        assert np.array_equal(g["q"], want) and np.array_equal(g["state"], st)
+    assert abs(int(got[0]["n"]) - int(got[1]["n"])) <= 1
+    assert abs(float(got[0]["work"]) - float(got[1]["work"])) <= FLEET_COST.max() + FLEET_COST.min()
+    if order == "sorted":  # what contiguous B/N slices would have given the two ranks on this batch
+        contig = [float(FLEET_COST[mid[a:b]].sum()) for a, b in (shard_bounds(B, r, 2) for r in range(2))]
+        assert max(contig) / min(contig) > 3.0
