@@ -42,7 +42,7 @@ KERNEL_AUTO, KERNEL_REGISTER, KERNEL_QUAD, KERNEL_LDS, KERNEL_REDUCED, KERNEL_WI
 
 EXPORTS = ["dexr_last_error", "dexr_version", "dexr_device_count", "dexr_default_options", "dexr_model_create",
            "dexr_model_destroy", "dexr_model_info", "dexr_model_get_tuning", "dexr_model_set_tuning", "dexr_model_kernel",
-           "dexr_model_lane_plan",
+           "dexr_model_lane_plan", "dexr_model_reserve",
            "dexr_retarget_dev", "dexr_retarget_seq_dev", "dexr_seq_compose_dev", "dexr_fleet_workspace_bytes",
            "dexr_retarget_multi_dev", "dexr_retarget_multi", "dexr_retarget", "dexr_retarget_f64",
            "dexr_retarget_kp_dev", "dexr_retarget_kp", "dexr_eval", "dexr_fk", "dexr_mano_keypoints_dev",
@@ -82,6 +82,7 @@ def load() -> C.CDLL:
     lib.dexr_model_get_tuning.argtypes = [vp, C.POINTER(Tuning)]
     lib.dexr_model_set_tuning.argtypes = [vp, C.POINTER(Tuning)]
     lib.dexr_model_kernel.argtypes = [vp, i32p, i32p, i32p]
+    lib.dexr_model_reserve.argtypes = [vp, C.c_int64]
     lib.dexr_model_lane_plan.argtypes = [vp, C.c_int32, i32p, i32p, vp, vp]
     lib.dexr_retarget_dev.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, optp, vp]
     lib.dexr_retarget_seq_dev.argtypes = [vp, i64, C.c_int32, vp, C.c_int32, vp, vp, vp, vp, vp, C.c_float, optp, vp]
@@ -174,6 +175,11 @@ class Model:
             setattr(t, k, v)
         check(load().dexr_model_set_tuning(self._h, C.byref(t)))
         return t
+
+    def reserve(self, max_batch: int):
+        """Pre-allocate the lazily grown device workspaces for batches of up to `max_batch` frames (dexr_model_reserve):
+        afterwards no device-pointer entry point allocates or synchronises with the host."""
+        check(load().dexr_model_reserve(self._h, int(max_batch)))
 
     def kernel(self):
         """(family, bucket, chain) of the float32 solve kernel this handle launches."""

@@ -340,6 +340,23 @@ int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st)
 // of those with >= 24 passes; "a projection is active": 14 % / 99.8 %): one elementwise kernel + the bucketing kernels
 // (~25 us) put those frames at the front of the index list.  That IS the default for DexPilot batches large enough for the
 // tail to matter (longest_first = -1: automatic; 0: never; 1: the F(x0) screening above; 2: the state keys at any size).
+size_t lpt_slot_bytes(int64_t B) {
+  const size_t b = (size_t)B;
+  return 256 + b * sizeof(float) + b * sizeof(int32_t) + (dexr_fleet_ws_ints() + b) * sizeof(int32_t);
+}
+int lpt_slot_grow(dexr_model::LptSlot& sl, size_t bytes) {
+  if (sl.bytes >= bytes) return DEXR_OK;
+  if (sl.buf) {
+    if (sl.done) HIP_TRY(hipEventSynchronize(sl.done));
+    HIP_TRY(hipFree(sl.buf));
+    sl.buf = nullptr;
+    sl.bytes = 0;
+  }
+  HIP_TRY(hipMalloc(&sl.buf, bytes));
+  sl.bytes = bytes;
+  return DEXR_OK;
+}
+
 int launch_wide(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
   const int want = m->tune.longest_first;
   const bool plain = !kp.perm && !kp.bucket && kp.T == 0 && kp.n_comp == 1;
@@ -352,23 +369,18 @@ int launch_wide(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
   if (!on) return launch_wide_once(m, kp, st);
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
-    return launch_wide_once(m, kp, st);  // graph capture: no allocation / cross-stream fencing inside a captured region
+    return launch_wide_once(m, kp, st);  // graph capture: no allocation / cross-stream fencing inside a captured region --
+                                         // a captured graph runs the frames in natural order (same answers, the eager
+                                         // call's schedule is the faster one for tail-bound batches; documented in dexr.h)
   const size_t B = (size_t)kp.B;
-  const size_t ws_ints = dexr_fleet_ws_ints() + B;
-  const size_t bytes = 256 + B * sizeof(float) + B * sizeof(int32_t) + ws_ints * sizeof(int32_t);
+  const size_t bytes = lpt_slot_bytes(kp.B);
   dexr_model::LptSlot& sl = m->lpt[m->lnext.fetch_add(1u) % dexr_model::LSLOTS];
   if (!sl.done) HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
   else HIP_TRY(hipStreamWaitEvent(st, sl.done, 0));  // the slot's previous user (possibly another stream) has finished
-  if (sl.bytes < bytes) {
-    if (sl.buf) {
-      HIP_TRY(hipEventSynchronize(sl.done));
-      HIP_TRY(hipFree(sl.buf));
-      sl.buf = nullptr;
-      sl.bytes = 0;
-    }
-    HIP_TRY(hipMalloc(&sl.buf, bytes));
-    sl.bytes = bytes;
-  }
+  // A slot that dexr_model_reserve(B) sized is used as it is: no allocation, no host synchronisation on this path.  Without a
+  // reservation the slot grows here -- hipMalloc on the first ordered call, hipEventSynchronize + hipFree + hipMalloc when a
+  // larger batch arrives (the one place a `_dev` entry point may block; call dexr_model_reserve to rule it out).
+  { const int rc = lpt_slot_grow(sl, bytes); if (rc != DEXR_OK) return rc; }
   unsigned char* base = static_cast<unsigned char*>(sl.buf);
   float* sum = reinterpret_cast<float*>(base);
   float* f0 = reinterpret_cast<float*>(base + 256);
@@ -1090,6 +1102,21 @@ int dexr_model_get_tuning(const dexr_model* m, dexr_tuning* out) {
   return DEXR_OK;
 }
 
+int dexr_model_reserve(dexr_model* m, int64_t max_batch) {
+  if (!m) return fail(DEXR_ERR_INVALID, "null argument");
+  if (max_batch < 0) return fail(DEXR_ERR_INVALID, "negative batch");
+  // the hard-frames-first workspaces of the sixteen-lane kernel (launch_wide): every slot, sized for max_batch frames
+  if (!m->wide || m->gen) return DEXR_OK;
+  const size_t bytes = lpt_slot_bytes(max_batch);
+  for (int i = 0; i < dexr_model::LSLOTS; ++i) {
+    dexr_model::LptSlot& sl = m->lpt[i];
+    if (!sl.done) HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    const int rc = lpt_slot_grow(sl, bytes);
+    if (rc != DEXR_OK) return rc;
+  }
+  return DEXR_OK;
+}
+
 int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning) {
   if (!m || !tuning) return fail(DEXR_ERR_INVALID, "null argument");
   if (tuning->struct_size < sizeof(uint32_t) || tuning->struct_size > sizeof(dexr_tuning))
@@ -1512,8 +1539,13 @@ int dexr_retarget_multi_dev(const dexr_model* const* models, int32_t n_models, i
       int rc = DEXR_OK;
       // The first heavy DexPilot model's bucket is walked hard frames first (keys from the projection state, like
       // launch_wide's plain batches): its launch is the step's critical path and ends in the tail of exactly those frames.
+      // Gate: the host never learns the bucket sizes, so the model's share is ESTIMATED as an even split B / n_models
+      // -- a ~10 000-frame bucket of a 40 000-frame fleet does not pay ~25 us of key / bucketing / gather kernels for a launch
+      // that is not tail-bound; and only the state-key modes ask for it (longest_first -1: automatic, 2: always; 1 is the
+      // F(x0) screening mode of plain batches, 0 is off).
+      const int lf = m->tune.longest_first;
       if (!ordered_one && heavy && !m->gen && selected_family(m) == FAM_WIDE && m->h.kind == DEXR_KIND_DEXPILOT && m->h.n_opt >= 9 &&
-          m->tune.longest_first != 0 && B >= 4 * (int64_t)m->n_cu * 4 * 2 * 4) {
+          (lf == 2 || (lf < 0 && B / n_models >= 4 * (int64_t)m->n_cu * 4 * 2 * 4))) {
         ordered_one = true;
         const int32_t* operm = nullptr;
         const int32_t* oseg = nullptr;

@@ -601,7 +601,7 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
           } else {  // SmoothL1 of the vector norm, weighted, mean over the V vectors (optimizer.py:262-273, 523-546)
             // (norm, its reciprocal and the solver's divisions from v_rsq_f64 / v_rcp_f64 + two Newton steps: RealTraits<double>)
             const double d2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-            const double id = d2 > 0 ? RealTraits<double>::rsqrt(d2) : 0.0;
+            const double id = d2 > 0 ? RealTraits<double, true>::rsqrt(d2) : 0.0;
             const double d = d2 * id;
             const bool in = d < beta;
             const double w = my_wt;
@@ -938,7 +938,7 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
             GPROF_STAGE(6)
             double sm = is_v ? fabs(s[lane]) : 0.0;
             sm = gen_wave_max(sm);
-            const double scale = (cap > 0 && sm > cap) ? RealTraits<double>::div(cap, sm) : 1.0;
+            const double scale = (cap > 0 && sm > cap) ? RealTraits<double, true>::div(cap, sm) : 1.0;
             double my_s = 0.0, my_d = 0.0;
             bool clipped = false;
             if (is_v) {
@@ -997,7 +997,7 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
           continue;
         }
         if (accept) {
-          const double rho = RealTraits<double>::div(F - Ft, fmax(pred, 1e-300));
+          const double rho = RealTraits<double, true>::div(F - Ft, fmax(pred, 1e-300));
           const bool small = smax < tol || pred <= 1e-18 * fmax(F, 1e-30);
           if (is_v) x[lane] = xt[lane];
           gen_sync();

@@ -163,8 +163,9 @@ struct WideTable {
 enum { MODE_SOLVE = 0, MODE_EVAL = 1, MODE_FK = 2 };
 enum { ST_CONVERGED = 0, ST_MAXITER = 1, ST_FALLBACK = 2 };  // == DEXR_STATUS_* in dexr.h
 
-template <typename real> struct RealTraits;
-template <> struct RealTraits<float> {
+// FAST selects, for double, the hardware-estimate versions of 1 / sqrt, sqrt and division (see the specialisation below); float has one version.
+template <typename real, bool FAST = false> struct RealTraits;
+template <bool FAST> struct RealTraits<float, FAST> {
   static __device__ __forceinline__ float rsqrt(float v) { return __frsqrt_rn(v); }
   static __device__ __forceinline__ float sqrt(float v) { return __fsqrt_rn(v); }
   static __device__ __forceinline__ float div(float a, float b) { return a / b; }
@@ -189,11 +190,26 @@ template <> struct RealTraits<float> {
   // min(max(v, lo), hi) in one instruction (v_med3_f32; fmin / fmax of register operands cost a canonicalising v_max each)
   static __device__ __forceinline__ float clamp(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
 };
-template <> struct RealTraits<double> {
-  // 1 / sqrt(v), sqrt(v), a / b from the hardware estimates (v_rsq_f64 / v_rcp_f64, ~26 bits) + two Newton steps: full double
-  // precision to an ulp or two for the well-scaled arguments of the solver (pivots of a damped Hessian, residual norms,
-  // step lengths) in ~10 instructions, where a correctly rounded ::sqrt followed by an IEEE division is ~50 -- four times per
-  // pass in the Cholesky factorisation alone (round 4: the float64 tip pass spent a sixth of its instructions there)
+// float64, correctly rounded: the validation / polish launches (dexr_retarget_f64 on the generic kernels is "the reference's own
+// arithmetic": IEEE sqrt and division, rsqrt(inf) = 0, div(x, 0) = inf -- ADVICE r4).
+template <> struct RealTraits<double, false> {
+  static __device__ __forceinline__ double rsqrt(double v) { return 1.0 / ::sqrt(v); }
+  static __device__ __forceinline__ double sqrt(double v) { return ::sqrt(v); }
+  static __device__ __forceinline__ double div(double a, double b) { return a / b; }
+  static __device__ __forceinline__ void sincos(double a, double* s, double* c) { ::sincos(a, s, c); }
+  static __device__ __forceinline__ double eps() { return 1.1102230246251565e-16; }
+  static __device__ __forceinline__ double clamp(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+};
+// float64, FAST: the float64 tip pass (dexr_tip.hpp) and the general kernel (dexr_gen.hpp) only.
+// 1 / sqrt(v), sqrt(v), a / b from the hardware estimates (v_rsq_f64 / v_rcp_f64, ~26 bits) + two Newton steps in ~10
+// instructions, where a correctly rounded ::sqrt followed by an IEEE division is ~50 -- four times per pass in the Cholesky
+// factorisation alone (round 4: the float64 tip pass spent a sixth of its instructions there).
+// Accuracy: each Newton step squares the relative error (2^-26 -> 2^-51 -> rounding), the result is within 2 ulp of the
+// correctly rounded value for normal, well-scaled arguments (pivots of a damped Hessian, residual norms, step lengths: all
+// within 1e-30 .. 1e30 here).  NOT IEEE at the edges: rsqrt(inf) and div(x, 0) yield NaN (inf x 0 inside the Newton step)
+// where the correctly rounded versions give 0 and inf, rsqrt(0) = NaN (callers test v > 0 first), denormal arguments lose
+// accuracy.  The solver treats a NaN objective / step as a rejected step or a fallback to last_qpos, never as an answer.
+template <> struct RealTraits<double, true> {
   static __device__ __forceinline__ double rsqrt(double v) {
     double r = __builtin_amdgcn_rsq(v);
     r = r * fma(-0.5 * v * r, r, 1.5);
@@ -258,10 +274,10 @@ template <int N> struct TabTraits<LocalTab<N>> { static constexpr bool LOCAL = t
 // CHAIN = true prunes, at compile time, everything a plain serial chain does not need: the component is one
 // unbranched chain of exactly NMAX revolute joints hanging off the base, every joint is an optimised variable (no
 // mimic / fixed-valued joints).  An Allegro or LEAP finger under VectorOptimizer is exactly that.
-template <int NMAX, typename real, bool CHAIN = false>
+template <int NMAX, typename real, bool CHAIN = false, bool FASTM = false>
 struct LaneSolver {
   static constexpr int NH = NMAX * (NMAX + 1) / 2;
-  using RT = RealTraits<real>;
+  using RT = RealTraits<real, FASTM>;  // FASTM: the float64 tip kernel's estimate-based sqrt / division
 
   uint32_t revmask = ~0u;  // wave-uniform: bit k set = joint k is revolute (set by the kernel; saves the jtype loads)
   // ---- per-lane register state ---------------------------------------------------------------------------
@@ -647,8 +663,8 @@ template <int NMAX, typename real, int MODE, bool CHAIN = false, bool EXT = (NMA
 __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MAX : DEXR_BLOCK_MAX, (CHAIN && NMAX <= 4 && sizeof(real) == 4) ? DEXR_CHAIN_MINW : (TIP ? DEXR_TIP64_MINW : 1)) dexr_kernel(const KernelParams kp, const dexr_comp_table* __restrict__ comps) {
   static_assert(!TIP || (CHAIN && NMAX == 4 && MODE == MODE_SOLVE), "tip pass: 4-joint chain solve only");
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  using LS = LaneSolver<NMAX, real, CHAIN>;
-  using RT = RealTraits<real>;
+  using LS = LaneSolver<NMAX, real, CHAIN, TIP>;
+  using RT = RealTraits<real, TIP>;
   const int lane = threadIdx.x & 63;
   // readfirstlane: tell the compiler the wave index (hence the component, every table address and every branch on
   // table contents) is wave-uniform -> s_load / SGPR operands / scalar branches instead of per-lane loads + exec masks

@@ -201,7 +201,7 @@ static __device__ __forceinline__ R tip_eval(const TipTabT<R>& tt, const R (&x)[
   if constexpr (sizeof(R) == 4) {
     d = __builtin_amdgcn_sqrtf(d2);
   } else {
-    rs = RealTraits<double>::rsqrt(d2);
+    rs = RealTraits<double, true>::rsqrt(d2);
     d = d2 > 0 ? d2 * rs : (RR)0;
   }
   const bool quad = d < beta;

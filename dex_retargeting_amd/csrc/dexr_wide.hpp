@@ -145,7 +145,9 @@ struct WideLds {
   static constexpr int FS = JR + 4 * 4 * NRP * 4;      // 32 bytes: row of the frame's inputs / of its item, item, frame of
                                                        // the sequence, DexPilot bits (registers are the scarce resource)
   static constexpr int XL = FS + 32;                   // NMAX floats: regularisation target (the frame's start row)
-  static constexpr int SLOT = XL + NMAX * 4;
+  static constexpr bool TGLDS = !MIMIC && NMAX == 24;  // 24-row grid: the terms' target vectors / weights live here, not in
+  static constexpr int TG = XL + NMAX * 4;             //   four registers of the term's lane (the grid is at 256 VGPRs)
+  static constexpr int SLOT = TG + (TGLDS ? 256 : 0);
   // LDS decides the occupancy: two blocks of four waves per CU (160 KB); the 16-row joint grid is built for three
   static_assert(2 * 4 * (SLOT0 + 4 * SLOT) <= 160 * 1024, "two blocks per CU must fit");
   static_assert(MIMIC || NMAX != 16 || 3 * (4 * (SLOT0 + 4 * SLOT) + 512) <= 160 * 1024, "three blocks per CU must fit");
@@ -209,6 +211,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   int64_t* FS64 = reinterpret_cast<int64_t*>(sbase + L::FS);     // [0] irow, [1] lrow, [2] item
   int32_t* FS32 = reinterpret_cast<int32_t*>(sbase + L::FS) + 6;  // [0] frame of the sequence, [1] DexPilot bits
   float* XLl = reinterpret_cast<float*>(sbase + L::XL);
+  float* TGl = reinterpret_cast<float*>(sbase + L::TG);
 
   const dexr_comp_table& tb = comps[comp];
   const WideTable& wt = wtabs[comp];
@@ -223,6 +226,17 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   const int ld = kp.ld;
   const bool seq = kp.T > 0;
   WPROF_DECL
+  // COLD PATHS READ THE KERNEL ARGUMENTS AGAIN.  Taking a frame and retiring it happen once per frame, a pass 5-40 times; the
+  // ~25 kernel arguments only those two need (batch pointers, strides, DexPilot distances, the keypoint map) were loaded once,
+  // kept in SGPRs for the whole pass loop and, there being ~100 of those, spilled to VGPR lanes (259 spilled SGPRs = 5 VGPRs of a
+  // kernel at 256, `v_readlane`s all over the loop).  Through a pointer the compiler cannot see through (the kernarg segment,
+  // kp is the first argument; address space 4 keeps the reads scalar loads) they are s_loads inside the cold path instead.
+  typedef const __attribute__((address_space(4))) KernelParams ColdParams;
+  auto cold = [&]() -> ColdParams& {
+    ColdParams* q = (ColdParams*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q));
+    return *q;
+  };
 
   // ---- wave-constant tables into LDS (lane-varying joint indices read them in the kinematics) ----------------------
   for (int k = lane; k < NJ; k += 64) {
@@ -329,13 +343,16 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 #pragma unroll
     for (int j = 0; j < NP; ++j) Ha[i][j] = wv2{0.f, 0.f};
 
-  auto ref_row = [&](int row, float (&rv)[3]) {
+  auto ref_row = [&](ColdParams& kp, int row, float (&rv)[3]) {
     const int64_t irow = f_irow();
     if (kp.kpts) {
-      const float* pa = kp.kpts + (irow * kp.n_kp + kp.h_task[row]) * 3;
+      // (32-bit element offsets inside the frame's keypoint block: as 64-bit byte offsets of a lane's own rows they are
+      // loop invariants the compiler keeps in VGPR pairs across the pass loop -- two of them went to scratch)
+      const float* frame = kp.kpts + irow * (int64_t)(kp.n_kp * 3);
+      const float* pa = frame + kp.h_task[row] * 3;
       const int o = kp.h_origin[row];
       if (o >= 0) {
-        const float* pb = kp.kpts + (irow * kp.n_kp + o) * 3;
+        const float* pb = frame + o * 3;
 #pragma unroll
         for (int i = 0; i < 3; ++i) rv[i] = pa[i] - pb[i];
       } else {
@@ -348,7 +365,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       for (int i = 0; i < 3; ++i) rv[i] = r[i];
     }
   };
-  auto xl = [&](int s, const float* lastp, int t_seq) -> float {  // regularisation target of own joint s (see dexr_quad.hpp)
+  auto xl = [&](ColdParams& kp, int s, const float* lastp, int t_seq) -> float {  // regularisation target of own joint s (see dexr_quad.hpp)
     float v;
     if (seq && t_seq > 0)
       v = __hip_atomic_load(const_cast<float*>(lastp) + tb.api[jsel(s)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -361,12 +378,14 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   // the keypoints in every pass put a global-load round trip into each pass and was the 1.5 x between the kernel's HBM
   // traffic and its algorithmic bytes.  (Not at n = 32, where the Hessian grid already spills.)
   constexpr bool TGREG = NMAX <= 24;
+  constexpr bool TGLDS = L::TGLDS;  // ... in 16 bytes of the frame slot per term where the grid leaves no registers (n = 24)
   float tgt[4] = {0.f, 0.f, 0.f, 1.f};
   // frames of the lane's own term (table reads indexed by the lane: taken once, here, where the lane index is still a
   // loop-invariant the compiler may use -- inside the pass loop it is opaque, see the top of the loop)
   const int my_ft = l < nt ? tb.term_task[l] : 0, my_fo = l < nt ? tb.term_origin[l] : -1;
   const int my_ref = l < nt ? tb.term_ref[l] : 0;
   auto load_frame = [&](int64_t it, int t) {
+    ColdParams& kp = cold();  // (shadows the kernel argument inside this cold path)
     const int t_seq = t;
     const int64_t lrow = row_of(it);
     const int64_t irow = seq ? (int64_t)t * kp.seq_stride + lrow : lrow;
@@ -383,7 +402,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       xj[s] = 0;
       float xlast = 0;
       if (jopt[s]) {
-        xlast = xl(s, lastp, t_seq);
+        xlast = xl(kp, s, lastp, t_seq);
         const float v = (kp.x0 && !(seq && t_seq > 0)) ? kp.x0[lrow * ld + tb.api[jsel(s)]] : xlast;
         xj[s] = fminf(fmaxf(v, BOXw[2 * jo_[s]]), BOXw[2 * jo_[s] + 1]);
       } else if (jfix[s]) {
@@ -410,7 +429,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       float dist = 0.f;
       if (l < n_pair) {
         float rv[3];
-        ref_row(l, rv);
+        ref_row(kp, l, rv);
         dist = sqrtf(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
       }
       bool bb = false;
@@ -439,9 +458,9 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     __builtin_amdgcn_wave_barrier();
   };
   // target vector and weight of one term (optimizer.py:246, 479-507)
-  auto term_target = [&](int row, float (&tv)[3], float& wgt) {
+  auto term_target = [&](ColdParams& kp, int row, float (&tv)[3], float& wgt) {
     float rv[3];
-    ref_row(row, rv);
+    ref_row(kp, row, rv);
     wgt = 1.f;
     if (dexpilot) {
       if (row < n_pair) {
@@ -469,8 +488,12 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   auto load_target = [&]() {
     if (TGREG && l < nt) {
       float tv[3], wgt;
-      term_target(my_ref, tv, wgt);
-      tgt[0] = tv[0]; tgt[1] = tv[1]; tgt[2] = tv[2]; tgt[3] = wgt;
+      term_target(cold(), my_ref, tv, wgt);
+      if (TGLDS) {
+        *reinterpret_cast<float4*>(TGl + l * 4) = make_float4(tv[0], tv[1], tv[2], wgt);  // (read by the same lane only)
+      } else {
+        tgt[0] = tv[0]; tgt[1] = tv[1]; tgt[2] = tv[2]; tgt[3] = wgt;
+      }
     }
   };
 
@@ -482,6 +505,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   FS32[1] = 0;
   if (l < NMAX) XLl[l] = 0.f;
   if (NJ2 > 1 && l + 16 < NMAX) XLl[l + 16] = 0.f;
+  if (TGLDS) *reinterpret_cast<float4*>(TGl + l * 4) = make_float4(0.f, 0.f, 0.f, 1.f);
   // frames on the fixed base never move
   if (l < tb.n_base_frame) {
 #pragma unroll
@@ -663,10 +687,13 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       const int ft = my_ft, fo = my_fo;
       double rd[3];
       float tv[3], wgt;
-      if (TGREG) {
+      if (TGLDS) {
+        const float4 tg = *reinterpret_cast<const float4*>(TGl + l * 4);
+        tv[0] = tg.x; tv[1] = tg.y; tv[2] = tg.z; wgt = tg.w;
+      } else if (TGREG) {
         tv[0] = tgt[0]; tv[1] = tgt[1]; tv[2] = tgt[2]; wgt = tgt[3];
       } else {
-        term_target(my_ref, tv, wgt);
+        term_target(cold(), my_ref, tv, wgt);  // (n = 32: every pass)
       }
       float ptf[3], pof[3] = {0, 0, 0};
 #pragma unroll
@@ -1235,10 +1262,11 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         F = Fe;
         take = true;
       } else {
-        const double noise = (double)kp.floor_scale * fabs(F);
+        // (float: the float64 product kept (double) floor_scale alive across the pass loop, in scratch; pred is a float anyway)
+        const float noise = kp.floor_scale * fabsf((float)F);
         // (bitwise, not short-circuit: `&&` / `||` on lane-varying conditions compile to nested exec-mask branches)
         const bool finite = (bool)((int)(Fe == Fe) & (int)(smax == smax) & (int)(fabs(Fe) < 1e30));
-        const bool below_floor = (bool)((int)ok & (int)finite & (int)((double)pred <= noise) & (int)(smax < 1e-2f));
+        const bool below_floor = (bool)((int)ok & (int)finite & (int)(pred <= noise) & (int)(smax < 1e-2f));
         const bool accept = (bool)((int)(ok || MODCHOL) & (int)finite & ((int)(Fe <= F) | (int)below_floor));
         ++my_iters;
         pending = false;
@@ -1401,6 +1429,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     WPROF_STAGE(7)
     // (last) retire finished frames
     if (active && done) {
+      ColdParams& kp = cold();  // (shadows the kernel argument inside this cold path)
       bool badl = false;
 #pragma unroll
       for (int s = 0; s < NJ2; ++s)

@@ -79,10 +79,16 @@ class MultiRobotSeqRetargeting:
         self.num_retargeting = 0
 
     def reset(self):
+        """seq_retarget.py:150-153: last_qpos back to the limit midpoint, counters to zero -- the low-pass filter keeps its
+        state, exactly as the reference's SeqRetargeting.reset() leaves `self.filter` alone (use reset_filter() for a clean
+        filter as well)."""
         self.last_qpos.copy_(self._mid)
+        self.num_retargeting = 0
+
+    def reset_filter(self):
+        """[not-in-ref] forget the low-pass filter state of every robot: the next frame initialises it (LPFilter.reset)."""
         for c in self._compose:
             c["y"] = None
-        self.num_retargeting = 0
 
     def warm_start(self, wrist_pos, wrist_quat, hand_type: HandType = HandType.right, is_mano_convention: bool = False):
         """hand_robot_viewer.py:150-160 for every robot and track: wrist_pos (B, 3), wrist_quat (B, 4) (w, x, y, z) -> the

@@ -135,6 +135,14 @@ int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning);  /* re-runs
 /* Which float32 solve kernel the handle launches: DEXR_KERNEL_* in *family, joint bucket in *bucket, 1 in *chain
  * when the serial-chain specialisation is active (2: with its tip pass) (diagnostics for tools/ and tests). */
 int dexr_model_kernel(const dexr_model* m, int32_t* family, int32_t* bucket, int32_t* chain);
+/* [not-in-ref] Pre-allocate what the `_dev` entry points would otherwise allocate lazily for batches of up to max_batch frames:
+ * the hard-frames-first workspaces of the sixteen-lane kernel (dexr_tuning.longest_first; DexPilot batches of >= 32 768 frames
+ * by default).  Without it the FIRST such call does a hipMalloc and a call with a larger batch than any before does
+ * hipEventSynchronize + hipFree + hipMalloc -- the only place a `_dev` entry point may block on the host; after a reserve()
+ * for the largest batch none does.  Under stream capture the ordering is skipped altogether (no allocation, no cross-stream
+ * event inside a captured region): a captured graph walks the frames in natural order -- the same answers, bit for bit, on
+ * the schedule of longest_first = 0.  No-op for models other kernels serve. */
+int dexr_model_reserve(dexr_model* m, int64_t max_batch);
 /* Diagnostics: the lane plan of component `comp` for the sixteen-lane kernel -- chain_out[16][16]: lane l, step s ->
  * local joint (bit 7 set when that lane publishes the joint's frame, 0xFF: none); anc_rev_out[DEXR_MAXJ]: revolute
  * ancestors-or-self of each joint.  DEXR_ERR_UNSUPPORTED when the model does not fit that kernel. */
@@ -230,7 +238,9 @@ int dexr_seq_compose_dev(int64_t B, int32_t T, int32_t n_q, int32_t n_opt, int32
  *   last, qpos_out  B x ld float32 rows, ld >= max n_opt; a model reads / writes its first n_opt columns
  *   state      B uint32 in/out (read and written for frames of DexPilot models only; may be NULL)
  *   status_out B int32 or NULL
- *   workspace  dexr_fleet_workspace_bytes(B) bytes of device memory (contents irrelevant)
+ *   workspace  dexr_fleet_workspace_bytes(B) bytes of device memory (contents irrelevant).  ALWAYS size it with that function:
+ *              since round 4 it also holds the ordering grids of the hard-frames-first walk (about 4x the round-3 formula);
+ *              a buffer sized by an older formula is refused with DEXR_ERR_INVALID, never overrun
  * All pointers except `models` are DEVICE pointers; enqueues on `stream`. */
 #define DEXR_FLEET_MAX_MODELS 16
 size_t dexr_fleet_workspace_bytes(int64_t B);

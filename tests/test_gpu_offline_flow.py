@@ -90,6 +90,41 @@ def test_offline_multi_robot_flow_matches_the_viewer_loop_and_the_oracle(require
     print(f"offline multi-robot flow: K={K} robots x B={B} tracks x T={T} frames, max |dq| vs oracle {worst:.2e} rad")
 
 
+def test_reset_keeps_the_filter_state_like_the_reference(require_gpu):
+    """seq_retarget.py:150-153: SeqRetargeting.reset() puts last_qpos back to the limit midpoint and zeroes the counters; the
+    LPFilter is left as it is, so the first frame after a reset is filtered against the LAST output before it (ADVICE r4:
+    MultiRobotSeqRetargeting.reset() used to clear the filter).  Compared with a host SeqRetargeting driven the same way, with
+    a real filter (low_pass_alpha 0.3); reset_filter() [not-in-ref] is the clean start."""
+    torch = pytest.importorskip("torch")
+    from dex_retargeting_amd.multi_robot import MultiRobotSeqRetargeting
+
+    rel, B, T = "offline/leap_hand_right.yml", 2, 4
+    kp, wrist_pos, wrist_quat = world_tracks(B, 2 * T)
+    cfg = lambda: RetargetingConfig.load_from_file(os.path.join(cases.CONFIG_DIR, rel), override=dict(low_pass_alpha=0.3)).build()
+    host = [cfg() for _ in range(B)]
+    multi = MultiRobotSeqRetargeting([cfg()], B, device="cuda:0")
+    assert host[0].filter is not None
+    t_kp = torch.from_numpy(kp).to("cuda:0")
+    idx = host[0].optimizer.target_link_human_indices
+    for t in range(2 * T):
+        if t == T:
+            for h in host:
+                h.reset()
+            multi.reset()
+        got = multi.retarget(t_kp[t])[0].cpu().numpy()
+        for b, h in enumerate(host):
+            want = h.retarget(kp[t, b][idx, :])
+            assert np.abs(got[b] - want).max() < 2e-5, (t, b, np.abs(got[b] - want).max())
+    # a cleared filter initialises on the next frame: output == the unfiltered composition of that frame
+    multi.reset_filter()
+    out = multi.retarget(t_kp[0])[0].cpu().numpy()
+    raw = multi.raw_qpos(0).cpu().numpy().astype(np.float64)
+    names = host[0].optimizer.target_joint_names
+    dof_names = host[0].joint_names
+    for j, n in enumerate(names):
+        assert np.abs(out[:, dof_names.index(n)] - raw[:, j]).max() < 1e-6
+
+
 def test_multi_robot_rejects_models_it_cannot_serve(require_gpu):
     from dex_retargeting_amd.multi_robot import MultiRobotSeqRetargeting
 

@@ -104,7 +104,8 @@ class WholeModel:
 def kernel_lm(cm, *, lam0=1e-4, tol=2e-6, max_iter=64, step_cap=0.3, lam_jump=1.0, lam_fastdec=0.1, blind_tol_scale=10.0,
               max_blind=8, stall_from=2, stall_ratio=0.9, stall_cap=20.0, newton=True, eps=5.96e-8, gn_when=None,
               cap_mode="inf", lam_floor=1e-9, trace=None, inner_retry=0, cap_grow=0.0, cap_max=1.2, gersh_at=99, retry_mult=None, pivot_rule=None, pivot_floor=1e-3, blind_contract=0.0, neg_boost=0.0, jump_mode="hd", noise_scale=None,
-              dec_rule=None, accel=0.0, accel_rho=0.9, gn_mode=None, gn_exit=0.05, gn_lam=None):
+              dec_rule=None, accel=0.0, accel_rho=0.9, gn_mode=None, gn_exit=0.05, gn_lam=None, tr_retry=0, tr_factor=2.0, tr_pow=1.0,
+              lam_start=None, first_jump=None):
     """Returns (x (B,T,m), iters (B,T)).  `eps`: rounding unit of the kernel's arithmetic (float32) for the
     below-the-floor logic.  gn_when: optional callable(F, lam, it) -> bool mask selecting Gauss-Newton models."""
     B, T, m = cm.B, cm.T, cm.m
@@ -115,7 +116,7 @@ def kernel_lm(cm, *, lam0=1e-4, tol=2e-6, max_iter=64, step_cap=0.3, lam_jump=1.
     if gn_mode:  # per-frame model switch: Gauss-Newton (PSD) Hessian after an indefinite Newton model, Newton again near the end
         Hn, Hg = Hs, cm(x, False)[2]
         gn = np.zeros((B, T), bool)
-    lam = np.full((B, T), lam0)
+    lam = np.full((B, T), lam0 if lam_start is None else lam_start)
     nu = np.full((B, T), 2.0)
     sprev = np.full((B, T), 1e30)
     blind = np.zeros((B, T), int)
@@ -182,6 +183,32 @@ def kernel_lm(cm, *, lam0=1e-4, tol=2e-6, max_iter=64, step_cap=0.3, lam_jump=1.
             if pivot_rule == "kernel":
                 ok = ~modified  # gates last_step / below_floor only (see accept below)
         dmax = np.abs(np.where(vm, d, 0)).max(-1)
+        if first_jump is not None and _ == 0:  # the solve's FIRST model is indefinite or proposes a wild step: start damped
+            kf, lbig = first_jump
+            wild = ~done & (~ok | (dmax > kf * step_cap))
+            lam = np.where(wild, np.maximum(lam, lbig), lam)
+            Hm = np.where(ff, Hs, 0.0) + np.where(free, 2 * delta + lam[..., None], 1.0)[..., None] * eye
+            Hm = np.where(ff | (eye > 0), Hm, 0.0)
+            ok2 = np.linalg.eigvalsh(Hm).min(-1) > 1e-30
+            Hsafe = np.where(ok2[..., None, None], Hm, eye)
+            d2 = -np.linalg.solve(Hsafe, gm[..., None])[..., 0]
+            d = np.where(wild[..., None], d2, d)
+            ok = np.where(wild, ok2, ok)
+            dmax = np.abs(np.where(vm, d, 0)).max(-1)
+        for _r in range(tr_retry):  # trust region by damping: a step far beyond the radius is re-solved with more damping
+            big = ok & ~done & (dmax > tr_factor * step_cap) & (step_cap > 0)
+            if not big.any():
+                break
+            hd0 = np.where(vm, np.einsum("btii->bti", Hs), 0.0).sum(-1) / vm.sum(-1)
+            lam = np.where(big, np.maximum(lam, 1e-3 * np.abs(hd0)) * (dmax / step_cap) ** tr_pow, lam)
+            Hm = np.where(ff, Hs, 0.0) + np.where(free, 2 * delta + lam[..., None], 1.0)[..., None] * eye
+            Hm = np.where(ff | (eye > 0), Hm, 0.0)
+            ok2 = np.linalg.eigvalsh(Hm).min(-1) > 1e-30
+            Hsafe = np.where(ok2[..., None, None], Hm, eye)
+            d2 = -np.linalg.solve(Hsafe, gm[..., None])[..., 0]
+            d = np.where(big[..., None], d2, d)
+            ok = np.where(big, ok2, ok)
+            dmax = np.abs(np.where(vm, d, 0)).max(-1)
         gd = -(gm * d).sum(-1)
         dd = (np.where(vm, d, 0) ** 2).sum(-1)
         if cap_grow > 0 and _ == 0:
