@@ -72,6 +72,24 @@ def algorithmic_bytes_per_frame(n_opt: int, dexpilot: bool, n_rows: int, keypoin
     return (21 if keypoints else n_rows) * 12 + n_opt * 4 + n_opt * 4 + (8 if dexpilot else 0)
 
 
+def pmc_counters(name: str, batch: int):
+    """(traffic bytes per step, SQ_INSTS_VALU per step, note) from the committed rocprofv3 PMC summary profiles/pmc_<name>.json
+    (tools/profile_round.sh <name>): 2 x FETCH_SIZE + WRITE_SIZE summed over EVERY kernel of a step (solve kernels and the
+    ordering / bucketing kernels around them; gfx950 correction per MI355X_MICROARCH.md).  Attached only while the summary was
+    taken on this batch size and on the sources that build the workload's kernels (dex_retargeting_amd/_build.source_hash)."""
+    path = os.path.join(REPO, "profiles", f"pmc_{name}.json")
+    if not os.path.exists(path):
+        return None, None, f"no committed PMC summary (profiles/pmc_{name}.json)"
+    from dex_retargeting_amd._build import source_hash
+
+    pmc = json.load(open(path))
+    if pmc.get("batch") != batch:
+        return None, None, "committed PMC summary is for another batch size"
+    if pmc.get("source_sha16") != source_hash(name):
+        return None, None, "committed PMC summary was taken on other kernel sources (source_sha16 mismatch): counters withheld"
+    return pmc.get("hbm_bytes_per_launch"), pmc.get("SQ_INSTS_VALU"), None
+
+
 def algorithmic_flops_per_pass(compiled) -> float:
     """FP operations of ONE solver pass (FK + value/gradient/Hessian + factorisation + step) over all components of a
     frame, counted from the compiled tables: per component with n joints and T terms
@@ -294,34 +312,26 @@ class Workload:
         flops_frame = algorithmic_flops_per_pass(self.opt.compiled_model()) * (iters_mean + 1.0)  # +1: start point's model
         tf = self.B * flops_frame / (kernel_ms * 1e-3) / 1e12
         peak_tf = FP32_VALU_PEAK_TFLOPS if precision == "f32" else FP64_VALU_PEAK_TFLOPS
-        traffic, valu_frac = None, None
-        # HBM bytes per launch as counted by rocprofv3 PMC passes of this same command (tools/profile_round.sh writes
-        # the summary, committed under profiles/): 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction per
-        # MI355X_MICROARCH.md.  Only attached to the line it was measured for (same batch, f32, keypoint input).
-        pmc_path = os.path.join(REPO, "profiles", f"pmc_{self.name}.json")
-        pmc_note = None
-        if os.path.exists(pmc_path) and precision == "f32" and batch_kind == "kp" and world == 1:
-            from dex_retargeting_amd._build import source_hash
-
-            pmc = json.load(open(pmc_path))
-            if pmc.get("batch") != self.B:
-                pmc_note = "committed PMC summary is for another batch size"
-            elif pmc.get("source_sha16") != source_hash(self.name):
-                pmc_note = "committed PMC summary was taken on other kernel sources (source_sha16 mismatch): counters withheld"
-            else:
-                traffic = pmc.get("hbm_bytes_per_launch")
-                if "SQ_INSTS_VALU" in pmc:
-                    # a wave64 VALU instruction issues over 2 cycles on a SIMD-32 (MI355X_MICROARCH.md, "Wave scheduling":
-                    # 32 lanes/cycle x 2; 157.3 TF = 64 FLOP/clk/SIMD); 1024 SIMDs at 2.4 GHz.  A lower bound on the busy
-                    # share: packed-f32 and f64 instructions take 4 (round 3 charged 4 to every instruction: 2x too high)
-                    valu_frac = pmc["SQ_INSTS_VALU"] * 2.0 / (1024 * kernel_ms * 1e-3 * 2.4e9)
+        # HBM bytes per step as counted by rocprofv3 PMC passes of this same command (tools/profile_round.sh writes the
+        # summary, committed under profiles/): see pmc_counters.  One summary per record: <workload>, <workload>_f64,
+        # <workload>_cold.
+        pmc_name = self.name + ("_f64" if precision == "f64" else "") + ("_cold" if batch_kind == "ref" else "")
+        traffic, valu_frac, pmc_note = None, None, None
+        if world == 1:
+            traffic, n_valu, pmc_note = pmc_counters(pmc_name, self.B)
+            if n_valu:
+                # a wave64 VALU instruction issues over 2 cycles on a SIMD-32 (MI355X_MICROARCH.md, "Wave scheduling":
+                # 32 lanes/cycle x 2; 157.3 TF = 64 FLOP/clk/SIMD); 1024 SIMDs at 2.4 GHz.  A lower bound on the busy
+                # share: packed-f32 and f64 instructions take 4 (round 3 charged 4 to every instruction: 2x too high)
+                valu_frac = n_valu * 2.0 / (1024 * kernel_ms * 1e-3 * 2.4e9)
         fam, bucket, chain = self.model.kernel()
         kname = KERNEL_NAMES[fam] + f", bucket {bucket}" + (", serial-chain specialisation" + (" with the tip pass" if chain == 2 else "") if chain else "")
         if precision == "f64":
             kname = f"dexr_kernel<{bucket}, double" + (", CHAIN, TIP> (the tip pass of the serial-chain kernel in float64 arithmetic, "
                                                         "dexr_tip.hpp)" if chain == 2 else "> (register kernel, float64 arithmetic)")
         return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic, "valu_issue_frac": valu_frac, "pmc_note": pmc_note,
+                "traffic": traffic, "traffic_over_algorithmic": None if not traffic else traffic / (self.B * bpf),
+                "valu_issue_frac": valu_frac, "pmc_note": pmc_note,
                 "valu": {"achieved": tf, "peak": peak_tf, "unit": "TFLOP/s", "frac": tf / peak_tf,
                          "algorithmic_flops_per_frame": flops_frame},
                 "kernel": kname, "kernel_ms": kernel_ms, "algorithmic_bytes_per_frame": bpf}
@@ -615,6 +625,14 @@ def general_kernel_measure(torch, dev, steps, warmup, B=65536):
                        "21 reference rows: 37 variables in one component (generic tables)", "batch": B, "dtype": "f64",
            "kernel": "dexr_gen_kernel (one wavefront per frame)", "value": B / (ms * 1e-3), "unit": "frames/s", "n_gpus": 1,
            "ms_per_step": ms, "steps": steps, "solver": {"iters_mean": float(iters.mean()), "iters_max": int(iters.max())}}
+    n_opt = int(t_last.shape[1])
+    bpf = algorithmic_bytes_per_frame(n_opt, False, 0, True)
+    traffic, n_valu, note = pmc_counters("general_kernel", B)
+    achieved = B * bpf / (ms * 1e-3) / 1e9
+    rec["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                       "traffic": traffic, "traffic_over_algorithmic": None if not traffic else traffic / (B * bpf),
+                       "valu_issue_frac": None if not n_valu else n_valu * 2.0 / (1024 * ms * 1e-3 * 2.4e9), "pmc_note": note,
+                       "kernel_ms": ms, "algorithmic_bytes_per_frame": bpf}
     n = 128
     return rec, dict(kp=kp[1:n + 1], last=last[:n], q=out[:n].cpu().numpy())
 
@@ -926,7 +944,23 @@ def run_single(args):
     from dex_retargeting_amd import _lib
 
     B = args.batch
+    import bench_line
+
+    if args.probe == "general_kernel":  # (tools/profile_round.sh general_kernel: the sub-record's loop alone, for rocprofv3)
+        rec, _ = general_kernel_measure(torch, dev, args.steps, args.warmup)
+        probe = {"probe": "general_kernel", "config": {"batch_per_gpu": rec["batch"]}, "roofline": {"kernel_ms": rec["ms_per_step"]},
+                 "value": rec["value"], "unit": "frames/s"}
+        print(bench_line.dumps(probe))  # (a few bytes for tools/prof_summary.py, not a contract line)
+        return
     wl = Workload(args.workload, rank, B, dev, torch)
+    if args.probe in ("f64", "cold_start"):
+        batches = wl.tracking if args.probe == "f64" else wl.stage_cold()
+        opts = _lib.default_options(precision=1) if args.probe == "f64" else None
+        e, k = wl.timed(batches, args.steps, args.warmup, opts=opts)
+        probe = {"probe": args.probe, "config": {"batch_per_gpu": B}, "roofline": {"kernel_ms": k}, "value": B * args.steps / e,
+                 "unit": "frames/s"}
+        print(bench_line.dumps(probe))  # (a few bytes for tools/prof_summary.py, not a contract line)
+        return
     diag = wl.diagnostics(wl.tracking)
 
     # ---- headline: float32 tracking -----------------------------------------------------------------------------
@@ -1240,6 +1274,9 @@ def main():
     ap.add_argument("--nccl-proto", default=None, help="sets NCCL_PROTO (e.g. Simple, LL, LL128)")
     ap.add_argument("--fleet-order", default="iid", choices=("iid", "sorted"),
                     help="mixed_fleet: order of the global batch (sorted = by robot; ranks take 1/N of every robot either way)")
+    ap.add_argument("--probe", default=None, choices=("f64", "cold_start", "general_kernel"),
+                    help="time ONLY this sub-record's loop and print a small JSON line (what tools/profile_round.sh wraps in "
+                         "rocprofv3 for the sub-records' PMC summaries)")
     ap.add_argument("--dry-run-launch", action="store_true",
                     help="launch + rendezvous plumbing only (no GPU work): used by the CPU tests of the N > 1 launcher")
     args = ap.parse_args()

@@ -139,6 +139,9 @@ def fleet_measure(args, batch=None, standalone=True):
     mid, kp = last_b["mid"], last_b["kp"]
     bpf = 21 * 12 + 2 * 4 * fleet.n_max + 4 + 8  # keypoints + padded last/qpos rows + model id + DexPilot state in/out
     achieved = B * bpf / (step_ms * 1e-3) / 1e9
+    import bench as _bench  # (pmc_counters: the committed rocprofv3 PMC summary of this command, keyed on batch + sources)
+
+    traffic, n_valu, pmc_note = _bench.pmc_counters("mixed_fleet", B) if world == 1 else (None, None, None)
     out_json = {
         "metric": "retargeted frames/sec, mixed-fleet batch (BASELINE.json configs[4])",
         "value": world * B * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -152,7 +155,10 @@ def fleet_measure(args, batch=None, standalone=True):
                    "collective": "none" if coll is None else coll["collective"],
                    "rccl_world_size": None if coll is None else coll["rccl_world_size"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": step_ms,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "traffic_over_algorithmic": None if not traffic else traffic / (B * bpf),
+                     "valu_issue_frac": None if not n_valu else n_valu * 2.0 / (1024 * step_ms * 1e-3 * 2.4e9), "pmc_note": pmc_note,
+                     "kernel_ms": step_ms,
                      "algorithmic_bytes_per_frame": bpf,
                      "kernel": "dexr_retarget_multi_dev: device-side bucketing (3 small kernels) + one solve launch per model "
                                "over its index list, in-place rows"},

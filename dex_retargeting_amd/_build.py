@@ -42,6 +42,11 @@ KERNEL_SOURCES = {
     "allegro_vector": ["dexr_kernel.hpp", "dexr_tip.hpp", "dexr_math.hpp", "dexr_inst.hip"],
     "shadow_dexpilot": ["dexr_wide.hpp", "dexr_wide_inst.hip", "dexr_big.hpp", "dexr_math.hpp"],
     "leap_position": ["dexr_wide.hpp", "dexr_wide_inst.hip", "dexr_big.hpp", "dexr_math.hpp"],
+    # sub-records of the default line (bench.py --probe): the float64 / cold-start launches of the headline config, the general
+    # kernel; "mixed_fleet" is absent on purpose: four robots = every kernel family, i.e. all sources (the fallback)
+    "allegro_vector_f64": ["dexr_kernel.hpp", "dexr_tip.hpp", "dexr_math.hpp", "dexr_inst.hip"],
+    "allegro_vector_cold": ["dexr_kernel.hpp", "dexr_tip.hpp", "dexr_math.hpp", "dexr_inst.hip"],
+    "general_kernel": ["dexr_gen.hpp", "dexr_gen_inst.hip", "dexr_kernel.hpp", "dexr_big.hpp", "dexr_math.hpp"],
 }
 
 

@@ -295,8 +295,14 @@ int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st)
   kp.q0 = (uint32_t)(per_comp * 4);
   const unsigned slot = m->qnext.fetch_add(1u) % dexr_model::QSLOTS;
   kp.queue = m->d_queue + (size_t)slot * kp.n_comp;
-  hipError_t qe = hipMemsetAsync(kp.queue, 0, (size_t)kp.n_comp * sizeof(unsigned), st);
-  if (qe != hipSuccess) return fail(DEXR_ERR_HIP, "queue reset failed: %s", hipGetErrorString(qe));
+  // The queue counter numbers the frames from q0 on.  When the static tiles already cover the batch (q0 >= B: every small
+  // launch, the one-frame-per-call regime in particular) whatever a row draws is >= q0 >= B -- "dry" -- for ANY counter value, so
+  // the reset (a fill kernel + its launch: ~4 us of a 37 us one-frame call) is skipped; the counters only ever grow, and a
+  // launch that does hand out frames through the queue resets its slot as before.
+  if ((int64_t)kp.q0 < kp.B) {
+    hipError_t qe = hipMemsetAsync(kp.queue, 0, (size_t)kp.n_comp * sizeof(unsigned), st);
+    if (qe != hipSuccess) return fail(DEXR_ERR_HIP, "queue reset failed: %s", hipGetErrorString(qe));
+  }
 #ifdef DEXR_WIDE_PROF
   static double* wprof = nullptr;  // profiling build only: stage cycles of wave 0 (dexr_wide.hpp WPROF_*)
   if (!wprof) (void)hipMalloc((void**)&wprof, 12 * sizeof(double));

@@ -1212,9 +1212,11 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         // are busy would start late (near the end of the queue other waves' rows are idle by then)
         const unsigned nwant = (unsigned)__popcll(want) >> 4;
         unsigned base = 0;
-        if (lane == 0) base = atomicAdd(queue, nwant);
+        // (static tiles cover the batch: nothing to draw, the counter -- which such launches do not reset -- is not touched)
+        const bool no_queue = (int64_t)kp.q0 >= kp.B;
+        if (!no_queue && lane == 0) base = atomicAdd(queue, nwant);
         base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + kp.q0;
-        if ((int64_t)base >= nB) {
+        if (no_queue || (int64_t)base >= nB) {
           dry = true;
         } else {
           pool_next = base;

@@ -8,7 +8,8 @@ answers are DIFFERENT local minima (human targets are multi-modal: e.g. a mimic 
 either joint limit) and the GPU's is certified: a tight float64 minimisation of F started AT the GPU answer neither
 moves it by 1e-4 rad nor lowers F.  HOW MANY such frames a config may have is pinned PER CONFIG in
 tests/golden/parity_ceilings.json ("far": frames >= 1e-4 rad from the oracle, "worse": those whose certified minimum has
-the higher F): the measured count of the round it was last refreshed in plus a small margin, and ZERO for every config
+the higher F): since round 5 exactly the measured counts (rounds 4 and 5 measured the same 39 rows on different boxes; why
+the 34 "worse" frames cannot be had for less than half of all passes: profiles/r05_worse_minimum_tail.txt), ZERO for every config
 that measured zero -- the headline config cannot regress from 0 to 80 far frames and stay green; "far_r3":
 the same count against the UNCHANGED oracle of rounds 1-3, pinned as well (the checker was repaired in round 4,
 this column was not, so a regression of the library shows there whatever happens to the checker).
@@ -160,7 +161,10 @@ def test_ceilings_table_is_tight_where_it_matters():
     for rel, cap in CEILINGS.items():
         assert 0 <= cap["worse"] <= cap["far"] <= B // 50 and cap["worse"] <= B // 100, (rel, cap)
         assert 0 <= cap["far_r3"] <= B // 50, (rel, cap)  # (the global gate of rounds 2-3: < 2 % far from that oracle)
-    assert CEILINGS["teleop/allegro_hand_right.yml"] == {"far": 0, "worse": 0, "far_r3": 2}  # (0 measured; the margin of far_r3 is 2)
+    assert CEILINGS["teleop/allegro_hand_right.yml"] == {"far": 0, "worse": 0, "far_r3": 0}
+    # round 5: the ceilings ARE the measured counts (no "+ 1": two boxes, two rounds and a rebuilt library gave the same 39 rows;
+    # a frame's answer does not depend on the schedule and the oracle phase is deterministic numpy)
+    assert sum(c["far"] for c in CEILINGS.values()) == 63 and sum(c["worse"] for c in CEILINGS.values()) == 34
 
 
 @pytest.mark.parametrize("rel", ALL)

@@ -72,21 +72,50 @@ for p in dbs("kt"):
     except Exception as e:
         print("# (per-dispatch view unavailable:", e, ")")
 
+# Which kernels run INSIDE a timed step, and how often: the kernel-trace run and the PMC runs are the same command with KS / PS
+# timed steps (+ 3 / + 1 warm-up steps), so a kernel dispatched c times per step appears c x (KS + 3 - PS - 1) more often in the
+# trace than in a PMC pass; staging / diagnostic launches appear equally often in both and drop out.  A step's counters are the
+# sum over its kernels -- the solve kernels AND the ordering / bucketing kernels around them (round 4 counted kernels named
+# dexr::* only: the hard-frames-first pass, whose kernels live in an anonymous namespace, was missing from the traffic figure).
+KS = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+PS = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+trace_counts = collections.Counter()
+for p in dbs("kt"):
+    try:
+        for name, n in q(p, "select name, count(*) from kernels group by name"):
+            trace_counts[name] += n
+    except Exception as e:
+        print("# (kernel counts unavailable:", e, ")")
+per_kernel = {}
 for tag in ("fetch", "write", "sq"):
-    print(f"\n# separate PMC pass ({tag}): counter, dispatches, per-dispatch average; FETCH/WRITE_SIZE in KB as reported "
-          f"(gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> x2, MI355X_MICROARCH.md)")
+    print(f"\n# separate PMC pass ({tag}): per kernel of a timed step -- dispatches per step, counter, per-dispatch average over the "
+          f"timed steps; FETCH/WRITE_SIZE in KB as reported (gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> x2, MI355X_MICROARCH.md)")
     for p in dbs(tag):
-        agg = collections.defaultdict(list)
-        for k, c, v in q(p, "select kernel_name, counter_name, value from counters_collection"):
-            if "dexr" in k:
-                agg[c].append(v)
-        for c, v in sorted(agg.items()):
-            # the first dispatches are the untimed warm-start / warm-up launches: report the steady state (last half)
-            tail = v[len(v) // 2:]
-            avg = sum(tail) / len(tail)
-            print(f"{c:24s} n={len(v):3d} avg(last half)={avg:.6g} last={v[-1]:.6g}")
-            summary[c] = avg
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        try:
+            rows = q(p, "select kernel_name, counter_name, value from counters_collection order by dispatch_id")
+        except Exception:
+            rows = q(p, "select kernel_name, counter_name, value from counters_collection")
+        for k, c, v in rows:
+            agg[k][c].append(v)
+        for k, cs in agg.items():
+            n_pmc = len(next(iter(cs.values())))
+            per_step = (trace_counts.get(k, 0) - n_pmc) / float(KS + 2 - PS) if trace_counts else (1.0 if "dexr" in k else 0.0)
+            c_k = int(round(per_step))
+            if c_k <= 0 or abs(per_step - c_k) > 0.2:
+                continue  # not a kernel of the timed loop
+            for c, v in sorted(cs.items()):
+                tail = v[-c_k * PS:]
+                avg = sum(tail) / len(tail)
+                print(f"{k[:70]:70s} x{c_k} {c:20s} n={len(v):3d} avg={avg:.6g}")
+                summary[c] = summary.get(c, 0.0) + c_k * avg
+                per_kernel.setdefault(k[:70], {"per_step": c_k})[c] = avg
+if per_kernel:
+    summary["per_kernel"] = per_kernel
 if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
     summary["hbm_bytes_per_launch"] = (2.0 * summary["FETCH_SIZE"] + summary["WRITE_SIZE"]) * 1024.0
-    print(f"\n# HBM traffic per launch = 2 x FETCH_SIZE + WRITE_SIZE = {summary['hbm_bytes_per_launch'] / 1e6:.2f} MB")
+    print(f"\n# HBM traffic per step (all kernels of the step) = 2 x FETCH_SIZE + WRITE_SIZE = {summary['hbm_bytes_per_launch'] / 1e6:.2f} MB")
+    for k, v in per_kernel.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            print(f"#   {k:70s} x{v['per_step']}: {(2.0 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024.0 / 1e6:8.2f} MB per dispatch")
 json.dump(summary, open(os.path.join(out, f"pmc_{w}.json"), "w"), indent=1)
