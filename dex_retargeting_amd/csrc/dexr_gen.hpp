@@ -326,18 +326,13 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
   const int my_var = is_j ? l_var[lane] : -1;
   const int my_parent = is_j ? l_parent[lane] : -1;
   const bool my_rev = is_j && l_jtype[lane] == DEXR_JOINT_REVOLUTE;
-  const double my_jmul = is_j ? l_jmul[lane] : 0.0;
-  double myX[12], my_ax[3], my_fo[3];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) myX[i] = is_j ? tb.X[(size_t)lane * 12 + i] : 0.0;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    my_ax[i] = is_j ? tb.axis[lane * 3 + i] : 0.0;
-    my_fo[i] = is_f ? tb.frame_off[(size_t)lane * 3 + i] : 0.0;
-  }
+#define my_jmul (is_j ? l_jmul[lane] : 0.0)  /* the wave's LDS copy, at use (registers are the scarce resource) */
+  // (the placement, local axis and frame offset of the lane's joint / link -- 21 doubles -- are read again from the tables at
+  // the top of every evaluation: resident in L2, issued before the sines and cosines they wait behind; held in registers
+  // across the whole pass they were 42 of the VGPRs a kernel at 256 spills)
   const int my_fjoint = is_f ? l_fjoint[lane] : -1;
-  const double my_joff = is_j ? tb.joff[lane] : 0.0;
-  const double my_lo = is_v ? tb.lo[lane] : 0.0, my_hi = is_v ? tb.hi[lane] : 0.0;
+#define my_lo (is_v ? tb.lo[lane] : 0.0)  /* box of the lane's variable: read from the tables where the step is clipped */
+#define my_hi (is_v ? tb.hi[lane] : 0.0)
   const int my_api = is_v ? tb.var_api[lane] : 0;
   const int my_ft = is_t ? l_ttask[lane] : 0, my_fo_t = is_t ? l_torigin[lane] : -1;  // lane t: frames of term t
   // terms whose task / origin chain joint `lane` lies on (bit t): the column of joint k for term t needs nothing else
@@ -431,7 +426,7 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
       if (MODE == MODE_FK) {
         if (is_j) my_qfix = kp.xin[it * kp.n_q + my_src];
       } else if (is_j && my_var < 0) {
-        my_qfix = my_jmul * (double)kp.fixed[it * kp.ldf + my_src] + my_joff;
+        my_qfix = my_jmul * (double)kp.fixed[it * kp.ldf + my_src] + tb.joff[lane];
       }
       uint32_t nst = 0;
       double my_tgt[3] = {0, 0, 0}, my_wt = 1.0;  // lane t: target and weight of term t
@@ -496,7 +491,30 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
         // every joint's local transform X_k . motion(q_k) at once (sines / cosines of all joints in one go, not one level at
         // a time): rotation about / translation along the joint's own axis
         double Lc[12];
+        double my_ax[3], my_fo[3];
         {
+          int lane_o = lane;
+          asm volatile("" : "+v"(lane_o));  // (opaque: the loads below stay inside the evaluation)
+          double myX[12];
+          const int jl = is_j ? lane_o : 0, fl = is_f ? lane_o : 0;
+#pragma unroll
+          for (int i = 0; i < 12; ++i) myX[i] = tb.X[(size_t)jl * 12 + i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            my_ax[i] = tb.axis[jl * 3 + i];
+            my_fo[i] = tb.frame_off[(size_t)fl * 3 + i];
+          }
+          const double my_joff = tb.joff[jl];
+          if (!is_j) {  // (lanes beyond the joints used to carry zeros)
+#pragma unroll
+            for (int i = 0; i < 12; ++i) myX[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) my_ax[i] = 0.0;
+          }
+          if (!is_f) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) my_fo[i] = 0.0;
+          }
           double q = my_qfix;
           if (MODE != MODE_FK && my_var >= 0) q = my_jmul * xs[my_var] + my_joff;
           const double ax = my_ax[0], ay = my_ax[1], az = my_ax[2];
@@ -1048,4 +1066,7 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
   GPROF_FLUSH()
 }
 
+#undef my_jmul
+#undef my_lo
+#undef my_hi
 }  // namespace dexr

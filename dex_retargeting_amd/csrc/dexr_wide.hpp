@@ -145,8 +145,12 @@ struct WideLds {
   static constexpr int FS = JR + 4 * 4 * NRP * 4;      // 32 bytes: row of the frame's inputs / of its item, item, frame of
                                                        // the sequence, DexPilot bits (registers are the scarce resource)
   static constexpr int XL = FS + 32;                   // NMAX floats: regularisation target (the frame's start row)
-  static constexpr bool TGLDS = !MIMIC && NMAX == 24;  // 24-row grid: the terms' target vectors / weights live here, not in
-  static constexpr int TG = XL + NMAX * 4;             //   four registers of the term's lane (the grid is at 256 VGPRs)
+  // (TGLDS: the terms' target vectors / weights in 256 B of the frame slot instead of four registers of the term's lane.  It
+  // takes the 24-row grid from 2 spilled VGPRs to none -- and 1 KB of LDS per wave, 8 KB per CU, which is what the small-component
+  // kernels of a FLEET batch need to sit beside the heavy model's blocks: same box, fleet step 0.750 -> 0.79-0.85 ms
+  // (profiles/r05_fleet_ab_tg_lds_same_box.txt).  Off.)
+  static constexpr bool TGLDS = false;
+  static constexpr int TG = XL + NMAX * 4;
   static constexpr int SLOT = TG + (TGLDS ? 256 : 0);
   // LDS decides the occupancy: two blocks of four waves per CU (160 KB); the 16-row joint grid is built for three
   static_assert(2 * 4 * (SLOT0 + 4 * SLOT) <= 160 * 1024, "two blocks per CU must fit");
@@ -488,7 +492,10 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   auto load_target = [&]() {
     if (TGREG && l < nt) {
       float tv[3], wgt;
-      term_target(cold(), my_ref, tv, wgt);
+      int row = my_ref;
+      asm volatile("" : "+v"(row));  // (opaque: the 64-bit offsets of this row into the keypoint map are formed here, in the
+                                     // cold path, not kept -- in scratch -- across the pass loop)
+      term_target(cold(), row, tv, wgt);
       if (TGLDS) {
         *reinterpret_cast<float4*>(TGl + l * 4) = make_float4(tv[0], tv[1], tv[2], wgt);  // (read by the same lane only)
       } else {
@@ -693,7 +700,9 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       } else if (TGREG) {
         tv[0] = tgt[0]; tv[1] = tgt[1]; tv[2] = tgt[2]; wgt = tgt[3];
       } else {
-        term_target(cold(), my_ref, tv, wgt);  // (n = 32: every pass)
+        int row = my_ref;
+        asm volatile("" : "+v"(row));
+        term_target(cold(), row, tv, wgt);  // (n = 32: every pass)
       }
       float ptf[3], pof[3] = {0, 0, 0};
 #pragma unroll
