@@ -142,6 +142,11 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         if force or _stale(o, [wide_s, os.path.join(CSRC, "dexr_wide.hpp"), BIG_HEADER] + HEADERS):
             # the 16-row grid fits three waves per SIMD (168 VGPRs, 18 of them spilled; 11.8 KB of LDS per wave)
             jobs.append((wide_s, o, NO_SLP + [f"-DDEXR_NMAX={n}"] + (["-DDEXR_WIDE_MINW=3"] if n == 16 else [])))
+    for n in (16, 24, 32):  # ... one frame per wave (SPRINT): the launch shape of small batches
+        o = os.path.join(BUILD, f"dexr_wide_s_{n}.o")
+        objs.append(o)
+        if force or _stale(o, [wide_s, os.path.join(CSRC, "dexr_wide.hpp"), BIG_HEADER] + HEADERS):
+            jobs.append((wide_s, o, NO_SLP + [f"-DDEXR_NMAX={n}", "-DDEXR_SPRINT=1"] + (["-DDEXR_WIDE_MINW=3"] if n == 16 else [])))
     for tag, defs in (("m", []), ("mc", ["-DDEXR_MODCHOL=1"])):  # the same kernel on the grid of the optimised variables
         o = os.path.join(BUILD, f"dexr_wide_{tag}_16.o")         # (mimic joints), plain / modified Cholesky
         objs.append(o)

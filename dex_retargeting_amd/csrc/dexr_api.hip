@@ -279,7 +279,12 @@ int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st)
   const size_t per_wave = m->wide_mimic ? dexr::wide_lds_per_wave_m_16() : dexr::wide_lds_per_wave(m->wbucket);
   int wpb = 4;
   while (wpb > 1 && per_wave * wpb > 80 * 1024) wpb >>= 1;
-  const int64_t tiles = (kp.B + 3) / 4;
+  // ONE FRAME PER WAVE for small plain batches of the joint-space grids (dexr_wide.hpp SPRINT; dexr_tuning.sprint_max_batch):
+  // with fewer frames than the chip has row slots a wave's four rows share one frame's term loop instead of idling
+  const int64_t sprint_max = m->tune.sprint_max_batch < 0 ? 2048 : m->tune.sprint_max_batch;  // (measured: it wins up to ~2 048 frames = one wave per frame on every SIMD pair, profiles/r05_sprint_one_frame_per_wave.txt)
+  const bool sprint = !m->wide_mimic && kp.B <= sprint_max && !kp.perm && !kp.bucket && kp.T == 0 && !kp.screen && kp.n_comp == 1;
+  const int fpw = sprint ? 1 : 4;  // frames per wave
+  const int64_t tiles = (kp.B + fpw - 1) / fpw;
   // waves per SIMD: 2 (256 VGPRs; 15-17 KB of LDS per wave); the 16-row joint grid is built for 3 (168 VGPRs, 11.8 KB):
   // LEAP DexPilot 1.24 -> 1.14 ms, Allegro DexPilot 0.84 -> 0.75 ms
   // (the 24-row grid at three waves per SIMD -- 168 VGPRs, 85 registers spilled -- measured 34-40 % SLOWER in round 4, with the
@@ -292,7 +297,7 @@ int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st)
   const int64_t waves = per_comp * kp.n_comp;
   const int64_t blocks = (waves + wpb - 1) / wpb;
   if (blocks > 0x7fffffffLL) return fail(DEXR_ERR_INVALID, "batch too large for one launch");
-  kp.q0 = (uint32_t)(per_comp * 4);
+  kp.q0 = (uint32_t)(per_comp * fpw);
   const unsigned slot = m->qnext.fetch_add(1u) % dexr_model::QSLOTS;
   kp.queue = m->d_queue + (size_t)slot * kp.n_comp;
   // The queue counter numbers the frames from q0 on.  When the static tiles already cover the batch (q0 >= B: every small
@@ -310,6 +315,7 @@ int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st)
   kp.g64out = wprof;
 #endif
   dexr::wide_launch_fn fn = m->wide_mimic ? (m->wide_modchol ? dexr::launch_wide_mc_16 : dexr::launch_wide_m_16)
+                            : sprint      ? dexr::find_wide_sprint_launcher(m->wbucket)
                                           : dexr::find_wide_launcher(m->wbucket);
   if (!fn) return fail(DEXR_ERR_UNSUPPORTED, "no sixteen-lane kernel for bucket %d", m->wbucket);
   hipError_t e = fn(kp, m->d_wide, dim3((unsigned)blocks), dim3(64 * wpb), per_wave * wpb, st);
@@ -688,6 +694,7 @@ void default_tuning(dexr_model* m) {
   t.pivot_rule = -1;
   t.longest_first = -1;
   t.fork_streams = -1;
+  t.sprint_max_batch = -1;
 }
 
 // A model in the generic table format (dexr_tables.h): validate every index the general kernel will follow, upload the
@@ -1135,6 +1142,7 @@ int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning) {
   if (t.chain < 0 || t.chain > 2) return fail(DEXR_ERR_INVALID, "chain must be 0 (never), 1 (serial-chain kernel + tip pass) or 2 (serial-chain kernel)");
   if (t.longest_first < -1 || t.longest_first > 2) return fail(DEXR_ERR_INVALID, "longest_first must be -1, 0, 1 or 2");
   if (t.fork_streams < -1 || t.fork_streams > 1) return fail(DEXR_ERR_INVALID, "fork_streams must be -1, 0 or 1");
+  if (t.sprint_max_batch < -1) return fail(DEXR_ERR_INVALID, "sprint_max_batch must be -1 (policy), 0 (off) or a batch size");
   if (t.persist_from < 0 || t.qchunk < 0 || t.persist_occ < 0 || t.resident_waves < 0 || t.max_blind < 0)
     return fail(DEXR_ERR_INVALID, "negative launch parameter");
   if (!(t.step_cap >= 0) || !(t.lam_jump >= 0) || !(t.lam_fastdec >= 0) || !(t.floor_scale >= 0) || !(t.blind_tol_scale >= 0) || !(t.lam_recover >= 0))

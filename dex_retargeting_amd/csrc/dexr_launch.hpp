@@ -83,6 +83,12 @@ hipError_t launch_wide_24(const KernelParams&, const WideTable*, dim3, dim3, siz
 hipError_t launch_wide_32(const KernelParams&, const WideTable*, dim3, dim3, size_t, hipStream_t);
 hipError_t launch_wide_m_16(const KernelParams&, const WideTable*, dim3, dim3, size_t, hipStream_t);  // mimic joints folded
 hipError_t launch_wide_mc_16(const KernelParams&, const WideTable*, dim3, dim3, size_t, hipStream_t);  // + modified Cholesky
+hipError_t launch_wide_s_16(const KernelParams&, const WideTable*, dim3, dim3, size_t, hipStream_t);  // one frame per wave (SPRINT)
+hipError_t launch_wide_s_24(const KernelParams&, const WideTable*, dim3, dim3, size_t, hipStream_t);
+hipError_t launch_wide_s_32(const KernelParams&, const WideTable*, dim3, dim3, size_t, hipStream_t);
+size_t wide_lds_per_wave_s_16();
+size_t wide_lds_per_wave_s_24();
+size_t wide_lds_per_wave_s_32();
 size_t wide_lds_per_wave_m_16();
 size_t wide_lds_per_wave_mc_16();
 size_t wide_lds_per_wave_16();
@@ -90,6 +96,9 @@ size_t wide_lds_per_wave_24();
 size_t wide_lds_per_wave_32();
 static inline wide_launch_fn find_wide_launcher(int bucket) {
   return bucket == 16 ? launch_wide_16 : bucket == 24 ? launch_wide_24 : bucket == 32 ? launch_wide_32 : nullptr;
+}
+static inline wide_launch_fn find_wide_sprint_launcher(int bucket) {
+  return bucket == 16 ? launch_wide_s_16 : bucket == 24 ? launch_wide_s_24 : bucket == 32 ? launch_wide_s_32 : nullptr;
 }
 static inline size_t wide_lds_per_wave(int bucket) {
   return bucket == 16 ? wide_lds_per_wave_16() : bucket == 24 ? wide_lds_per_wave_24() : bucket == 32 ? wide_lds_per_wave_32() : 0;

@@ -158,11 +158,20 @@ struct WideLds {
   static constexpr int WAVE = SLOT0 + 4 * SLOT;
 };
 
-template <int NMAX, bool MIMIC, bool MODCHOL>
+// SPRINT (round 5; joint-space grids): ONE FRAME PER WAVE -- the launch shape of small batches (the reference's one-frame-per-
+// call loop above all), where a wave's four rows would otherwise hold one frame and three idle copies of the instruction
+// stream.  All four rows hold the SAME frame and run kinematics, terms, factorisation and the step logic redundantly (identical
+// instructions on identical inputs: identical bits, no exchange needed), but the TERM LOOP -- 40 % of a DexPilot pass -- is split:
+// row s forms the columns and outer products of terms s, s + 4, ... and the partial Hessians / gradients / second-order vectors
+// are summed across the rows by an xor butterfly (ds_bpermute, lane ^ 16, lane ^ 32: every row ends with the same bits).  Same
+// damping rules, same sequence of trial points up to the summation order of the Hessian; only row 0 writes results.
+template <int NMAX, bool MIMIC, bool MODCHOL, bool SPRINT = false>
 __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const KernelParams kp, const dexr_comp_table* __restrict__ comps,
                                                                          const WideTable* __restrict__ wtabs) {
   static_assert(NMAX == 16 || NMAX == 24 || NMAX == 32, "bucket");
   static_assert(!MIMIC || NMAX == 16, "the variable grid of the mimic kernel has 16 rows");
+  static_assert(!SPRINT || !MIMIC, "one frame per wave: joint-space grids only");
+  constexpr int FPW = SPRINT ? 1 : 4;  // frames a wave holds at a time
   using L = WideLds<NMAX, MIMIC>;
   constexpr int NJ = L::NJ;
   constexpr int NR = NMAX / 4;
@@ -806,7 +815,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     // hands; the pass is bound by LDS round trips, not by VALU issue.)
     const int nrow = per_coord ? 3 : 4;  // SmoothL1 per coordinate has no rank-one row
     // columns of term t -> gradient / second-order accumulators and the term's weighted Jacobian rows in buffer `buf`
-    auto publish = [&](int t) {
+    auto publish = [&](int t, bool on) {  // on: SPRINT rows beyond the last term of their share contribute zero columns
       float* JRw = JRl;
       const float* T = TBl + t * 16;
       const float4 t0 = *reinterpret_cast<const float4*>(T);
@@ -880,8 +889,9 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         // both joint slots of the lane (l, l + 16) at once in packed float32 arithmetic (v_pk_*): the two columns are
         // the same formula on different operands, and a pass is bound by the number of VALU instructions issued.
         //   v = in_t (p_task - o) - in_o (p_origin - o);  column = a x v (revolute)  |  (in_t - in_o) a (prismatic)
-        const wv2 ft = wv2{(float)((mt >> l) & 1u), (float)((mt >> (l + 16)) & 1u)} * jm2;
-        const wv2 fo = wv2{(float)((mo >> l) & 1u), (float)((mo >> (l + 16)) & 1u)} * jm2;
+        const wv2 jmv = (SPRINT && !on) ? wv2{0.f, 0.f} : jm2;
+        const wv2 ft = wv2{(float)((mt >> l) & 1u), (float)((mt >> (l + 16)) & 1u)} * jmv;
+        const wv2 fo = wv2{(float)((mo >> l) & 1u), (float)((mo >> (l + 16)) & 1u)} * jmv;
         const wv2 sg = ft - fo;
         wv2 v[3], c[3];
         v[0] = ft * t2.x - fo * t3.x - sg * jog2[0];
@@ -913,7 +923,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
           const int k = jo_[s];
           const bool in_t = (mt >> k) & 1u, in_o = (mo >> k) & 1u;
           float c0 = 0, c1 = 0, c2 = 0;
-          if (jopt[s] && (in_t || in_o)) {
+          if (jopt[s] && (in_t || in_o) && (!SPRINT || on)) {
             if (jrev[s]) {
               float v0 = 0, v1 = 0, v2 = 0;
               if (in_t) { v0 += t2.x - jog[s][0]; v1 += t2.y - jog[s][1]; v2 += t2.z - jog[s][2]; }
@@ -971,14 +981,29 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     // barrier per term, no exposed LDS write -> read latency -- changed nothing: tools/prof_wide_stages.sh shows the same
     // cycles per pass for a lone wave and for two waves per SIMD, i.e. a pass is bound by the wave's own instruction
     // issue (~8 cycles per dependent VALU instruction), not by LDS round trips.  Fewer instructions is what helps.)
+    if (SPRINT) {
+      const int ntq = (nt + 3) >> 2;  // row s: terms s, s + 4, ...
 #pragma clang loop unroll(disable) vectorize(disable)
-    for (int t = 0; t < nt; ++t) {
-      publish(t);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      outer();
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      for (int tq = 0; tq < ntq; ++tq) {
+        const int t = 4 * tq + slot;
+        const bool on = t < nt;
+        publish(on ? t : 0, on);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        outer();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else {
+#pragma clang loop unroll(disable) vectorize(disable)
+      for (int t = 0; t < nt; ++t) {
+        publish(t, true);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        outer();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
     }
 
     if (!MIMIC && NJ2 == 2) {
@@ -991,6 +1016,29 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         jcf[0][i] += jcf2[i].x;
         jcf[S1][i] += jcf2[i].y;
       }
+    }
+    if (SPRINT) {
+      // the rows' partial sums -> every row: v + v(lane ^ 16), then + (lane ^ 32).  Both partners of an exchange add the same
+      // two numbers, so the four rows end with identical bits (the redundant stages after this stay in lockstep).
+      const int x16 = (lane ^ 16) << 2, x32 = (lane ^ 32) << 2;
+      auto xsum = [&](float v) -> float {
+        v += __int_as_float(__builtin_amdgcn_ds_bpermute(x16, __float_as_int(v)));
+        v += __int_as_float(__builtin_amdgcn_ds_bpermute(x32, __float_as_int(v)));
+        return v;
+      };
+#pragma unroll
+      for (int s2 = 0; s2 < NJ2; ++s2) {
+        gnew[s2] = xsum(gnew[s2]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) jcf[s2][i] = xsum(jcf[s2][i]);
+      }
+#pragma unroll
+      for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j <= i / 2; ++j) {
+          Hn[i][j].x = xsum(Hn[i][j].x);
+          Hn[i][j].y = xsum(Hn[i][j].y);
+        }
     }
     WPROF_STAGE(3)
     // (4) second-order kinematic term: H[r][c] += a_c . CF_r for every revolute ancestor-or-self c of r
@@ -1185,8 +1233,8 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   double F = 0;
   float smax = 0, pred = 0;
   bool ok = true;
-  unsigned pool_next = (unsigned)((tile * 4 < (int64_t)kp.q0 && tile * 4 < nB) ? tile * 4 : 0);
-  unsigned pool_end = (unsigned)((tile * 4 < (int64_t)kp.q0 && tile * 4 < nB) ? ((tile * 4 + 4 < nB) ? tile * 4 + 4 : nB) : 0);
+  unsigned pool_next = (unsigned)((tile * FPW < (int64_t)kp.q0 && tile * FPW < nB) ? tile * FPW : 0);
+  unsigned pool_end = (unsigned)((tile * FPW < (int64_t)kp.q0 && tile * FPW < nB) ? ((tile * FPW + FPW < nB) ? tile * FPW + FPW : nB) : 0);
   bool dry = false;
   unsigned* queue = kp.queue + comp;
   auto reset_state = [&]() {
@@ -1219,7 +1267,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       if (pool_next >= pool_end && !dry) {
         // take exactly as many frames as there are idle rows: a frame parked in this wave's pool while its other rows
         // are busy would start late (near the end of the queue other waves' rows are idle by then)
-        const unsigned nwant = (unsigned)__popcll(want) >> 4;
+        const unsigned nwant = SPRINT ? 1u : (unsigned)__popcll(want) >> 4;  // (SPRINT: the four rows are idle together)
         unsigned base = 0;
         // (static tiles cover the batch: nothing to draw, the counter -- which such launches do not reset -- is not touched)
         const bool no_queue = (int64_t)kp.q0 >= kp.B;
@@ -1234,9 +1282,9 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       }
       if (pool_next < pool_end) {
         const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
-        const unsigned cand = pool_next + ((below - (unsigned)l) >> 4);
+        const unsigned cand = SPRINT ? pool_next : pool_next + ((below - (unsigned)l) >> 4);  // (SPRINT: one frame, every row)
         const bool got = !active && cand < pool_end;
-        pool_next += (unsigned)__popcll(__ballot(got)) >> 4;
+        pool_next += SPRINT ? (__ballot(got) != 0ull ? 1u : 0u) : (unsigned)__popcll(__ballot(got)) >> 4;
         if (got) {
           load_frame((int64_t)cand, 0);
           load_target();
@@ -1447,16 +1495,17 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         if (jopt[s]) badl = badl || !(xacc[s] == xacc[s]);
       const bool bad = row_max(badl ? 1.f : 0.f) > 0.f;
       if (bad) status = ST_FALLBACK;
+      const bool writer = !SPRINT || slot == 0;  // (SPRINT: the four rows hold the same answer)
 #pragma unroll
       for (int s = 0; s < NJ2; ++s)
-        if (jopt[s]) {
+        if (jopt[s] && writer) {
           const float v = bad ? XLl[jo_[s]] : xacc[s];
           const int api = tb.api[jsel(s)];
           const int64_t irow = f_irow();
           kp.qout[irow * ld + api] = v;
           if (kp.qout64) kp.qout64[irow * ld + api] = (double)v;
         }
-      if (l == 0) {
+      if (l == 0 && writer) {
         const int64_t irow = f_irow();
         if (kp.status) atomicMax(&kp.status[irow], status);
 #ifdef DEXR_WIDE_DIAG
@@ -1473,7 +1522,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         load_target();
         reset_state();
       } else {
-        if (l == 0 && dexpilot && kp.state && comp == 0) kp.state[f_lrow()] = f_nst();
+        if (l == 0 && writer && dexpilot && kp.state && comp == 0) kp.state[f_lrow()] = f_nst();
         active = false;
         done = true;
       }

@@ -115,6 +115,12 @@ typedef struct dexr_tuning {
                            earlier override is dropped.  (Until round 3 an override was inferred from "differs from the
                            reported value", which pinned stale values of re-used structs and made defaults sticky.)
                            A caller whose (older) struct ends before this field leaves the override state untouched.   */
+  int32_t sprint_max_batch; /* sixteen-lane kernel, joint-space grids (no mimic joints), plain batches: calls of at most this many
+                           frames run ONE FRAME PER WAVE -- the four rows of a wave share the frame's term loop instead of
+                           three of them idling (the reference's one-frame-per-call loop: Shadow DexPilot 0.20 -> 0.16 ms per
+                           retarget()).  Same damping rules and trial points up to the summation order of the Hessian: answers
+                           agree with the four-frames-per-wave launch to float32 solve accuracy, not bit for bit.  0 off;
+                           -1 measured policy (2 048: above that the chip has fewer wave slots than frames)           */
 } dexr_tuning;
 #define DEXR_TUNE_LAM_JUMP 1u
 #define DEXR_TUNE_LAM_FASTDEC 2u

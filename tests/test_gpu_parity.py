@@ -719,12 +719,22 @@ def test_mixed_fleet_equals_per_model_calls(B):
     out = out.cpu().numpy()
     for m, (seq, prob) in enumerate(builds):
         sel = mid == m
+        # a fleet bucket is walked four frames per wave whatever its size; a plain call of a few hundred frames of a
+        # joint-space model takes the one-frame-per-wave shape (dexr_tuning.sprint_max_batch), whose Hessian is summed in
+        # another order: bitwise equality against the same launch shape, float32 solve accuracy against the default one
+        opts[m].device_model().tune(sprint_max_batch=0)
         st = np.zeros(int(sel.sum()), np.uint32) if prob.kind == "dexpilot" else None
         want = opts[m].retarget_keypoints_batch(kp[sel], None, last[sel][:, : prob.n_opt], state=st)
         assert np.array_equal(out[sel][:, : prob.n_opt], want)
         assert np.all(out[sel][:, prob.n_opt:] == 0)
         if st is not None:
             assert np.array_equal(state.cpu().numpy()[sel].astype(np.uint32), st)
+        opts[m].device_model().tune(sprint_max_batch=-1)
+        st2 = np.zeros(int(sel.sum()), np.uint32) if prob.kind == "dexpilot" else None
+        want2 = opts[m].retarget_keypoints_batch(kp[sel], None, last[sel][:, : prob.n_opt], state=st2)
+        assert np.abs(want2 - want).max() < 2e-5
+        if st is not None:
+            assert np.array_equal(st2, st)
 
 
 # ---- fused T-frame sequence kernel + compose kernel ----------------------------------------
@@ -1024,6 +1034,50 @@ def test_longest_first_ordering_changes_the_schedule_not_the_answers():
     for lf in (1, 2, -1):
         for q, st, it in out[lf]:
             assert np.array_equal(q, out[0][0][0]) and np.array_equal(st, out[0][0][1]) and np.array_equal(it, out[0][0][2])
+
+
+@pytest.mark.parametrize("rel", ["teleop/shadow_hand_right_dexpilot.yml", "offline/leap_hand_right.yml", "teleop/shadow_hand_right.yml",
+                                 "teleop/allegro_hand_right_dexpilot.yml", "offline/shadow_hand_right.yml", "offline/panda_gripper.yml"])
+def test_one_frame_per_wave_launch_shape_agrees_with_four_per_wave_and_the_oracle(rel):
+    """dexr_tuning.sprint_max_batch (round 5): plain batches of up to 2 048 frames of a joint-space model on the sixteen-lane
+    kernel run one frame per wave -- the four rows of a wave share the frame's term loop (partial Hessians summed by an xor
+    butterfly) and run everything else redundantly.  Same damping rules and trial points up to the summation order: the same
+    iteration counts on (nearly) every frame, the same DexPilot state, answers within float32 solve accuracy of the
+    four-frames-per-wave launch and within 1e-4 rad of the float64 oracle; B = 1 (the reference's own calling pattern), a
+    batch that is not a multiple of anything, and the largest batch the policy sends that way."""
+    seq, prob = build(rel)
+    model = seq.optimizer.device_model()
+    assert model.kernel()[0] == _lib.KERNEL_WIDE
+    dex = prob.kind == "dexpilot"
+    for B in (1, 333, 2048):
+        kp = np.ascontiguousarray(cases.human_keypoints(B + 1, seed=cases.SEED + 3))
+        mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
+        st0 = np.zeros(B, np.uint32) if dex else None
+        model.tune(sprint_max_batch=0)
+        last = model.retarget(kp[:-1], None, mid, state=st0, keypoints=True)
+        res = {}
+        for name, smax in (("four", 0), ("one", -1)):
+            model.tune(sprint_max_batch=smax)
+            st = None if st0 is None else st0.copy()
+            q, info = model.retarget(kp[1:], None, last, state=st, keypoints=True, want_info=True)
+            res[name] = (q, info["iters"], info["status"], st)
+        model.tune(sprint_max_batch=-1)
+        (qa, ita, sa, sta), (qb, itb, sb, stb) = res["four"], res["one"]
+        assert (sa == 0).all() and (sb == 0).all()
+        assert np.abs(qa - qb).max() < 5e-5, (rel, B, np.abs(qa - qb).max())
+        assert (ita != itb).mean() <= 0.01, (rel, B, int((ita != itb).sum()))
+        if dex:
+            assert np.array_equal(sta, stb)
+        if B == 333:
+            ref = np.ascontiguousarray(cases.ref_from_keypoints(prob, kp[1:]), dtype=np.float32)
+            kw = {}
+            if dex:
+                proj = ((st0[:, None] >> np.arange(prob.n_pair, dtype=np.uint32)) & 1).astype(bool)
+                w, rv, _ = prob.dexpilot_preamble(ref, proj)
+                kw = dict(weights=w, dexpilot_ref=rv)
+            want = solvers.solve_lm_batched(prob, ref, None, last, newton=True, max_iter=100, **kw)
+            dq = np.abs(qb.astype(np.float64) - want).max(1)
+            assert (dq < 1e-4).mean() >= 0.99, (rel, float((dq < 1e-4).mean()))  # (human targets are multi-modal: see test_gpu_all_configs)
 
 
 @pytest.mark.parametrize("rel", ["teleop/allegro_hand_right.yml", "teleop/shadow_hand_right_dexpilot.yml"])
