@@ -147,6 +147,11 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         objs.append(o)
         if force or _stale(o, [wide_s, os.path.join(CSRC, "dexr_wide.hpp"), BIG_HEADER] + HEADERS):
             jobs.append((wide_s, o, NO_SLP + [f"-DDEXR_NMAX={n}", "-DDEXR_SPRINT=1"] + (["-DDEXR_WIDE_MINW=3"] if n == 16 else [])))
+    for tag, defs in (("s_m", ["-DDEXR_SPRINT=1"]), ("s_mc", ["-DDEXR_SPRINT=1", "-DDEXR_MODCHOL=1"])):  # ... on the variable grid
+        o = os.path.join(BUILD, f"dexr_wide_{tag}_16.o")
+        objs.append(o)
+        if force or _stale(o, [wide_s, os.path.join(CSRC, "dexr_wide.hpp"), BIG_HEADER] + HEADERS):
+            jobs.append((wide_s, o, NO_SLP + ["-DDEXR_NMAX=16", "-DDEXR_MIMIC=1"] + defs))
     for tag, defs in (("m", []), ("mc", ["-DDEXR_MODCHOL=1"])):  # the same kernel on the grid of the optimised variables
         o = os.path.join(BUILD, f"dexr_wide_{tag}_16.o")         # (mimic joints), plain / modified Cholesky
         objs.append(o)

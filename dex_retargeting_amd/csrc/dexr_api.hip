@@ -279,10 +279,10 @@ int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st)
   const size_t per_wave = m->wide_mimic ? dexr::wide_lds_per_wave_m_16() : dexr::wide_lds_per_wave(m->wbucket);
   int wpb = 4;
   while (wpb > 1 && per_wave * wpb > 80 * 1024) wpb >>= 1;
-  // ONE FRAME PER WAVE for small plain batches of the joint-space grids (dexr_wide.hpp SPRINT; dexr_tuning.sprint_max_batch):
+  // ONE FRAME PER WAVE for small plain batches (dexr_wide.hpp SPRINT; dexr_tuning.sprint_max_batch):
   // with fewer frames than the chip has row slots a wave's four rows share one frame's term loop instead of idling
   const int64_t sprint_max = m->tune.sprint_max_batch < 0 ? 2048 : m->tune.sprint_max_batch;  // (measured: it wins up to ~2 048 frames = one wave per frame on every SIMD pair, profiles/r05_sprint_one_frame_per_wave.txt)
-  const bool sprint = !m->wide_mimic && kp.B <= sprint_max && !kp.perm && !kp.bucket && kp.T == 0 && !kp.screen && kp.n_comp == 1;
+  const bool sprint = kp.B <= sprint_max && !kp.perm && !kp.bucket && kp.T == 0 && !kp.screen && kp.n_comp == 1;
   const int fpw = sprint ? 1 : 4;  // frames per wave
   const int64_t tiles = (kp.B + fpw - 1) / fpw;
   // waves per SIMD: 2 (256 VGPRs; 15-17 KB of LDS per wave); the 16-row joint grid is built for 3 (168 VGPRs, 11.8 KB):
@@ -314,7 +314,8 @@ int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st)
   (void)hipMemsetAsync(wprof, 0, 12 * sizeof(double), st);
   kp.g64out = wprof;
 #endif
-  dexr::wide_launch_fn fn = m->wide_mimic ? (m->wide_modchol ? dexr::launch_wide_mc_16 : dexr::launch_wide_m_16)
+  dexr::wide_launch_fn fn = m->wide_mimic ? (sprint ? (m->wide_modchol ? dexr::launch_wide_s_mc_16 : dexr::launch_wide_s_m_16)
+                                                    : (m->wide_modchol ? dexr::launch_wide_mc_16 : dexr::launch_wide_m_16))
                             : sprint      ? dexr::find_wide_sprint_launcher(m->wbucket)
                                           : dexr::find_wide_launcher(m->wbucket);
   if (!fn) return fail(DEXR_ERR_UNSUPPORTED, "no sixteen-lane kernel for bucket %d", m->wbucket);

@@ -86,6 +86,10 @@ hipError_t launch_wide_mc_16(const KernelParams&, const WideTable*, dim3, dim3, 
 hipError_t launch_wide_s_16(const KernelParams&, const WideTable*, dim3, dim3, size_t, hipStream_t);  // one frame per wave (SPRINT)
 hipError_t launch_wide_s_24(const KernelParams&, const WideTable*, dim3, dim3, size_t, hipStream_t);
 hipError_t launch_wide_s_32(const KernelParams&, const WideTable*, dim3, dim3, size_t, hipStream_t);
+hipError_t launch_wide_s_m_16(const KernelParams&, const WideTable*, dim3, dim3, size_t, hipStream_t);
+hipError_t launch_wide_s_mc_16(const KernelParams&, const WideTable*, dim3, dim3, size_t, hipStream_t);
+size_t wide_lds_per_wave_s_m_16();
+size_t wide_lds_per_wave_s_mc_16();
 size_t wide_lds_per_wave_s_16();
 size_t wide_lds_per_wave_s_24();
 size_t wide_lds_per_wave_s_32();

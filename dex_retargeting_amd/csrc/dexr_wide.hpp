@@ -158,7 +158,7 @@ struct WideLds {
   static constexpr int WAVE = SLOT0 + 4 * SLOT;
 };
 
-// SPRINT (round 5; joint-space grids): ONE FRAME PER WAVE -- the launch shape of small batches (the reference's one-frame-per-
+// SPRINT (round 5; every grid): ONE FRAME PER WAVE -- the launch shape of small batches (the reference's one-frame-per-
 // call loop above all), where a wave's four rows would otherwise hold one frame and three idle copies of the instruction
 // stream.  All four rows hold the SAME frame and run kinematics, terms, factorisation and the step logic redundantly (identical
 // instructions on identical inputs: identical bits, no exchange needed), but the TERM LOOP -- 40 % of a DexPilot pass -- is split:
@@ -170,7 +170,6 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
                                                                          const WideTable* __restrict__ wtabs) {
   static_assert(NMAX == 16 || NMAX == 24 || NMAX == 32, "bucket");
   static_assert(!MIMIC || NMAX == 16, "the variable grid of the mimic kernel has 16 rows");
-  static_assert(!SPRINT || !MIMIC, "one frame per wave: joint-space grids only");
   constexpr int FPW = SPRINT ? 1 : 4;  // frames a wave holds at a time
   using L = WideLds<NMAX, MIMIC>;
   constexpr int NJ = L::NJ;
@@ -830,8 +829,9 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         // third family joint takes the scalar path.
         float c0, c1, c2;
         {
-          const wv2 ft = wv2{(float)((mt >> fk2x) & 1u), (float)((mt >> fk2y) & 1u)} * fon2;
-          const wv2 fo = wv2{(float)((mo >> fk2x) & 1u), (float)((mo >> fk2y) & 1u)} * fon2;
+          const wv2 fonv = (SPRINT && !on) ? wv2{0.f, 0.f} : fon2;
+          const wv2 ft = wv2{(float)((mt >> fk2x) & 1u), (float)((mt >> fk2y) & 1u)} * fonv;
+          const wv2 fo = wv2{(float)((mo >> fk2x) & 1u), (float)((mo >> fk2y) & 1u)} * fonv;
           const wv2 sg = ft - fo;
           wv2 v[3], d[3];
           v[0] = ft * t2.x - fo * t3.x - sg * jog2[0];
@@ -857,8 +857,8 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         for (int e = 2; e < FAM; ++e) {
           if (e < fam_max) {
             const int k = famk[e] >= 0 ? famk[e] : 0;
-            const bool on = famk[e] >= 0;
-            const bool in_t = on && ((mt >> k) & 1u), in_o = on && ((mo >> k) & 1u);
+            const bool fam_on = famk[e] >= 0 && (!SPRINT || on);
+            const bool in_t = fam_on && ((mt >> k) & 1u), in_o = fam_on && ((mo >> k) & 1u);
             float d0 = 0, d1 = 0, d2 = 0;
             if (in_t || in_o) {
               if ((revmask >> k) & 1u) {
@@ -1027,11 +1027,11 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         return v;
       };
 #pragma unroll
-      for (int s2 = 0; s2 < NJ2; ++s2) {
-        gnew[s2] = xsum(gnew[s2]);
+      for (int s2 = 0; s2 < NJ2; ++s2) gnew[s2] = xsum(gnew[s2]);
+#pragma unroll
+      for (int s2 = 0; s2 < NCOL; ++s2)
 #pragma unroll
         for (int i = 0; i < 3; ++i) jcf[s2][i] = xsum(jcf[s2][i]);
-      }
 #pragma unroll
       for (int i = 0; i < NR; ++i)
 #pragma unroll

@@ -19,7 +19,11 @@ namespace dexr {
 #ifndef DEXR_SPRINT
 #define DEXR_SPRINT 0
 #endif
-#if DEXR_MIMIC && DEXR_MODCHOL
+#if DEXR_MIMIC && DEXR_MODCHOL && DEXR_SPRINT
+#define DEXR_WNAME(base) base##s_mc_16
+#elif DEXR_MIMIC && DEXR_SPRINT
+#define DEXR_WNAME(base) base##s_m_16
+#elif DEXR_MIMIC && DEXR_MODCHOL
 #define DEXR_WNAME(base) base##mc_16
 #elif DEXR_MIMIC
 #define DEXR_WNAME(base) base##m_16

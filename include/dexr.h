@@ -115,7 +115,7 @@ typedef struct dexr_tuning {
                            earlier override is dropped.  (Until round 3 an override was inferred from "differs from the
                            reported value", which pinned stale values of re-used structs and made defaults sticky.)
                            A caller whose (older) struct ends before this field leaves the override state untouched.   */
-  int32_t sprint_max_batch; /* sixteen-lane kernel, joint-space grids (no mimic joints), plain batches: calls of at most this many
+  int32_t sprint_max_batch; /* sixteen-lane kernel, plain batches of a single-component model: calls of at most this many
                            frames run ONE FRAME PER WAVE -- the four rows of a wave share the frame's term loop instead of
                            three of them idling (the reference's one-frame-per-call loop: Shadow DexPilot 0.20 -> 0.16 ms per
                            retarget()).  Same damping rules and trial points up to the summation order of the Hessian: answers

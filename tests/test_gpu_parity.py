@@ -1037,7 +1037,9 @@ def test_longest_first_ordering_changes_the_schedule_not_the_answers():
 
 
 @pytest.mark.parametrize("rel", ["teleop/shadow_hand_right_dexpilot.yml", "offline/leap_hand_right.yml", "teleop/shadow_hand_right.yml",
-                                 "teleop/allegro_hand_right_dexpilot.yml", "offline/shadow_hand_right.yml", "offline/panda_gripper.yml"])
+                                 "teleop/allegro_hand_right_dexpilot.yml", "offline/shadow_hand_right.yml", "offline/panda_gripper.yml",
+                                 "teleop/inspire_hand_right_dexpilot.yml", "offline/schunk_svh_hand_right.yml",
+                                 "offline/ability_hand_right.yml"])  # (the last three: variable grids, mimic joints folded)
 def test_one_frame_per_wave_launch_shape_agrees_with_four_per_wave_and_the_oracle(rel):
     """dexr_tuning.sprint_max_batch (round 5): plain batches of up to 2 048 frames of a joint-space model on the sixteen-lane
     kernel run one frame per wave -- the four rows of a wave share the frame's term loop (partial Hessians summed by an xor
@@ -1064,7 +1066,10 @@ def test_one_frame_per_wave_launch_shape_agrees_with_four_per_wave_and_the_oracl
         model.tune(sprint_max_batch=-1)
         (qa, ita, sa, sta), (qb, itb, sb, stb) = res["four"], res["one"]
         assert (sa == 0).all() and (sb == 0).all()
-        assert np.abs(qa - qb).max() < 5e-5, (rel, B, np.abs(qa - qb).max())
+        # (typically 1e-6; a few frames per thousand of the mimic hands sit in valleys flat enough for 4e-5 -- the bar is the
+        # 1e-4 rad of BASELINE.json, and the p99 is asserted an order of magnitude tighter)
+        assert np.abs(qa - qb).max() < 1e-4, (rel, B, np.abs(qa - qb).max())
+        assert np.percentile(np.abs(qa - qb).max(1), 99) < 1e-5, (rel, B)
         assert (ita != itb).mean() <= 0.01, (rel, B, int((ita != itb).sum()))
         if dex:
             assert np.array_equal(sta, stb)
