@@ -146,7 +146,9 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(BUILD, f"dexr_wide_s_{n}.o")
         objs.append(o)
         if force or _stale(o, [wide_s, os.path.join(CSRC, "dexr_wide.hpp"), BIG_HEADER] + HEADERS):
-            jobs.append((wide_s, o, NO_SLP + [f"-DDEXR_NMAX={n}", "-DDEXR_SPRINT=1"] + (["-DDEXR_WIDE_MINW=3"] if n == 16 else [])))
+            # (register budgets: two waves per SIMD for the 16- / 24-row grids (246 / 256 registers, 3 spilled at n = 24), one for
+            # the 32-row grid (272): small batches do not need the occupancy)
+            jobs.append((wide_s, o, NO_SLP + [f"-DDEXR_NMAX={n}", "-DDEXR_SPRINT=1", "-DDEXR_WIDE_MINW=1" if n == 32 else "-DDEXR_WIDE_MINW=2"]))
     for tag, defs in (("s_m", ["-DDEXR_SPRINT=1"]), ("s_mc", ["-DDEXR_SPRINT=1", "-DDEXR_MODCHOL=1"])):  # ... on the variable grid
         o = os.path.join(BUILD, f"dexr_wide_{tag}_16.o")
         objs.append(o)

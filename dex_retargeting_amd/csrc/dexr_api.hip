@@ -284,12 +284,18 @@ int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st)
   const int64_t sprint_max = m->tune.sprint_max_batch < 0 ? 2048 : m->tune.sprint_max_batch;  // (measured: it wins up to ~2 048 frames = one wave per frame on every SIMD pair, profiles/r05_sprint_one_frame_per_wave.txt)
   const bool sprint = kp.B <= sprint_max && !kp.perm && !kp.bucket && kp.T == 0 && !kp.screen && kp.n_comp == 1;
   const int fpw = sprint ? 1 : 4;  // frames per wave
+  {
+    const bool ladder = sprint && m->tune.sprint_ladder != 0;  // (-1: policy = on)
+    const float mu_on[4] = {0.03f, 0.3f, 3.f, 30.f};
+    for (int r = 0; r < 4; ++r) kp.sprint_mu[r] = ladder ? mu_on[r] : 1.f;
+  }
   const int64_t tiles = (kp.B + fpw - 1) / fpw;
   // waves per SIMD: 2 (256 VGPRs; 15-17 KB of LDS per wave); the 16-row joint grid is built for 3 (168 VGPRs, 11.8 KB):
   // LEAP DexPilot 1.24 -> 1.14 ms, Allegro DexPilot 0.84 -> 0.75 ms
   // (the 24-row grid at three waves per SIMD -- 168 VGPRs, 85 registers spilled -- measured 34-40 % SLOWER in round 4, with the
   // LDS slot shrunk to make room for it: DESIGN.md section 4)
-  const int occ = (!m->wide_mimic && m->wbucket == 16) ? 3 : 2;
+  // (one frame per wave: the 32-row grid is built for one wave per SIMD -- dexr_wide_s_* in _build.py -- the others for two)
+  const int occ = sprint ? ((!m->wide_mimic && m->wbucket > 24) ? 1 : 2) : ((!m->wide_mimic && m->wbucket == 16) ? 3 : 2);
   int64_t resident = (int64_t)m->n_cu * 4 * occ;
   if (m->tune.resident_waves > 0) resident = m->tune.resident_waves;
   int64_t per_comp = (resident + kp.n_comp - 1) / kp.n_comp;
@@ -696,6 +702,7 @@ void default_tuning(dexr_model* m) {
   t.longest_first = -1;
   t.fork_streams = -1;
   t.sprint_max_batch = -1;
+  t.sprint_ladder = -1;
 }
 
 // A model in the generic table format (dexr_tables.h): validate every index the general kernel will follow, upload the
@@ -1144,6 +1151,7 @@ int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning) {
   if (t.longest_first < -1 || t.longest_first > 2) return fail(DEXR_ERR_INVALID, "longest_first must be -1, 0, 1 or 2");
   if (t.fork_streams < -1 || t.fork_streams > 1) return fail(DEXR_ERR_INVALID, "fork_streams must be -1, 0 or 1");
   if (t.sprint_max_batch < -1) return fail(DEXR_ERR_INVALID, "sprint_max_batch must be -1 (policy), 0 (off) or a batch size");
+  if (t.sprint_ladder < -1 || t.sprint_ladder > 1) return fail(DEXR_ERR_INVALID, "sprint_ladder must be -1, 0 or 1");
   if (t.persist_from < 0 || t.qchunk < 0 || t.persist_occ < 0 || t.resident_waves < 0 || t.max_blind < 0)
     return fail(DEXR_ERR_INVALID, "negative launch parameter");
   if (!(t.step_cap >= 0) || !(t.lam_jump >= 0) || !(t.lam_fastdec >= 0) || !(t.floor_scale >= 0) || !(t.blind_tol_scale >= 0) || !(t.lam_recover >= 0))

@@ -98,6 +98,10 @@ struct KernelParams {
   int32_t T;                           // frames per sequence; 0 = independent frames (no clipping of `last`)
   int64_t seq_stride;                  // rows between consecutive frames of one sequence
   float clip_eps;
+  // One-frame-per-wave launches of the sixteen-lane kernel (dexr_wide.hpp SPRINT): damping multiplier of each of the wave's four
+  // rows -- {1, 1, 1, 1}: the rows are copies of one iteration; a ladder such as {0.03, 0.3, 3, 30}: every pass tries four
+  // damping values from the accepted point and keeps the best acceptable trial point (dexr_tuning.sprint_ladder).
+  float sprint_mu[4];
 };
 
 // Per-component side table of the sixteen-lanes-per-frame kernel (dexr_wide.hpp), derived from the component's table by

@@ -695,6 +695,10 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   // ---- value / gradient (own joints) / Hessian grid at the kinematic state in LDS ------------------------------------
   float gnew[NJ2];
   wv2 Hn[NR][NP];
+  // SPRINT assembles a model only at a point it has already decided to keep: the new Hessian is accumulated straight into the
+  // accepted one's registers (36 fewer live registers at n = 24 than with a separate Hn; four frames per wave need both, the
+  // decision comes after the assembly there)
+  wv2 (&Hx)[NR][NP] = SPRINT ? Ha : Hn;
   // (1) lane t evaluates term t; returns F (identical in the 16 lanes of the row)
   auto terms = [&]() -> double {
     double Fv = 0;
@@ -766,10 +770,8 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     __builtin_amdgcn_wave_barrier();
     return Fv;
   };
-  auto assemble = [&]() -> double {
-    const double Fv = terms();
-    WPROF_STAGE(2)
-
+  // gradient (own joints) and Hessian grid of the data term at the kinematic state / term blocks the slot pointers address
+  auto model_rest = [&]() {
     // (2) own joints' axes / origins; accumulators of the pass: data-term gradient and second-order vector
     constexpr int NCOL = MIMIC ? FAM : NJ2;  // joints whose columns this lane forms
     float jax[NCOL][3], jog[NCOL][3], jcf[NCOL][3];
@@ -787,7 +789,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 #pragma unroll
     for (int i = 0; i < NR; ++i)
 #pragma unroll
-      for (int j = 0; j < NP; ++j) Hn[i][j] = wv2{0.f, 0.f};
+      for (int j = 0; j < NP; ++j) Hx[i][j] = wv2{0.f, 0.f};
     // packed views of the two joint slots (NJ2 == 2, joint-space grids): axes / origins, accumulators, per-lane masks
     constexpr int S1 = (MIMIC || NJ2 == 2) ? 1 : 0;  // (MIMIC: family joints 0 and 1 of the lane's variable)
     wv2 jax2[3], jog2[3], jcf2[3], gnew2 = wv2{0.f, 0.f};
@@ -972,7 +974,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
             const float ri = kk == 3 ? -jr[i] : jr[i];
             const wv2 rr = wv2{ri, ri};
 #pragma unroll
-            for (int jj = 0; jj <= i / 2; ++jj) Hn[i][jj] = __builtin_elementwise_fma(rr, jc[jj], Hn[i][jj]);
+            for (int jj = 0; jj <= i / 2; ++jj) Hx[i][jj] = __builtin_elementwise_fma(rr, jc[jj], Hx[i][jj]);
           }
         }
       }
@@ -1036,8 +1038,8 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       for (int i = 0; i < NR; ++i)
 #pragma unroll
         for (int j = 0; j <= i / 2; ++j) {
-          Hn[i][j].x = xsum(Hn[i][j].x);
-          Hn[i][j].y = xsum(Hn[i][j].y);
+          Hx[i][j].x = xsum(Hx[i][j].x);
+          Hx[i][j].y = xsum(Hx[i][j].y);
         }
     }
     WPROF_STAGE(3)
@@ -1078,7 +1080,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 #pragma unroll
         for (int j = 0; j <= i; ++j) {
           const float add = HBl[i * (i + 1) / 2 + j];
-          if (j & 1) Hn[i][j / 2].y += add; else Hn[i][j / 2].x += add;
+          if (j & 1) Hx[i][j / 2].y += add; else Hx[i][j / 2].x += add;
         }
     }
     if (newton && !MIMIC) {
@@ -1097,10 +1099,15 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         for (int j = 0; j <= i; ++j) {
           const float v = axc[j].x * cf.x + axc[j].y * cf.y + axc[j].z * cf.z;
           const float add = ((ANCw[4 * i + a] >> (4 * j + b)) & 1u) ? v : 0.f;
-          if (j & 1) Hn[i][j / 2].y += add; else Hn[i][j / 2].x += add;
+          if (j & 1) Hx[i][j / 2].y += add; else Hx[i][j / 2].x += add;
         }
       }
     }
+  };
+  auto assemble = [&]() -> double {
+    const double Fv = terms();
+    WPROF_STAGE(2)
+    model_rest();
     return Fv;
   };
 
@@ -1255,6 +1262,10 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     ok = true;
   };
   float screen_acc = 0.f;  // screening launch: sum of F(x0) over the frames of this wave (lane 0 of each row)
+  // SPRINT: the rows' damping multipliers (the ladder; all 1: the rows are copies) -- read once, selected by row where needed
+  const float mu_0 = SPRINT ? kp.sprint_mu[0] : 1.f, mu_1 = SPRINT ? kp.sprint_mu[1] : 1.f, mu_2 = SPRINT ? kp.sprint_mu[2] : 1.f,
+              mu_3 = SPRINT ? kp.sprint_mu[3] : 1.f;
+  const float mu_own = slot == 0 ? mu_0 : slot == 1 ? mu_1 : slot == 2 ? mu_2 : mu_3;
   for (;;) {
     // the lane's grid coordinates, made opaque once per pass: predicates on them (a == 2, b <= a, ...) are then recomputed
     // where they are used (one v_cmp) instead of being hoisted out of the loop as 64-bit lane masks -- dozens of SGPR pairs
@@ -1313,10 +1324,14 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       }
       continue;
     }
-    const double Fe = assemble();
+    // SPRINT evaluates the VALUE first and the model only at the point it keeps: with a ladder of damping values the four rows
+    // hold four different trial points (own kinematic state and term blocks in the row's own frame slot), the best acceptable one
+    // wins, and the split term loop then runs on the winner's slot; a pass whose steps are all rejected assembles nothing.
+    double Fe = SPRINT ? terms() : assemble();
     WPROF_STAGE(4)
     if (!done) {
       bool take = false;
+      int wrow = slot;  // SPRINT: the row whose trial point is kept
       if (!pending) {
         F = Fe;
         take = true;
@@ -1324,9 +1339,52 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         // (float: the float64 product kept (double) floor_scale alive across the pass loop, in scratch; pred is a float anyway)
         const float noise = kp.floor_scale * fabsf((float)F);
         // (bitwise, not short-circuit: `&&` / `||` on lane-varying conditions compile to nested exec-mask branches)
-        const bool finite = (bool)((int)(Fe == Fe) & (int)(smax == smax) & (int)(fabs(Fe) < 1e30));
-        const bool below_floor = (bool)((int)ok & (int)finite & (int)(pred <= noise) & (int)(smax < 1e-2f));
-        const bool accept = (bool)((int)(ok || MODCHOL) & (int)finite & ((int)(Fe <= F) | (int)below_floor));
+        bool finite = (bool)((int)(Fe == Fe) & (int)(smax == smax) & (int)(fabs(Fe) < 1e30));
+        bool below_floor = (bool)((int)ok & (int)finite & (int)(pred <= noise) & (int)(smax < 1e-2f));
+        bool accept = (bool)((int)(ok || MODCHOL) & (int)finite & ((int)(Fe <= F) | (int)below_floor));
+        if (SPRINT) {
+          // the four rows' candidates: the acceptable one with the lowest value wins (ties: the least damped); its trial point,
+          // value and step statistics replace every row's own, and `lam` becomes the damping it was computed with.  No row
+          // acceptable: a rejection from the LARGEST damping tried (row 3 holds it, and the curvature along its step).
+          const double score = accept ? Fe : 1e300;
+          double sc[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            sc[r] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(score), 16 * r), __builtin_amdgcn_readlane(__double2loint(score), 16 * r));
+          int w = 0;
+          double best = sc[0];
+#pragma unroll
+          for (int r = 1; r < 4; ++r)
+            if (sc[r] < best) { best = sc[r]; w = r; }
+          const bool any_ok = best < 1e300;
+          // "every row's step was tiny, verified and finite": the rejection-at-the-floor exit needs it of all four
+          const bool small_own = (bool)((int)(ok || MODCHOL) & (int)finite & (int)(smax < kp.tol));
+          const bool all_small = __ballot(small_own) == ~0ull;
+          const bool all_finite = __ballot(finite) == ~0ull;
+          if (any_ok) {
+            const int src = (16 * w + l) << 2;
+#pragma unroll
+            for (int s2 = 0; s2 < NJ2; ++s2) xj[s2] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(xj[s2])));
+            pred = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(pred)));
+            smax = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(smax)));
+            const int flags = __builtin_amdgcn_ds_bpermute(src, (int)ok | ((int)below_floor << 1));
+            ok = (bool)(flags & 1);
+            below_floor = (bool)((flags >> 1) & 1);
+            Fe = best;
+            finite = true;
+            accept = true;
+            lam = lam * (w == 0 ? mu_0 : w == 1 ? mu_1 : w == 2 ? mu_2 : mu_3);
+            wrow = w;
+          } else {
+            accept = false;
+            lam = lam * mu_3;
+            keff = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(keff), 48));
+            hdmean = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hdmean), 48));
+            ok = all_small;       // (only read by the exit test of the rejection branch below, together with:)
+            finite = all_finite;
+            smax = all_small ? 0.f : 1e30f;
+          }
+        }
         ++my_iters;
         pending = false;
         if (accept) {
@@ -1369,16 +1427,29 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         }
         done = (bool)((int)done | (int)(my_iters >= kp.max_iter));
       }
+      if (SPRINT && __any(take)) {
+        // the model at the kept point: its kinematic state and term blocks lie in the frame slot of the row that evaluated it
+        const int ws = __builtin_amdgcn_readfirstlane(wrow);
+        unsigned char* wb = wbase + L::SLOT0 + (size_t)ws * L::SLOT;
+        float *AXo = AXl, *OGo = OGl, *TBo = TBl;
+        AXl = reinterpret_cast<float*>(wb + L::AX);
+        OGl = reinterpret_cast<float*>(wb + L::OG);
+        TBl = reinterpret_cast<float*>(wb + L::TB);
+        model_rest();
+        AXl = AXo; OGl = OGo; TBl = TBo;
+      }
       if (take) {  // the evaluated point becomes the accepted point: keep its gradient and Hessian
 #pragma unroll
         for (int s = 0; s < NJ2; ++s) {
           xacc[s] = xj[s];
           if (jin[s]) GVl[jo_[s]] = jopt[s] ? gnew[s] + 2.f * delta * (xj[s] - XLl[jo_[s]]) : 0.f;
         }
+        if (!SPRINT) {
 #pragma unroll
-        for (int i = 0; i < NR; ++i)
+          for (int i = 0; i < NR; ++i)
 #pragma unroll
-          for (int j = 0; j <= i / 2; ++j) Ha[i][j] = Hn[i][j];
+            for (int j = 0; j <= i / 2; ++j) Ha[i][j] = Hn[i][j];
+        }
       }
     }
     // active set of the accepted point, gathered from the 16 lanes of the row
@@ -1412,9 +1483,11 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     bool okf = true;
 #pragma clang loop unroll(disable)
     for (int attempt = 0;; ++attempt) {
-      okf = factor_and_solve(freemask, lam);
+      okf = factor_and_solve(freemask, lam * mu_own);
       // (not at n = 32: the loop around the 32 x 32 factorisation costs 60 more spilled registers, +16 % per launch)
-      const bool retry = !MODCHOL && NMAX <= 24 && attempt < 3 && !done && !okf;  // (uniform over the row's 16 lanes)
+      // (SPRINT: a row whose damped model is indefinite is simply not a candidate; only when NO row has a step is the damping
+      // raised here, for all of them, from the largest value tried)
+      const bool retry = !MODCHOL && NMAX <= 24 && attempt < 3 && !done && (SPRINT ? __ballot(okf) == 0ull : !okf);  // (uniform over the row's 16 lanes)
       if (!__any(retry)) break;
       if (retry) {
         float gdl = 0.f, ddl = 0.f;
@@ -1427,6 +1500,10 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         }
         const float gd = row_sum(gdl), dd = row_sum(ddl);
         keff = gd / fmaxf(dd, 1e-30f);
+        if (SPRINT) {  // (row 3: the largest damping of the ladder)
+          keff = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(keff), 48));
+          lam = lam * mu_3;
+        }
         ++my_iters;
         WDIAG(++d_nrej; ++d_nfail;)
         ++nrej;
@@ -1461,7 +1538,8 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       const float alpha = (bool)((int)(kp.step_cap > 0) & ((int)(dmax > kp.step_cap) | ((int)MODCHOL & (int)!okf & (int)(dmax > 0.f))))
                               ? fminf(kp.step_cap / dmax, MODCHOL ? 8.f : 1e30f) : 1.f;
       WDIAG(if (alpha < 1.f) ++d_ncap;)
-      pred = alpha * (1.f - 0.5f * alpha) * gd + 0.5f * alpha * alpha * lam * dd;
+      const float lam_row = lam * mu_own;  // (the damping this row's step was computed with)
+      pred = alpha * (1.f - 0.5f * alpha) * gd + 0.5f * alpha * alpha * lam_row * dd;
       keff = gd / fmaxf(dd, 1e-30f);
       float sl = 0.f;
 #pragma unroll
@@ -1475,7 +1553,18 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       pending = true;
       // (see dexr_quad.hpp: verified undamped model, tiny Newton step; beyond 10 tol only on the quadratic tail of the
       // iteration -- the step must be at most a tenth of the previous accepted one, as in the small-component kernel)
-      if ((bool)((int)okf & (int)(smax < kp.blind_tol) & (int)(lam <= kp.lam0) & ((int)(smax < 10.f * kp.tol) | (int)(smax < 0.1f * sprev)))) {
+      bool last_step = (bool)((int)okf & (int)(smax < kp.blind_tol) & (int)(lam_row <= kp.lam0) & ((int)(smax < 10.f * kp.tol) | (int)(smax < 0.1f * sprev)));
+      if (SPRINT) {  // any row's step qualifies: the least damped such row's point is the answer, for every row
+        const unsigned long long lb = __ballot(last_step);
+        if (lb != 0ull) {
+          const int r = (__ffsll((long long)lb) - 1) >> 4;
+          const int src = (16 * r + l) << 2;
+#pragma unroll
+          for (int s2 = 0; s2 < NJ2; ++s2) xj[s2] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(xj[s2])));
+          last_step = true;
+        }
+      }
+      if (last_step) {
         ++my_iters;
         pending = false;
         done = true;

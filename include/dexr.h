@@ -121,6 +121,13 @@ typedef struct dexr_tuning {
                            retarget()).  Same damping rules and trial points up to the summation order of the Hessian: answers
                            agree with the four-frames-per-wave launch to float32 solve accuracy, not bit for bit.  0 off;
                            -1 measured policy (2 048: above that the chip has fewer wave slots than frames)           */
+  int32_t sprint_ladder; /* ... and in that launch shape the four rows of a wave may each try THEIR OWN damping value per pass
+                           (lambda x 0.03, 0.3, 3, 30): four trial points are evaluated for the instructions of one, the best
+                           acceptable one is kept, a pass whose steps are all rejected assembles no model.  Fewer passes on
+                           frames that start at an indefinite model (the clean one-frame-per-call regime: Shadow vector 8.5 -> 5.7
+                           passes in the host emulation), but ANOTHER iteration than the four-frames-per-wave launch's: answers agree
+                           to 1e-4 rad except where a multi-modal frame settles in a different certified minimum.  1 on, 0 off
+                           (the rows are copies of one iteration), -1 measured policy                                   */
 } dexr_tuning;
 #define DEXR_TUNE_LAM_JUMP 1u
 #define DEXR_TUNE_LAM_FASTDEC 2u

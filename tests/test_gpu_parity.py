@@ -729,10 +729,13 @@ def test_mixed_fleet_equals_per_model_calls(B):
         assert np.all(out[sel][:, prob.n_opt:] == 0)
         if st is not None:
             assert np.array_equal(state.cpu().numpy()[sel].astype(np.uint32), st)
+        # (default policy: one frame per wave with the ladder of damping values -- from these FAR starts, the limit midpoint,
+        # a few per cent of the multi-modal frames settle in another certified minimum; the projection state does not depend
+        # on the iteration)
         opts[m].device_model().tune(sprint_max_batch=-1)
         st2 = np.zeros(int(sel.sum()), np.uint32) if prob.kind == "dexpilot" else None
         want2 = opts[m].retarget_keypoints_batch(kp[sel], None, last[sel][:, : prob.n_opt], state=st2)
-        assert np.abs(want2 - want).max() < 2e-5
+        assert (np.abs(want2 - want).max(1) < 1e-4).mean() > 0.9
         if st is not None:
             assert np.array_equal(st2, st)
 
@@ -755,6 +758,11 @@ def test_fused_sequence_kernel_equals_frame_by_frame(rel):
     kp = torch.from_numpy(cases.human_keypoints(B * (2 * T), seed=6).reshape(2 * T, B, 21, 3)).cuda()
     step = RetargetingConfig.load_from_file(cfg_path).build_device(B)
     fused = RetargetingConfig.load_from_file(cfg_path).build_device(B)
+    # (the fused kernel walks its sequences four frames per wave; the frame-by-frame path would take the one-frame-per-wave
+    # shape with its ladder of damping values at this batch size -- another iteration, which from the far start of a
+    # sequence's first frame settles ~3 % of multi-modal frames in another minimum.  This test is about the carry, so both
+    # sides run the same iteration.)
+    step.model.tune(sprint_max_batch=0)
     # float64-sequence models are compared with a looser bound (the frame-by-frame path is float32 + float64 polish)
     polish_model = step.optimizer.retargeting_type != "VECTOR" and step.model.kernel()[0] == _lib.KERNEL_REGISTER
     tol = 2e-5 if (polish_model or step.optimizer.adaptor is not None) else 2e-6
@@ -1041,12 +1049,18 @@ def test_longest_first_ordering_changes_the_schedule_not_the_answers():
                                  "teleop/inspire_hand_right_dexpilot.yml", "offline/schunk_svh_hand_right.yml",
                                  "offline/ability_hand_right.yml"])  # (the last three: variable grids, mimic joints folded)
 def test_one_frame_per_wave_launch_shape_agrees_with_four_per_wave_and_the_oracle(rel):
-    """dexr_tuning.sprint_max_batch (round 5): plain batches of up to 2 048 frames of a joint-space model on the sixteen-lane
-    kernel run one frame per wave -- the four rows of a wave share the frame's term loop (partial Hessians summed by an xor
-    butterfly) and run everything else redundantly.  Same damping rules and trial points up to the summation order: the same
-    iteration counts on (nearly) every frame, the same DexPilot state, answers within float32 solve accuracy of the
-    four-frames-per-wave launch and within 1e-4 rad of the float64 oracle; B = 1 (the reference's own calling pattern), a
-    batch that is not a multiple of anything, and the largest batch the policy sends that way."""
+    """dexr_tuning.sprint_max_batch / sprint_ladder (round 5): plain batches of up to 2 048 frames of a model on the sixteen-lane
+    kernel run one frame per wave.
+    (a) sprint_ladder = 0 -- the four rows of a wave are COPIES of one iteration that share the frame's term loop (partial
+        Hessians summed by an xor butterfly): the same damping rules and trial points up to the summation order, i.e. the same
+        iteration counts on (nearly) every frame, the same DexPilot state, answers within float32 solve accuracy of the
+        four-frames-per-wave launch.
+    (b) sprint_ladder = 1 (the policy) -- every row tries its own damping value (lambda x 0.03 / 0.3 / 3 / 30), the best acceptable
+        trial point of a pass is kept: ANOTHER iteration, with fewer passes.  On tracking frames it reaches the same minimum
+        (1e-4 rad on >= 99.5 % of the frames, the rest certified elsewhere by the oracle check), needs no more passes on average
+        and a shorter slowest frame, and stays within 1e-4 rad of the float64 oracle on >= 99 % of the frames.
+    B = 1 (the reference's own calling pattern), a batch that is not a multiple of anything, the largest batch the policy sends
+    that way."""
     seq, prob = build(rel)
     model = seq.optimizer.device_model()
     assert model.kernel()[0] == _lib.KERNEL_WIDE
@@ -1058,21 +1072,26 @@ def test_one_frame_per_wave_launch_shape_agrees_with_four_per_wave_and_the_oracl
         model.tune(sprint_max_batch=0)
         last = model.retarget(kp[:-1], None, mid, state=st0, keypoints=True)
         res = {}
-        for name, smax in (("four", 0), ("one", -1)):
-            model.tune(sprint_max_batch=smax)
+        for name, smax, lad in (("four", 0, 0), ("copies", -1, 0), ("ladder", -1, 1)):
+            model.tune(sprint_max_batch=smax, sprint_ladder=lad)
             st = None if st0 is None else st0.copy()
             q, info = model.retarget(kp[1:], None, last, state=st, keypoints=True, want_info=True)
             res[name] = (q, info["iters"], info["status"], st)
-        model.tune(sprint_max_batch=-1)
-        (qa, ita, sa, sta), (qb, itb, sb, stb) = res["four"], res["one"]
-        assert (sa == 0).all() and (sb == 0).all()
-        # (typically 1e-6; a few frames per thousand of the mimic hands sit in valleys flat enough for 4e-5 -- the bar is the
-        # 1e-4 rad of BASELINE.json, and the p99 is asserted an order of magnitude tighter)
+        model.tune(sprint_max_batch=-1, sprint_ladder=-1)
+        (qa, ita, sa, sta), (qb, itb, sb, stb), (qc, itc, sc, stc) = res["four"], res["copies"], res["ladder"]
+        assert (sa == 0).all() and (sb == 0).all() and (sc == 0).all()
+        # (a) copies: typically 1e-6; a few frames per thousand of the mimic hands sit in valleys flat enough for 4e-5 -- the bar
+        # is the 1e-4 rad of BASELINE.json, and the p99 is asserted an order of magnitude tighter
         assert np.abs(qa - qb).max() < 1e-4, (rel, B, np.abs(qa - qb).max())
         assert np.percentile(np.abs(qa - qb).max(1), 99) < 1e-5, (rel, B)
         assert (ita != itb).mean() <= 0.01, (rel, B, int((ita != itb).sum()))
+        # (b) ladder
+        same = np.abs(qa - qc).max(1) < 1e-4
+        assert same.mean() >= 0.995, (rel, B, float(same.mean()))
+        if B > 1:
+            assert itc.mean() <= ita.mean() + 0.05 and itc.max() <= ita.max() + 2, (rel, B, ita.mean(), itc.mean(), ita.max(), itc.max())
         if dex:
-            assert np.array_equal(sta, stb)
+            assert np.array_equal(sta, stb) and np.array_equal(sta, stc)
         if B == 333:
             ref = np.ascontiguousarray(cases.ref_from_keypoints(prob, kp[1:]), dtype=np.float32)
             kw = {}
@@ -1081,8 +1100,9 @@ def test_one_frame_per_wave_launch_shape_agrees_with_four_per_wave_and_the_oracl
                 w, rv, _ = prob.dexpilot_preamble(ref, proj)
                 kw = dict(weights=w, dexpilot_ref=rv)
             want = solvers.solve_lm_batched(prob, ref, None, last, newton=True, max_iter=100, **kw)
-            dq = np.abs(qb.astype(np.float64) - want).max(1)
-            assert (dq < 1e-4).mean() >= 0.99, (rel, float((dq < 1e-4).mean()))  # (human targets are multi-modal: see test_gpu_all_configs)
+            for q in (qb, qc):
+                dq = np.abs(q.astype(np.float64) - want).max(1)
+                assert (dq < 1e-4).mean() >= 0.99, (rel, float((dq < 1e-4).mean()))  # (human targets are multi-modal: see test_gpu_all_configs)
 
 
 @pytest.mark.parametrize("rel", ["teleop/allegro_hand_right.yml", "teleop/shadow_hand_right_dexpilot.yml"])
@@ -1393,7 +1413,9 @@ def test_fleet_batch_with_caller_fixed_joints():
     for m, o in enumerate(opts):
         sel = mid == m
         st = np.zeros(int(sel.sum()), np.uint32) if o.retargeting_type == "DEXPILOT" else None
+        o.device_model().tune(sprint_max_batch=0)  # (a fleet bucket is walked four frames per wave: compare like with like)
         want = o.retarget_keypoints_batch(kp[sel], fixed[sel] if m == 0 else None, last[sel][:, : o.opt_dof], state=st)
+        o.device_model().tune(sprint_max_batch=-1)
         assert np.abs(out[sel][:, : o.opt_dof] - want).max() < 2e-6, m
     # the host-array entry point takes the same rows
     st_h = np.zeros(B, np.uint32)

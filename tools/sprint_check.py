@@ -33,10 +33,13 @@ for rel in rels:
         kp = cases.human_keypoints(B + 1, seed=cases.SEED)
         mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
         res = {}
-        for mode, smax in (("four per wave", 0), ("one per wave", 1 << 20)):
-            model.tune(sprint_max_batch=smax)
+        for mode, smax, lad in (("four per wave", 0, 0), ("one per wave", 1 << 20, 0), ("ladder", 1 << 20, 1)):
+            model.tune(sprint_max_batch=smax, sprint_ladder=lad)
             st = np.zeros(B, np.uint32) if dex else None
-            last = model.retarget(np.ascontiguousarray(kp[:-1]), None, mid, state=st, keypoints=True)
+            last_m = model.retarget(np.ascontiguousarray(kp[:-1]), None, mid, state=st, keypoints=True)  # (cold start from the limit midpoint)
+            if mode == "four per wave":
+                last, st_first = last_m, (None if st is None else st.copy())
+            st = None if st_first is None else st_first.copy()  # every mode tracks from the SAME previous answers / state
             st_in = None if st is None else st.copy()
             q, info = model.retarget(np.ascontiguousarray(kp[1:]), None, last, state=st, keypoints=True, want_info=True)
             t_kp, t_last = torch.from_numpy(np.ascontiguousarray(kp[1:])).to(dev), torch.from_numpy(last).to(dev)
@@ -53,11 +56,18 @@ for rel in rels:
                 if i >= 3:
                     ev[i - 3][1].record(s)
             torch.cuda.synchronize()
-            res[mode] = dict(q=q, last=last, it=info["iters"], status=info["status"], st=st, us=float(np.median([a.elapsed_time(b) for a, b in ev])) * 1e3)
-        model.tune(sprint_max_batch=-1)
-        a, b = res["four per wave"], res["one per wave"]
+            res[mode] = dict(q=q, last=last_m, it=info["iters"], status=info["status"], st=st, us=float(np.median([a.elapsed_time(b) for a, b in ev])) * 1e3)
+        model.tune(sprint_max_batch=-1, sprint_ladder=-1)
+        a, b, c = res["four per wave"], res["one per wave"], res["ladder"]
+        if os.environ.get("DEXR_SPRINT_DUMP") and B >= 256:
+            np.savez(os.path.join(REPO, "gpurun_out", f"sprint_dump_{rel.split('/')[-1][:-4]}_{B}.npz"), kp=kp[1:], last=a["last"], kp_prev=kp[:-1], last_ladder=c["last"],
+                     q_four=a["q"], q_ladder=c["q"], it_four=a["it"], it_ladder=c["it"], st_in=np.zeros(B, np.uint32) if not dex else st_in)
         dl = np.abs(a["last"] - b["last"]).max()
+        dlc = np.abs(a["last"] - c["last"]).max(1)
         dq = np.abs(a["q"] - b["q"]).max(1)
-        print(f"{rel:44s} B={B:4d}  {a['us']:7.1f} -> {b['us']:7.1f} us   iters {a['it'].mean():.2f} / {b['it'].mean():.2f} (differ in {int((a['it'] != b['it']).sum())} frames)  "
-              f"max |dq| {dq.max():.2e} (> 1e-5: {int((dq > 1e-5).sum())})  cold-start solve max |dq| {dl:.2e}  status ok {bool((b['status'] == 0).all())}"
-              + (f"  state equal {bool(np.array_equal(a['st'], b['st']))}" if dex else ""))
+        dqc = np.abs(a["q"] - c["q"]).max(1)
+        print(f"{rel:44s} B={B:4d}  {a['us']:7.1f} -> {b['us']:7.1f} -> ladder {c['us']:7.1f} us   iters {a['it'].mean():.2f} / {b['it'].mean():.2f} / {c['it'].mean():.2f} "
+              f"(max {a['it'].max()} / {b['it'].max()} / {c['it'].max()}; differ in {int((a['it'] != b['it']).sum())} frames)  "
+              f"max |dq| {dq.max():.2e} (> 1e-5: {int((dq > 1e-5).sum())})  ladder: > 1e-4 in {int((dqc > 1e-4).sum())}, p99 {np.percentile(dqc, 99):.1e}  "
+              f"cold-start solve max |dq| {dl:.2e} (ladder: > 1e-4 in {int((dlc > 1e-4).sum())})  status ok {bool((b['status'] == 0).all())} {bool((c['status'] == 0).all())}"
+              + (f"  state equal {bool(np.array_equal(a['st'], b['st']))} {bool(np.array_equal(a['st'], c['st']))}" if dex else ""))
