@@ -31,7 +31,7 @@ class Tuning(C.Structure):
                 ("stall_cap", C.c_float), ("lam_jump", C.c_float), ("lam_fastdec", C.c_float),
                 ("floor_scale", C.c_float), ("step_cap", C.c_float), ("blind_tol_scale", C.c_float),
                 ("pivot_rule", C.c_int32), ("longest_first", C.c_int32), ("lam_recover", C.c_float),
-                ("fork_streams", C.c_int32), ("user_mask", C.c_uint32), ("sprint_max_batch", C.c_int32), ("sprint_ladder", C.c_int32)]
+                ("fork_streams", C.c_int32), ("user_mask", C.c_uint32), ("sprint_max_batch", C.c_int32), ("sprint_ladder", C.c_int32), ("tail_passes", C.c_int32)]
 
 
 TUNE_LAM_JUMP, TUNE_LAM_FASTDEC = 1, 2

@@ -269,23 +269,25 @@ hipError_t dexr_fleet_dexpilot_order_launch(int64_t B, const float* kpts, const 
                                             float escape_dist, int32_t* xws, const int32_t** out_perm, const int32_t** out_seg,
                                             hipStream_t st);
 hipError_t dexr_lpt_order_launch(int64_t B, const float* f0, const float* sum, float ratio, int32_t* key, int32_t* ws, hipStream_t st);
+hipError_t dexr_tail_list_launch(int64_t B, int32_t* status, float* fval, int32_t* key, int32_t* ws, hipStream_t st);
 hipError_t dexr_dexpilot_order_launch(int64_t B, const float* kpts, const float* ref, const uint32_t* state, int n_kp, int n_ref,
                                       const int32_t* h_task, const int32_t* h_origin, int F, float project_dist, float escape_dist,
                                       int32_t* key, int32_t* ws, hipStream_t st);
 namespace {
 
 // sixteen lanes per frame: four frames per wave, two waves per SIMD resident; persistent rows fed like the quads
-int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
+int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st, bool tail_launch = false) {
   const size_t per_wave = m->wide_mimic ? dexr::wide_lds_per_wave_m_16() : dexr::wide_lds_per_wave(m->wbucket);
   int wpb = 4;
   while (wpb > 1 && per_wave * wpb > 80 * 1024) wpb >>= 1;
   // ONE FRAME PER WAVE for small plain batches (dexr_wide.hpp SPRINT; dexr_tuning.sprint_max_batch):
   // with fewer frames than the chip has row slots a wave's four rows share one frame's term loop instead of idling
   const int64_t sprint_max = m->tune.sprint_max_batch < 0 ? 2048 : m->tune.sprint_max_batch;  // (measured: it wins up to ~2 048 frames = one wave per frame on every SIMD pair, profiles/r05_sprint_one_frame_per_wave.txt)
-  const bool sprint = kp.B <= sprint_max && !kp.perm && !kp.bucket && kp.T == 0 && !kp.screen && kp.n_comp == 1;
+  // (tail_launch: the second launch of a large batch, over the device-built list of the frames the first left unfinished)
+  const bool sprint = tail_launch || (kp.B <= sprint_max && !kp.perm && !kp.bucket && kp.T == 0 && !kp.screen && kp.n_comp == 1);
   const int fpw = sprint ? 1 : 4;  // frames per wave
   {
-    const bool ladder = sprint && m->tune.sprint_ladder != 0;  // (-1: policy = on)
+    const bool ladder = sprint && (tail_launch || m->tune.sprint_ladder != 0);  // (-1: policy = on; the tail launch always)
     const float mu_on[4] = {0.03f, 0.3f, 3.f, 30.f};
     for (int r = 0; r < 4; ++r) kp.sprint_mu[r] = ladder ? mu_on[r] : 1.f;
   }
@@ -376,9 +378,58 @@ int lpt_slot_grow(dexr_model::LptSlot& sl, size_t bytes) {
   return DEXR_OK;
 }
 
+// TAIL LAUNCH (round 5; dexr_tuning.tail_passes).  A launch over many more frames than the chip holds is bound by its slowest
+// frames: 2-6 % of the frames of a tracking batch need two to six times the mean number of passes, and they finish on a chip
+// that is otherwise idle.  The first launch therefore stops every frame after P passes; the frames left with status MAXITER are
+// listed on the device (one elementwise kernel + the fleet's bucketing kernels) and a second launch in the one-frame-per-wave
+// shape (dexr_wide.hpp SPRINT) continues each from its accepted point with the ladder of damping values -- a pass costs less
+// there and the ladder needs about half as many.  Everything is stream-ordered on the caller's stream; the workspace is one of
+// the model's LSLOTS buffers (dexr_model_reserve sizes them).
+int launch_wide_tail(const dexr_model* m, dexr::KernelParams kp, int P, hipStream_t st) {
+  const size_t B = (size_t)kp.B;
+  const size_t bytes = lpt_slot_bytes(kp.B);
+  dexr_model::LptSlot& sl = m->lpt[m->lnext.fetch_add(1u) % dexr_model::LSLOTS];
+  if (!sl.done) HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+  else HIP_TRY(hipStreamWaitEvent(st, sl.done, 0));
+  { const int rc = lpt_slot_grow(sl, bytes); if (rc != DEXR_OK) return rc; }
+  unsigned char* base = static_cast<unsigned char*>(sl.buf);
+  int32_t* own_status = reinterpret_cast<int32_t*>(base + 256);  // (the screening values' place: unused on this path)
+  int32_t* key = reinterpret_cast<int32_t*>(base + 256 + B * sizeof(float));
+  int32_t* ws = key + B;
+  dexr::KernelParams k1 = kp;
+  k1.max_iter = P;
+  if (!k1.status) {
+    k1.status = own_status;
+    HIP_TRY(hipMemsetAsync(own_status, 0, B * sizeof(int32_t), st));
+  }
+  int rc = launch_wide_once(m, k1, st);
+  if (rc != DEXR_OK) return rc;
+  hipError_t e = dexr_tail_list_launch(kp.B, k1.status, kp.fval, key, ws, st);
+  if (e != hipSuccess) return fail(DEXR_ERR_HIP, "tail list kernels failed: %s", hipGetErrorString(e));
+  dexr::KernelParams k2 = kp;
+  k2.status = k1.status;
+  k2.perm = ws + dexr_fleet_ws_ints();
+  k2.bucket = ws + 2 * DEXR_FLEET_MAX_MODELS;
+  k2.x0 = kp.qout;  // continue from the accepted point the first launch wrote (the regularisation target stays `last`)
+  k2.iters_base = P;
+  rc = launch_wide_once(m, k2, st, true);
+  HIP_TRY(hipEventRecord(sl.done, st));
+  return rc;
+}
+
 int launch_wide(const dexr_model* m, dexr::KernelParams kp, hipStream_t st) {
   const int want = m->tune.longest_first;
   const bool plain = !kp.perm && !kp.bucket && kp.T == 0 && kp.n_comp == 1;
+  {
+    // (policy: OFF.  Measured, 65 536 tracking frames, profiles/r05_tail_launch.txt: LEAP position 1.106 ms in one launch,
+    // 1.18-1.29 ms with caps of 16 ... 6 passes; Shadow DexPilot 1.158 (hard frames first) -> 1.24-1.33.  The capped main launch is
+    // throughput-bound and gets barely shorter, while the handed-over frames then run at a quarter of the occupancy, after it.)
+    const int P = m->tune.tail_passes < 0 ? 0 : m->tune.tail_passes;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (plain && P > 0 && kp.max_iter > P && !kp.x0 && !kp.screen && kp.B >= 16384 &&
+        hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone)
+      return launch_wide_tail(m, kp, P, st);
+  }
   // (automatic: from 9 variables on -- measured on all 13 DexPilot configs, 65 536 frames: Shadow 1.35 -> 1.11 / 1.28 -> 1.07 ms,
   // LEAP 0.90 -> 0.78 / 0.87 -> 0.78, Allegro 0.71 -> 0.60 / 0.63 -> 0.62, SVH 0.93 -> 0.77 / 1.13 -> 1.07; the six-variable
   // Ability / Inspire hands lose 2-7 % to the ~25 us of ordering, their launches are not tail-bound)
@@ -703,6 +754,7 @@ void default_tuning(dexr_model* m) {
   t.fork_streams = -1;
   t.sprint_max_batch = -1;
   t.sprint_ladder = -1;
+  t.tail_passes = -1;
 }
 
 // A model in the generic table format (dexr_tables.h): validate every index the general kernel will follow, upload the
@@ -1152,6 +1204,7 @@ int dexr_model_set_tuning(dexr_model* m, const dexr_tuning* tuning) {
   if (t.fork_streams < -1 || t.fork_streams > 1) return fail(DEXR_ERR_INVALID, "fork_streams must be -1, 0 or 1");
   if (t.sprint_max_batch < -1) return fail(DEXR_ERR_INVALID, "sprint_max_batch must be -1 (policy), 0 (off) or a batch size");
   if (t.sprint_ladder < -1 || t.sprint_ladder > 1) return fail(DEXR_ERR_INVALID, "sprint_ladder must be -1, 0 or 1");
+  if (t.tail_passes < -1) return fail(DEXR_ERR_INVALID, "tail_passes must be -1 (policy), 0 (off) or a pass count");
   if (t.persist_from < 0 || t.qchunk < 0 || t.persist_occ < 0 || t.resident_waves < 0 || t.max_blind < 0)
     return fail(DEXR_ERR_INVALID, "negative launch parameter");
   if (!(t.step_cap >= 0) || !(t.lam_jump >= 0) || !(t.lam_fastdec >= 0) || !(t.floor_scale >= 0) || !(t.blind_tol_scale >= 0) || !(t.lam_recover >= 0))

@@ -314,6 +314,30 @@ hipError_t dexr_dexpilot_order_launch(int64_t B, const float* kpts, const float*
   return dexr_fleet_bucket_launch(3, B, key, ws, st);
 }
 
+// TAIL LIST of a large batch (dexr_api.hip: launch_wide): the frames the first launch left at its pass cap (status MAXITER) become
+// the index list of the second, one-frame-per-wave launch; their status / final-value entries are cleared for it to set.
+namespace {
+__global__ void __launch_bounds__(256) tail_key_kernel(int32_t* __restrict__ status, float* __restrict__ fval, int64_t B,
+                                                       int32_t* __restrict__ key) {
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x) {
+    const bool tail = status[b] == 1;  // DEXR_STATUS_MAXITER
+    key[b] = tail ? 0 : -1;
+    if (tail) {
+      status[b] = 0;
+      if (fval) fval[b] = 0.f;
+    }
+  }
+}
+}  // namespace
+hipError_t dexr_tail_list_launch(int64_t B, int32_t* status, float* fval, int32_t* key, int32_t* ws, hipStream_t st) {
+  const int64_t want = (B + 255) / 256;
+  const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  hipLaunchKernelGGL(tail_key_kernel, dim3(blocks), dim3(256), 0, st, status, fval, B, key);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return dexr_fleet_bucket_launch(1, B, key, ws, st);  // (key -1: skipped; bucket 0 = the tail, stable order)
+}
+
 // One DexPilot model's bucket of a fleet batch, hard frames first: extra workspace (int32) = key[B] | bucketing workspace
 // (dexr_fleet_ws_ints() + B) | out_perm[B] | out_seg[2] -- dexr_fleet_order_ws_ints(B) in all
 size_t dexr_fleet_order_ws_ints(int64_t B) { return 3 * (size_t)(B > 0 ? B : 0) + dexr_fleet_ws_ints() + 4; }

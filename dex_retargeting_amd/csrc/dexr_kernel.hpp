@@ -102,6 +102,7 @@ struct KernelParams {
   // rows -- {1, 1, 1, 1}: the rows are copies of one iteration; a ladder such as {0.03, 0.3, 3, 30}: every pass tries four
   // damping values from the accepted point and keeps the best acceptable trial point (dexr_tuning.sprint_ladder).
   float sprint_mu[4];
+  int32_t iters_base;  // passes a frame has already had in an earlier launch (the tail launch of a large batch continues the count)
 };
 
 // Per-component side table of the sixteen-lanes-per-frame kernel (dexr_wide.hpp), derived from the component's table by

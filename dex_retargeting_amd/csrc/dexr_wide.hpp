@@ -1254,7 +1254,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     nrej = 0;
     WDIAG(d_nrej = 0; d_ncap = 0; d_nfail = 0;)
     status = ST_MAXITER;
-    my_iters = 0;
+    my_iters = kp.iters_base;
     blind = 0;
     F = 0;
     smax = 0;

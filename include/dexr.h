@@ -128,6 +128,14 @@ typedef struct dexr_tuning {
                            passes in the host emulation), but ANOTHER iteration than the four-frames-per-wave launch's: answers agree
                            to 1e-4 rad except where a multi-modal frame settles in a different certified minimum.  1 on, 0 off
                            (the rows are copies of one iteration), -1 measured policy                                   */
+  int32_t tail_passes;  /* sixteen-lane kernel, plain LARGE batches (>= 16 384 frames of a single-component model): the main launch
+                           stops every frame after this many passes; the few per cent still unfinished are listed on the device
+                           and handed to a second launch in the one-frame-per-wave shape with the ladder above -- a launch is
+                           otherwise bound by the passes of its slowest frames, on a chip that is idle by then.  Deterministic
+                           per frame (the cap is fixed), but the handed-over frames follow the ladder's iteration from where
+                           they stood.  0 off, > 0 the cap, -1 measured policy = OFF: at 65 536 frames the capped main launch
+                           is throughput-bound and barely shorter, the second launch comes on top (LEAP position 1.11 ->
+                           1.18-1.29 ms for caps of 16 ... 6; answers equal to 1e-6 rad either way)                      */
 } dexr_tuning;
 #define DEXR_TUNE_LAM_JUMP 1u
 #define DEXR_TUNE_LAM_FASTDEC 2u

@@ -1105,6 +1105,42 @@ def test_one_frame_per_wave_launch_shape_agrees_with_four_per_wave_and_the_oracl
                 assert (dq < 1e-4).mean() >= 0.99, (rel, float((dq < 1e-4).mean()))  # (human targets are multi-modal: see test_gpu_all_configs)
 
 
+@pytest.mark.parametrize("rel", ["teleop/shadow_hand_right_dexpilot.yml", "offline/leap_hand_right.yml", "teleop/inspire_hand_right_dexpilot.yml"])
+def test_tail_launch_equals_the_single_launch(rel):
+    """dexr_tuning.tail_passes (round 5, opt-in: measured slower at 65 536 frames, profiles/r05_tail_launch.txt): the main launch
+    stops every frame after P passes, the unfinished ones are listed on the device and continued -- from their accepted point,
+    one frame per wave, ladder of damping values -- by a second launch.  Every frame ends converged, in the single launch's
+    minimum (1e-4 rad; 1e-6 typically), with the same DexPilot state; the iteration counts continue across the two launches; a
+    caller who passes no status array gets the same answers (the list is then built from an internal one)."""
+    seq, prob = build(rel)
+    model = seq.optimizer.device_model()
+    B = 20000
+    dex = prob.kind == "dexpilot"
+    kp = np.ascontiguousarray(cases.human_keypoints(B + 1, seed=cases.SEED + 5))
+    mid = np.repeat(prob.joint_limits.mean(1)[None], B, 0).astype(np.float32)
+    st0 = np.zeros(B, np.uint32) if dex else None
+    model.tune(tail_passes=0)
+    last = model.retarget(kp[:-1], None, mid, state=st0, keypoints=True)
+    st_a = None if st0 is None else st0.copy()
+    qa, ia = model.retarget(kp[1:], None, last, state=st_a, keypoints=True, want_info=True)
+    model.tune(tail_passes=6)
+    st_b = None if st0 is None else st0.copy()
+    qb, ib = model.retarget(kp[1:], None, last, state=st_b, keypoints=True, want_info=True)
+    st_c = None if st0 is None else st0.copy()
+    qc = model.retarget(kp[1:], None, last, state=st_c, keypoints=True)  # (no status / iteration arrays from the caller)
+    model.tune(tail_passes=-1)
+    assert (ia["status"] == 0).all() and (ib["status"] == 0).all()
+    handed = ib["iters"] > 6
+    assert 0.005 < handed.mean() < 0.5            # (the cap did hand frames over, and only a minority)
+    assert np.array_equal(ia["iters"][~handed], ib["iters"][~handed])
+    assert np.array_equal(qa[~handed], qb[~handed])  # frames that finished under the cap: the same launch, the same bits
+    dq = np.abs(qa - qb).max(1)
+    assert (dq < 1e-4).mean() >= 0.9995 and np.percentile(dq, 99) < 1e-5, (rel, float((dq < 1e-4).mean()))
+    assert np.array_equal(qb, qc)
+    if dex:
+        assert np.array_equal(st_a, st_b) and np.array_equal(st_a, st_c)
+
+
 @pytest.mark.parametrize("rel", ["teleop/allegro_hand_right.yml", "teleop/shadow_hand_right_dexpilot.yml"])
 def test_launches_on_two_streams_do_not_interfere(rel):
     """Independent batches issued alternately on two HIP streams through the same model handle (work-queue slots are
