@@ -1078,6 +1078,9 @@ def test_one_frame_per_wave_launch_shape_agrees_with_four_per_wave_and_the_oracl
             q, info = model.retarget(kp[1:], None, last, state=st, keypoints=True, want_info=True)
             res[name] = (q, info["iters"], info["status"], st)
         model.tune(sprint_max_batch=-1, sprint_ladder=-1)
+        st = None if st0 is None else st0.copy()
+        q_again, info_again = model.retarget(kp[1:], None, last, state=st, keypoints=True, want_info=True)  # (the policy = the ladder)
+        assert np.array_equal(q_again, res["ladder"][0]) and np.array_equal(info_again["iters"], res["ladder"][1])  # bit-reproducible
         (qa, ita, sa, sta), (qb, itb, sb, stb), (qc, itc, sc, stc) = res["four"], res["copies"], res["ladder"]
         assert (sa == 0).all() and (sb == 0).all() and (sc == 0).all()
         # (a) copies: typically 1e-6; a few frames per thousand of the mimic hands sit in valleys flat enough for 4e-5 -- the bar
