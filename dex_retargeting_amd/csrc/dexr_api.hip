@@ -284,7 +284,9 @@ int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st,
   // with fewer frames than the chip has row slots a wave's four rows share one frame's term loop instead of idling
   const int64_t sprint_max = m->tune.sprint_max_batch < 0 ? 2048 : m->tune.sprint_max_batch;  // (measured: it wins up to ~2 048 frames = one wave per frame on every SIMD pair, profiles/r05_sprint_one_frame_per_wave.txt)
   // (tail_launch: the second launch of a large batch, over the device-built list of the frames the first left unfinished)
-  const bool sprint = tail_launch || (kp.B <= sprint_max && !kp.perm && !kp.bucket && kp.T == 0 && !kp.screen && kp.n_comp == 1);
+  // (frame SEQUENCES included: a wave then walks one sequence's T frames with its four rows -- the offline retargeting of one
+  // recorded hand is exactly "three rows idle")
+  const bool sprint = tail_launch || (kp.B <= sprint_max && !kp.perm && !kp.bucket && !kp.screen && kp.n_comp == 1);
   const int fpw = sprint ? 1 : 4;  // frames per wave
   {
     const bool ladder = sprint && (tail_launch || m->tune.sprint_ladder != 0);  // (-1: policy = on; the tail launch always)

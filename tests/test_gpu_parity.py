@@ -758,11 +758,10 @@ def test_fused_sequence_kernel_equals_frame_by_frame(rel):
     kp = torch.from_numpy(cases.human_keypoints(B * (2 * T), seed=6).reshape(2 * T, B, 21, 3)).cuda()
     step = RetargetingConfig.load_from_file(cfg_path).build_device(B)
     fused = RetargetingConfig.load_from_file(cfg_path).build_device(B)
-    # (the fused kernel walks its sequences four frames per wave; the frame-by-frame path would take the one-frame-per-wave
-    # shape with its ladder of damping values at this batch size -- another iteration, which from the far start of a
-    # sequence's first frame settles ~3 % of multi-modal frames in another minimum.  This test is about the carry, so both
-    # sides run the same iteration.)
+    # (four frames / sequences per wave on both sides: the carry is what is tested here; the one-frame-per-wave shape both
+    # paths take by default at this batch size is compared in test_fused_sequence_one_per_wave_equals_frame_by_frame)
     step.model.tune(sprint_max_batch=0)
+    fused.model.tune(sprint_max_batch=0)
     # float64-sequence models are compared with a looser bound (the frame-by-frame path is float32 + float64 polish)
     polish_model = step.optimizer.retargeting_type != "VECTOR" and step.model.kernel()[0] == _lib.KERNEL_REGISTER
     tol = 2e-5 if (polish_model or step.optimizer.adaptor is not None) else 2e-6
@@ -787,6 +786,36 @@ def test_fused_sequence_kernel_equals_frame_by_frame(rel):
     if fused.dexpilot:
         assert torch.equal(fused.state, step.state)
 
+
+
+@pytest.mark.parametrize("rel", ["teleop/shadow_hand_right_dexpilot.yml", "offline/leap_hand_right.yml", "teleop/inspire_hand_right_dexpilot.yml"])
+def test_fused_sequence_one_per_wave_equals_frame_by_frame(rel):
+    """Small batches of SEQUENCES take the one-frame-per-wave shape too (a wave walks one sequence's T frames with its four rows
+    and the ladder of damping values): the fused kernel and T frame-by-frame calls run the same iteration on the same carried
+    start points -- raw answers, carried DexPilot bits and filtered robot qpos agree to float32 solve accuracy; B = 1 is the
+    reference's offline use (one recorded hand)."""
+    torch = pytest.importorskip("torch")
+    cfg_path = os.path.join(cases.CONFIG_DIR, rel)
+    for B, T in ((1, 12), (37, 5)):
+        frames = torch.from_numpy(cases.human_keypoints(B * T, seed=8).reshape(T, B, 21, 3)).cuda().contiguous()
+        step = RetargetingConfig.load_from_file(cfg_path).build_device(B)
+        fused = RetargetingConfig.load_from_file(cfg_path).build_device(B)
+        raw = torch.empty((T, B, fused.n_opt), dtype=torch.float32, device="cuda:0")
+        status = torch.zeros((T, B), dtype=torch.int32, device="cuda:0")
+        got = fused.retarget_sequence(frames, raw_out=raw, status_out=status)
+        torch.cuda.synchronize()
+        assert int((status != 0).sum()) == 0
+        tol = 2e-5
+        for t in range(T):
+            want = step.retarget_keypoints(frames[t])
+            dq = (raw[t] - step.last_qpos).abs().max(1).values
+            assert float((dq < tol).float().mean()) >= 0.97, (rel, B, t, float(dq.max()))
+            if bool((dq < tol).all()):
+                assert float((got[t] - want).abs().max()) < 1e-3, (rel, B, t)  # (filtered output: same history so far)
+            step.last_qpos.copy_(raw[t])  # keep the two in lock-step for the next frame
+        assert torch.equal(fused.last_qpos, raw[T - 1])
+        if fused.dexpilot:
+            assert torch.equal(fused.state, step.state)
 
 @pytest.mark.parametrize("key", ["teleop__allegro_hand_right", "teleop__ability_hand_right", "offline__inspire_hand_right",
                                  "teleop__panda_gripper"])
