@@ -27,6 +27,8 @@
 // Budgets: 256 VGPRs and 15-20 KB of LDS per wave = two waves per SIMD; the 16-row joint grid is built for three (168
 // VGPRs, 13 KB).  Everything that is read once or twice per pass lives in LDS or the tables, not in registers.
 // Damping / termination rules are those of dexr_quad.hpp.
+// SPRINT instantiations (round 5): one frame per wave for small batches and short sequences -- the four rows share the frame's
+// term loop and each tries its own damping value per pass (see the comment at the kernel).
 #pragma once
 
 #include "dexr_big.hpp"  // sincos_f64
