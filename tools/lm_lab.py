@@ -105,7 +105,7 @@ def kernel_lm(cm, *, lam0=1e-4, tol=2e-6, max_iter=64, step_cap=0.3, lam_jump=1.
               max_blind=8, stall_from=2, stall_ratio=0.9, stall_cap=20.0, newton=True, eps=5.96e-8, gn_when=None,
               cap_mode="inf", lam_floor=1e-9, trace=None, inner_retry=0, cap_grow=0.0, cap_max=1.2, gersh_at=99, retry_mult=None, pivot_rule=None, pivot_floor=1e-3, blind_contract=0.0, neg_boost=0.0, jump_mode="hd", noise_scale=None,
               dec_rule=None, accel=0.0, accel_rho=0.9, gn_mode=None, gn_exit=0.05, gn_lam=None, tr_retry=0, tr_factor=2.0, tr_pow=1.0,
-              lam_start=None, first_jump=None):
+              lam_start=None, first_jump=None, fail_floor=None):
     """Returns (x (B,T,m), iters (B,T)).  `eps`: rounding unit of the kernel's arithmetic (float32) for the
     below-the-floor logic.  gn_when: optional callable(F, lam, it) -> bool mask selecting Gauss-Newton models."""
     B, T, m = cm.B, cm.T, cm.m
@@ -124,6 +124,7 @@ def kernel_lm(cm, *, lam0=1e-4, tol=2e-6, max_iter=64, step_cap=0.3, lam_jump=1.
     done = np.zeros((B, T), bool)
     eye = np.eye(m)[None, None]
     vm = cm.vmask[None]
+    lfail = np.zeros((B, T))  # fail_floor = (mult, relax): the largest damping at which the factorisation failed, relaxed per accepted step
     for _ in range(max_iter + 2):
         if done.all():
             break
@@ -283,7 +284,12 @@ def kernel_lm(cm, *, lam0=1e-4, tol=2e-6, max_iter=64, step_cap=0.3, lam_jump=1.
         F = np.where(upd, Ft, F)
         gs = np.where(upd[..., None], gt, gs)
         Hs = np.where(upd[..., None, None], Ht, Hs)
+        if fail_floor is not None:
+            lfail = np.where(live & ~ok, np.maximum(lfail, lam), lfail)
         lam = np.where(acc, np.maximum(lam * shrink, lam_floor), np.where(rej, lam_rej, lam))
+        if fail_floor is not None:
+            lam = np.where(acc, np.maximum(lam, fail_floor[0] * lfail), lam)
+            lfail = np.where(acc, lfail * fail_floor[1], lfail)
         lam = np.where(overdamped, np.maximum(0.1 * lam, 0.5 * lam_ok), lam)
         nu = np.where(acc, 2.0, np.where(rej, nu * 2, nu))
         blind = np.where(acc, newblind, blind)
