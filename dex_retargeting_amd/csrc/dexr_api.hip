@@ -286,7 +286,9 @@ int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st,
   // (tail_launch: the second launch of a large batch, over the device-built list of the frames the first left unfinished)
   // (frame SEQUENCES included: a wave then walks one sequence's T frames with its four rows -- the offline retargeting of one
   // recorded hand is exactly "three rows idle")
-  const bool sprint = tail_launch || (kp.B <= sprint_max && !kp.perm && !kp.bucket && !kp.screen && kp.n_comp == 1);
+  // (... and the buckets of a small FLEET batch: kp.B is then the whole batch, an upper bound of the bucket the kernel reads from
+  // device memory -- several robots following one hand, hand_robot_viewer.py:134-181, is a batch of a few rows per model)
+  const bool sprint = tail_launch || (kp.B <= sprint_max && !kp.screen && kp.n_comp == 1);
   const int fpw = sprint ? 1 : 4;  // frames per wave
   {
     const bool ladder = sprint && (tail_launch || m->tune.sprint_ladder != 0);  // (-1: policy = on; the tail launch always)
