@@ -1079,6 +1079,25 @@ def run_single(args):
                            "unit": "frames/s", "n_gpus": 1, "ms_per_step": e2 / args.steps * 1e3, "solver": d2,
                            "roofline": w2.roofline(k2, d2["iters_mean"]), "two_streams": ts2})
 
+    # small batches (round 5): up to 2 048 frames a model on the sixteen-lane kernel runs one frame per wave with a ladder of
+    # damping values (dexr_tuning.sprint_max_batch / sprint_ladder); the same batches four frames per wave beside it
+    if rank == 0 and not args.headline_only and args.workload == "allegro_vector":
+        try:
+            sb = {"frames": 700, "note": "700 tracking frames per launch: default policy (one frame per wave + ladder) vs four frames per wave"}
+            for name in ("shadow_dexpilot", "leap_position"):
+                w3 = Workload(name, rank, 700, dev, torch)
+                d3 = w3.diagnostics(w3.tracking)
+                e3, k3 = w3.timed(w3.tracking, args.steps, args.warmup)
+                w3.model.tune(sprint_max_batch=0)
+                d4 = w3.diagnostics(w3.tracking)
+                e4, k4 = w3.timed(w3.tracking, args.steps, args.warmup)
+                w3.model.tune(sprint_max_batch=-1)
+                sb[name] = {"ms_per_step": e3 / args.steps * 1e3, "value": 700 * args.steps / e3, "iters_mean": d3["iters_mean"], "iters_max": d3["iters_max"],
+                            "four_per_wave": {"ms_per_step": e4 / args.steps * 1e3, "iters_mean": d4["iters_mean"], "iters_max": d4["iters_max"]}}
+            sub["small_batch"] = sb
+        except Exception as e:
+            sub["small_batch"] = {"error": repr(e)}
+
     fleet_m, offline_m, gen_m = None, None, None
     if rank == 0 and not args.headline_only and args.workload == "allegro_vector":
         try:  # BASELINE configs[4], the per-GPU slice: 1 048 576 / 8 frames of four robots in one batch

@@ -117,6 +117,14 @@ def final_line(d):
     for k in ("cold_start", "two_streams", "general_kernel"):
         if k in d:
             out[k] = _stub(d[k])
+    if isinstance(d.get("small_batch"), dict) and "error" not in d["small_batch"]:
+        sbd = d["small_batch"]
+        out["small_batch"] = {"frames": _num(sbd.get("frames"))}
+        for k, v in sbd.items():
+            if isinstance(v, dict) and "ms_per_step" in v:
+                out["small_batch"][k] = {"ms_per_step": _num(v["ms_per_step"]), "iters_max": _num(v.get("iters_max")),
+                                         "four_per_wave_ms": _num((v.get("four_per_wave") or {}).get("ms_per_step")),
+                                         "four_per_wave_iters_max": _num((v.get("four_per_wave") or {}).get("iters_max"))}
     if isinstance(d.get("also"), dict):
         out["also"] = {k: _stub(v) for k, v in d["also"].items()}
     if isinstance(d.get("online_teleop"), dict) and isinstance(d["online_teleop"].get("robots"), dict):
@@ -141,7 +149,7 @@ def dumps(line):
 
 def shrink(line):
     """Drop optional blocks, least important first, until the line fits."""
-    for k in ("online_ms_per_retarget", "two_streams", "cold_start", "general_kernel", "multi_gpu", "also", "f64", "solver"):
+    for k in ("small_batch", "online_ms_per_retarget", "two_streams", "cold_start", "general_kernel", "multi_gpu", "also", "f64", "solver"):
         if len(dumps(line)) <= MAX_BYTES:
             break
         line.pop(k, None)
