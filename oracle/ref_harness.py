@@ -118,6 +118,13 @@ def import_reference():
     import dex_retargeting.optimizer_utils as ou  # noqa: E402
     import dex_retargeting.seq_retarget as sr  # noqa: E402
 
+    # (tests/reference_suite aliases `dex_retargeting` to the drop-in inside its own pytest process; a checker that
+    # then imported "the reference" would silently compare the drop-in with itself -- refuse)
+    for mod in (opt, ka, sr, ou):
+        where = os.path.realpath(getattr(mod, "__file__", "") or "")
+        if not where.startswith("/root/reference/"):
+            raise RuntimeError(f"`{mod.__name__}` resolves to {where}, not to /root/reference: `dex_retargeting` is aliased in "
+                               f"this process (tests/reference_suite); import the reference in a process of its own")
     return opt, ka, sr, ou
 
 
