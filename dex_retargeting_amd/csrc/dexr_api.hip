@@ -294,6 +294,13 @@ int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st,
     const bool ladder = sprint && (tail_launch || m->tune.sprint_ladder != 0);  // (-1: policy = on; the tail launch always)
     const float mu_on[4] = {0.03f, 0.3f, 3.f, 30.f};
     for (int r = 0; r < 4; ++r) kp.sprint_mu[r] = ladder ? mu_on[r] : 1.f;
+    // THE LADDER TAKES NO BLIND STEPS (round 6).  "A nearly undamped Newton step below blind_tol is the answer" is safe on the
+    // four-frames-per-wave iteration, where lambda <= lambda0 is only reached through a run of well-predicted steps; on the ladder
+    // the least damped row sits at 0.03 x lambda from the first pass on, and the rule ended frames 1e-4 ... 1.5e-3 rad short of
+    // the minimum (offline Panda frame 1849 after 2 passes, LEAP DexPilot frame 419 after 5: tools/ladder_probe.py,
+    // profiles/r06_ladder_probe.txt; the B = 2 048 parity table's certification caught both).  Every step is verified by a
+    // pass at the new point; the pass that confirms convergence costs kinematics + value only (dexr_wide.hpp).
+    if (ladder) kp.blind_tol = 0.f;
   }
   const int64_t tiles = (kp.B + fpw - 1) / fpw;
   // waves per SIMD: 2 (256 VGPRs; 15-17 KB of LDS per wave); the 16-row joint grid is built for 3 (168 VGPRs, 11.8 KB):

@@ -1429,7 +1429,9 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         }
         done = (bool)((int)done | (int)(my_iters >= kp.max_iter));
       }
-      if (SPRINT && __any(take)) {
+      // (a frame that this very pass finished -- the accepted step was below the tolerance: the verification pass of the ladder,
+      // which takes no blind steps -- needs no model at its final point: value and kinematics were all the pass had to pay)
+      if (SPRINT && __any((bool)((int)take & (int)!done))) {
         // the model at the kept point: its kinematic state and term blocks lie in the frame slot of the row that evaluated it
         const int ws = __builtin_amdgcn_readfirstlane(wrow);
         unsigned char* wb = wbase + L::SLOT0 + (size_t)ws * L::SLOT;
@@ -1485,6 +1487,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     bool okf = true;
 #pragma clang loop unroll(disable)
     for (int attempt = 0;; ++attempt) {
+      if (SPRINT && !__any((bool)((int)active & (int)!done))) break;  // (the wave's one frame is finished: nothing to step from)
       okf = factor_and_solve(freemask, lam * mu_own);
       // (not at n = 32: the loop around the 32 x 32 factorisation costs 60 more spilled registers, +16 % per launch)
       // (SPRINT: a row whose damped model is indefinite is simply not a candidate; only when NO row has a step is the damping
@@ -1556,6 +1559,26 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       // (see dexr_quad.hpp: verified undamped model, tiny Newton step; beyond 10 tol only on the quadratic tail of the
       // iteration -- the step must be at most a tenth of the previous accepted one, as in the small-component kernel)
       bool last_step = (bool)((int)okf & (int)(smax < kp.blind_tol) & (int)(lam_row <= kp.lam0) & ((int)(smax < 10.f * kp.tol) | (int)(smax < 0.1f * sprev)));
+      // ... and no variable held at a bound may be about to come off it (round 6).  The step is judged by the model of the FREE
+      // variables; a held variable i stays held only while its multiplier g_i keeps its sign, and the step changes it by
+      // (H d)_i.  A frame whose held thumb joint had g_i = 1.4e-5 and (H d)_i = -3.7e-5 took a 1.1e-5 rad blind step and ended
+      // 1.5e-3 rad from the minimum the verified iteration reaches two passes later (LEAP DexPilot, tools/data/
+      // r06_straddle_far_frames.npz frame 1041; the host emulation tools/lm_lab.py reproduces it pass by pass).  |(H d)_i| is
+      // bounded by n_free x max diag(H) x |d|_inf (H's Gauss-Newton part is positive semi-definite); a quarter of that bound
+      // (8.7 x the failure's own ratio; lab: +0.9 % passes on Shadow DexPilot, none on LEAP, profiles/r06_blind_step_guard.txt)
+      // marks a weakly held variable, and such a frame verifies its last step like any other.
+      if (__any(last_step)) {
+        float hdl = 0.f;
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+          if ((bool)((int)(a == b) & (int)((freemask >> (4 * i + a)) & 1u))) hdl = fmaxf(hdl, (i & 1) ? Ha[i][i / 2].y : Ha[i][i / 2].x);
+        const float tau = 0.25f * (float)__popc(freemask) * (row_max(hdl) + 2.f * delta) * smax;
+        bool weakl = false;
+#pragma unroll
+        for (int s = 0; s < NJ2; ++s)
+          weakl = (bool)((int)weakl | ((int)jin[s] & (int)jopt[s] & (int)!son[s] & (int)(fabsf(GVl[sjg[s]]) < tau)));
+        last_step = (bool)((int)last_step & (int)!(row_max(weakl ? 1.f : 0.f) > 0.f));
+      }
       if (SPRINT) {  // any row's step qualifies: the least damped such row's point is the answer, for every row
         const unsigned long long lb = __ballot(last_step);
         if (lb != 0ull) {

@@ -222,8 +222,8 @@ def straddle(require_gpu):
     2 049 (four frames per wave): the launch policy's threshold (csrc/dexr_api.hip launch_wide_once) seen from both sides."""
     n = B_SMALL + 1
     rows = {}
+    dump = {}
     with _pool() as ex:
-        todo = []
         for rel in ALL:
             seq = RetargetingConfig.load_from_file(os.path.join(cases.CONFIG_DIR, rel)).build()
             prob = cases.problem_from_config(rel)
@@ -247,6 +247,12 @@ def straddle(require_gpu):
             if len(sel):
                 ref = np.ascontiguousarray(cases.ref_from_keypoints(prob, kp1[sel]), dtype=np.float32)
                 s_in = None if st_in is None else st_in[sel]
+                k = rel.replace("/", "__").replace(".yml", "")
+                dump[k + "__idx"], dump[k + "__ref"], dump[k + "__last"] = sel, ref, last[sel]
+                dump[k + "__q_gpu"], dump[k + "__q_oracle"] = qb[sel], qa[sel]  # (names as in the parity table's dump: tools/ladder_probe.py reads both)
+                dump[k + "__iters"] = ib["iters"][sel]
+                if s_in is not None:
+                    dump[k + "__state_in"] = s_in
                 w["fut"] = (ex.submit(oracle_jobs.oracle_solve, (rel, ref, last[sel], s_in, qa[sel])),
                             ex.submit(oracle_jobs.oracle_solve, (rel, ref, last[sel], s_in, qb[sel])),
                             ex.submit(oracle_jobs.certify_local_minimum, (rel, ref, last[sel], s_in, qa[sel])),
@@ -259,6 +265,7 @@ def straddle(require_gpu):
                          moved=float(max(ca[0].max(), cb[0].max())), dF=float(max(ca[1].max(), cb[1].max())))
     out = os.path.join(REPO, "gpurun_out")
     os.makedirs(out, exist_ok=True)
+    np.savez_compressed(os.path.join(out, "straddle_far_frames.npz"), **dump)
     with open(os.path.join(out, "straddle_2048_2049.txt"), "w") as f:
         f.write(f"# the same {B_SMALL} frames as a batch of {B_SMALL} and as rows 0..{B_SMALL - 1} of a batch of {B_SMALL + 1}, library defaults\n")
         f.write(f"{'config':44s} {'kernel':>14s} {'max dq':>9s} {'p99.9 dq':>9s} {'>=1e-4':>7s} {'worse@2048':>10s} {'worse@2049':>10s} {'cert moved':>10s} {'cert dF':>9s}\n")

@@ -1128,7 +1128,9 @@ def test_one_frame_per_wave_launch_shape_agrees_with_four_per_wave_and_the_oracl
         same = np.abs(qa - qc).max(1) < 1e-4
         assert same.mean() >= 0.995, (rel, B, float(same.mean()))
         if B > 1:
-            assert itc.mean() <= ita.mean() + 0.05 and itc.max() <= ita.max() + 2, (rel, B, ita.mean(), itc.mean(), ita.max(), itc.max())
+            # (round 6: the ladder takes no blind last step -- every frame's count includes the pass that CONFIRMS its last step,
+            # a pass of kinematics + value only; the four-per-wave count ends with an unverified step on most frames)
+            assert itc.mean() <= ita.mean() + 1.05 and itc.max() <= ita.max() + 2, (rel, B, ita.mean(), itc.mean(), ita.max(), itc.max())
         if dex:
             assert np.array_equal(sta, stb) and np.array_equal(sta, stc)
         if B == 333:

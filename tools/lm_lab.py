@@ -105,7 +105,7 @@ def kernel_lm(cm, *, lam0=1e-4, tol=2e-6, max_iter=64, step_cap=0.3, lam_jump=1.
               max_blind=8, stall_from=2, stall_ratio=0.9, stall_cap=20.0, newton=True, eps=5.96e-8, gn_when=None,
               cap_mode="inf", lam_floor=1e-9, trace=None, inner_retry=0, cap_grow=0.0, cap_max=1.2, gersh_at=99, retry_mult=None, pivot_rule=None, pivot_floor=1e-3, blind_contract=0.0, neg_boost=0.0, jump_mode="hd", noise_scale=None,
               dec_rule=None, accel=0.0, accel_rho=0.9, gn_mode=None, gn_exit=0.05, gn_lam=None, tr_retry=0, tr_factor=2.0, tr_pow=1.0,
-              lam_start=None, first_jump=None, fail_floor=None):
+              lam_start=None, first_jump=None, fail_floor=None, blind_guard=None):
     """Returns (x (B,T,m), iters (B,T)).  `eps`: rounding unit of the kernel's arithmetic (float32) for the
     below-the-floor logic.  gn_when: optional callable(F, lam, it) -> bool mask selecting Gauss-Newton models."""
     B, T, m = cm.B, cm.T, cm.m
@@ -224,6 +224,8 @@ def kernel_lm(cm, *, lam0=1e-4, tol=2e-6, max_iter=64, step_cap=0.3, lam_jump=1.
         last_step = ok & (smax < blind_tol_scale * tol) & (lam <= lam0)
         if blind_contract > 0:  # only when the previous step shows the fast (quadratic) contraction of a clean Newton tail
             last_step = last_step & ((smax < 10 * tol) | (smax < blind_contract * sprev))
+        if blind_guard is not None:  # callable(act, free, gs, Hs, step, smax) -> (B, T) bool: may the step be taken unverified?
+            last_step = last_step & blind_guard(act & vm, free, gs, Hs, xt - x, smax)
         Ft, gt, Ht = cm(np.where(done[..., None], x, xt), newton)
         noise = 16 * eps * np.abs(F) if noise_scale is None else noise_scale * np.abs(F)
         finite = np.isfinite(Ft)
