@@ -49,6 +49,9 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3
 FP64_VALU_PEAK_TFLOPS = 78.6
 N_BATCHES = 4  # pre-staged input batches rotated over the steps
+# what the sixteen-lane kernel computes in (csrc/dexr_wide.hpp:8-24): kinematics, residuals, objective value in float64; gradient,
+# Hessian, factorisation in float32.  (The headline's tip kernel is float32 throughout: "f32".)
+WIDE_DTYPE = "f64 kinematics + f32 Hessian"
 
 FLEET = ["teleop/allegro_hand_right.yml", "teleop/shadow_hand_right_dexpilot.yml", "teleop/leap_hand_right.yml",
          "teleop/ability_hand_right.yml"]  # BASELINE.json configs[4]: 4 URDFs in one batch
@@ -224,6 +227,42 @@ class Workload:
         if comm is not None:
             elapsed = float(comm.max_f64([elapsed], self.stream.cuda_stream)[0])
         return elapsed, kernel_ms
+
+    def sustained(self, batches, seconds=6.0, chunk=4000):
+        """A rate the driver can see from outside: back-to-back launches of the workload for >= `seconds` (the
+        staged batches rotating), HIP events on the launch stream every `chunk` steps.  ms/step from the events, from the wall
+        clock, and of the first / last tenth of the run (clock drift under sustained load)."""
+        torch = self.torch
+        est = 0.05e-3
+        for _ in range(3):
+            self.launch(batches[0], self.t_q)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(200):
+            self.launch(batches[k % len(batches)], self.t_q)
+        torch.cuda.synchronize()
+        est = max((time.perf_counter() - t0) / 200, 1e-6)
+        n_chunks = max(10, int(np.ceil(max(seconds / est, 40000) / chunk)))
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_chunks + 1)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k = 0
+        evs[0].record(self.stream)
+        for c in range(n_chunks):
+            for _ in range(chunk):
+                self.launch(batches[k % len(batches)], self.t_q)
+                k += 1
+            evs[c + 1].record(self.stream)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        per = np.array([evs[c].elapsed_time(evs[c + 1]) / chunk for c in range(n_chunks)])
+        tenth = max(1, n_chunks // 10)
+        steps = n_chunks * chunk
+        return {"steps": steps, "seconds": wall, "ms_per_step": float(evs[0].elapsed_time(evs[-1])) / steps, "wall_ms_per_step": wall / steps * 1e3,
+                "first_decile_ms_per_step": float(per[:tenth].mean()), "last_decile_ms_per_step": float(per[-tenth:].mean()),
+                "min_chunk_ms_per_step": float(per.min()), "max_chunk_ms_per_step": float(per.max()),
+                "value": self.B * steps / wall, "unit": "frames/s",
+                "note": f"{steps} consecutive launches ({n_chunks} chunks of {chunk} between HIP events), {len(batches)} staged batches rotating, single stream"}
 
     def timed_two_streams(self, batches, steps, warmup):
         """Throughput when consecutive (independent) batches are issued alternately on TWO HIP streams, each with its
@@ -434,7 +473,7 @@ def online_run(rel):
     r0 = data[0][indices, :] if position else data[0][indices[1, :], :] - data[0][indices[0, :], :]
     opt.device_model().retarget(r0[None].astype(np.float32), None, seq.last_qpos[None].astype(np.float32),
                                 state=np.zeros(1, np.uint32) if opt.retargeting_type == "DEXPILOT" else None)
-    dt, qs, refs, lasts = [], [], [], []
+    dt, qs, refs, lasts, raws = [], [], [], [], []
     for joint_pos in data:
         ref_value = joint_pos[indices, :] if position else joint_pos[indices[1, :], :] - joint_pos[indices[0, :], :]
         lasts.append(np.clip(seq.last_qpos, seq.joint_limits[:, 0], seq.joint_limits[:, 1]).astype(np.float32))
@@ -442,6 +481,7 @@ def online_run(rel):
         q = seq.retarget(ref_value)
         dt.append(time.perf_counter() - tic)
         qs.append(q)
+        raws.append(np.asarray(seq.last_qpos, dtype=np.float32).copy())  # the optimizer's own answer (unfiltered, target-joint order)
         refs.append(ref_value.astype(np.float32))
     # the bare C-ABI call on the same (ref, last) pairs: what a C / C++ caller of libdexr.so pays per frame
     model = opt.device_model()
@@ -453,7 +493,7 @@ def online_run(rel):
         tic = time.perf_counter()
         model.retarget(r1, None, l1, state=st)
         dt_abi.append(time.perf_counter() - tic)
-    return np.array(dt), np.array(qs), np.array(dt_abi), np.array(refs), np.array(lasts), seq
+    return np.array(dt), np.array(qs), np.array(dt_abi), np.array(refs), np.array(lasts), seq, np.array(raws)
 
 
 def online_record():
@@ -465,7 +505,7 @@ def online_record():
     ctx = None
     for rel, title in ONLINE_ROBOTS:
         try:
-            dt, qs, dt_abi, refs, lasts, seq = online_run(rel)
+            dt, qs, dt_abi, refs, lasts, seq, raws = online_run(rel)
         except Exception as e:  # never lose the headline line to a sub-record
             out["robots"][rel] = {"error": repr(e)}
             continue
@@ -477,7 +517,7 @@ def online_record():
                               "note": "dexr_retarget (host pointers) alone, through ctypes: pack -> one H2D -> solve "
                                       "kernel -> one D2H on the handle's private stream -> hipStreamSynchronize"}}
         ctx = ctx or []
-        ctx.append(dict(rel=rel, refs=refs, lasts=lasts, lo=seq.joint_limits[:, 0].copy(), hi=seq.joint_limits[:, 1].copy()))
+        ctx.append(dict(rel=rel, refs=refs, lasts=lasts, raws=raws, lo=seq.joint_limits[:, 0].copy(), hi=seq.joint_limits[:, 1].copy()))
         out["robots"][rel] = rec
     return out, ctx
 
@@ -512,6 +552,102 @@ def online_cpu_port(rec, ctxs):
             "note": "the oracle's plain-C closure + scipy's compiled SLSQP at the reference's ftol, its own warm-start chain over "
                     "the 621 fixture frames (the reference's loop, profile_online_retargeting.py:18-36, with compiled stand-ins "
                     "for pinocchio / nlopt and no torch overhead)"}
+
+
+def frame_parity(rel, refs, lasts, q_gpu, state_in=None, pool=None):
+    """Checker: `q_gpu` (B, n_opt) against the float64 oracle minimiser of F from the same (ref, last[, DexPilot state]) frame by
+    frame -- the block every sub-record carries: fraction within 1e-4 rad, max |dq| of those, and the frames that sit in ANOTHER
+    local minimum (counted, with how many of them have the higher objective)."""
+    from oracle import jobs
+
+    q64 = np.asarray(q_gpu, dtype=np.float64)
+    o = jobs.pooled_oracle_solve(rel, np.ascontiguousarray(refs, dtype=np.float32), np.ascontiguousarray(lasts, dtype=np.float32),
+                                 state_in, q64, chunk=64, pool=pool)
+    dq = np.abs(q64 - o["want"]).max(1)
+    far = dq >= 1e-4
+    return {"subset": int(len(dq)), "frac_within_1e-4": float((~far).mean()), "max_abs_dq_rad": float(dq[~far].max()) if (~far).any() else None,
+            "median_abs_dq_rad": float(np.median(dq)),
+            "other_minimum": {"frames": int(far.sum()), "worse": int((far & (o["F_gpu"] > o["F_want"] + 1e-10)).sum())}}
+
+
+def online_parity(rec, ctxs):
+    """Checker-side leg of `online_teleop` (VERDICT r5 #1c): every one of the 621 one-frame calls against the oracle from the SAME
+    last_qpos (the loop's own warm-start chain) -- the launch shape every SeqRetargeting.retarget() of a 9-32-joint model takes
+    (one frame per wave + ladder).  DexPilot robots: the projection bits each frame started from are rebuilt from the targets alone
+    (optimizer.py:466-476: the state never depends on the answers)."""
+    from oracle import cases, jobs
+
+    with jobs.host_pool() as pool:
+        for ctx in ctxs:
+            rel, refs, lasts, raws = ctx["rel"], ctx["refs"], ctx["lasts"], ctx["raws"]
+            prob = cases.problem_from_config(rel)
+            st_in = None
+            if prob.kind == "dexpilot":
+                proj = np.zeros((1, prob.n_pair), bool)
+                st_in = np.zeros(len(refs), np.uint32)
+                for i in range(len(refs)):
+                    st_in[i] = int((proj[0].astype(np.uint64) << np.arange(prob.n_pair, dtype=np.uint64)).sum())
+                    _, _, proj = prob.dexpilot_preamble(refs[i][None], proj)
+            try:
+                rec["robots"][rel]["parity"] = frame_parity(rel, refs, lasts, raws, st_in, pool=pool)
+            except Exception as e:
+                rec["robots"][rel]["parity"] = {"error": repr(e)}
+
+
+def reference_profile_script_record():
+    """Sub-record `reference_profile_script`: /root/reference/example/profiling/profile_online_retargeting.py:39-77
+    run UNMODIFIED -- its main(), its loop (:18-36), its prints -- with `dex_retargeting` aliased to the drop-in, in a process of
+    its own (tests/reference_suite/run_profile_script.py; the script and its pickle are staged byte for byte by
+    tests/reference_suite/stage.py, git-ignored).  7 robots x {vector, DexPilot} = 14 rows.  main() is executed twice in that
+    process: the script creates the process's first HIP context inside its first row's timer (pass 1, as printed), pass 2 is the
+    same script on a warm process."""
+    import subprocess
+
+    runner = os.path.join(REPO, "tests", "reference_suite", "run_profile_script.py")
+    r = subprocess.run([sys.executable, runner, "--json", "--passes", "2"], capture_output=True, text=True, timeout=900, cwd=REPO)
+    if r.returncode != 0:
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    recs = [json.loads(l.split(" ", 1)[1]) for l in r.stdout.splitlines() if l.startswith("REFERENCE_PROFILE_SCRIPT ")]
+    rows = recs[-1]["rows"]
+    out = {"script": "example/profiling/profile_online_retargeting.py (unmodified; sha256 in tests/reference_suite/_ref/MANIFEST.json)",
+           "frames_per_row": 621, "rows": rows, "unit": "fps (the script's own: 621 / summed perf_counter time around retarget())"}
+    if len(recs) > 1:
+        out["first_pass_rows"] = recs[0]["rows"]
+    out["stdout"] = [l for l in r.stdout.splitlines() if not l.startswith("REFERENCE_PROFILE_SCRIPT ")][-15:]
+    return out
+
+
+def reference_profile_cpu_port(rec):
+    """Checker-side leg of `reference_profile_script`: the CPU port (the oracle's plain-C closure + scipy's SLSQP at the reference's
+    ftol, its own warm-start chain) on the SAME 14 rows, same fixture, one call per frame."""
+    import bench_data
+    from dex_retargeting_amd.constants import ROBOT_NAME_MAP, HandType, RetargetingType, get_default_config_path
+    from oracle import cases, cport
+
+    data = np.load(bench_data.HUMAN_FIXTURE)
+    for row in rec["rows"]:
+        rn = [k for k, v in ROBOT_NAME_MAP.items() if v == row["robot"]][0]
+        rt = RetargetingType.vector if row["kind"] == "vector" else RetargetingType.dexpilot
+        rel = os.path.relpath(str(get_default_config_path(rn, rt, HandType.right)), cases.CONFIG_DIR)
+        prob = cases.problem_from_config(rel)
+        cp = cport.CProblem(prob)
+        refs = np.ascontiguousarray(cases.ref_from_keypoints(prob, data), dtype=np.float32)
+        lo, hi = prob.joint_limits[:, 0], prob.joint_limits[:, 1]
+        last = prob.joint_limits.mean(1).astype(np.float64)
+        proj = np.zeros((1, prob.n_pair), bool) if prob.kind == "dexpilot" else None
+        t = 0.0
+        for i in range(len(refs)):
+            tic = time.perf_counter()
+            kw = {}
+            if proj is not None:
+                w, rv, proj = prob.dexpilot_preamble(refs[i][None], proj)
+                kw = dict(weights=w, dexpilot_ref=rv)
+            q_ref, _ = cport.solve_ref_as_configured_c(cp, refs[i][None], None, np.clip(last, lo, hi)[None].astype(np.float32), **kw)
+            t += time.perf_counter() - tic
+            last = q_ref[0].astype(np.float64)
+        row["cpu_port_fps"] = len(refs) / t
+    rec["cpu_port"] = {"kind": "port", "cores": 1, "note": "oracle/csrc closure + scipy SLSQP at the reference's ftol on the same 621-frame "
+                                                            "loop per row (compiled stand-ins for pinocchio / nlopt, no torch overhead)"}
 
 
 OFFLINE_ROBOTS = ["offline/allegro_hand_right.yml", "offline/shadow_hand_right.yml", "offline/leap_hand_right.yml",
@@ -1047,6 +1183,12 @@ def run_single(args):
                                          "N(0,1) clipped to the limits: tests/test_optimizer.py:27-81 of the reference"}
     if rank == 0 and not args.headline_only:
         try:
+            sub["sustained"] = wl.sustained(wl.tracking, seconds=args.sustained_seconds)
+            sub["sustained"]["vs_ms_per_step"] = sub["sustained"]["ms_per_step"] / (elapsed / args.steps * 1e3)
+        except Exception as e:
+            sub["sustained"] = {"error": repr(e)}
+    if rank == 0 and not args.headline_only:
+        try:
             sub["two_streams"] = wl.timed_two_streams(wl.tracking, args.steps, args.warmup)
         except Exception as e:
             sub["two_streams"] = {"error": repr(e)}
@@ -1061,6 +1203,14 @@ def run_single(args):
             sub["online_teleop"], online_ctx = online_record()
         except Exception as e:
             sub["online_teleop"] = {"error": repr(e)}
+    ref_script = None
+    if rank == 0 and not args.headline_only and args.workload == "allegro_vector":
+        torch.cuda.synchronize()
+        try:
+            ref_script = reference_profile_script_record()
+        except Exception as e:
+            ref_script = {"error": repr(e)}
+        sub["reference_profile_script"] = ref_script
     also = {}
     if rank == 0 and not args.headline_only and args.workload == "allegro_vector":
         for name in ("shadow_dexpilot", "leap_position"):
@@ -1074,13 +1224,32 @@ def run_single(args):
             b2 = w2.tracking[(args.steps - 1) % N_BATCHES]
             w2.launch(b2, w2.t_q)
             torch.cuda.synchronize()
-            also[name] = (w2, b2, w2.t_q.cpu().numpy(),
-                          {"config_file": w2.rel, "workload": w2.title, "dtype": "f32", "value": B * args.steps / e2,
+            q2 = w2.t_q.cpu().numpy()
+            # the same config in the reference's own arithmetic (optimizer.py:263-300, 524-573: float64 throughout):
+            # dexr_solve_options.precision = 1 -> the register kernel dexr_kernel<24, double> (one lane per frame; the only
+            # all-float64 implementation of these models) -- a few steps, whatever it costs
+            try:
+                o64 = _lib.default_options(precision=1)
+                s64, w64 = max(2, min(args.steps, 4)), 1
+                d64b = w2.diagnostics(w2.tracking[:1], opts=o64)
+                e64b, k64b = w2.timed(w2.tracking, s64, w64, opts=o64)
+                w2.launch(b2, w2.t_q, opts=o64)
+                torch.cuda.synchronize()
+                f64rec = {"dtype": "f64", "value": B * s64 / e64b, "unit": "frames/s", "ms_per_step": e64b / s64 * 1e3, "steps": s64,
+                          "kernel": f"dexr_kernel<{w2.model.kernel()[1]}, double> (register kernel, float64 arithmetic throughout)",
+                          "solver": d64b, "max_abs_dq_vs_default_rad": float(np.abs(w2.t_q.cpu().numpy().astype(np.float64) - q2).max()),
+                          "p999_abs_dq_vs_default_rad": float(np.percentile(np.abs(w2.t_q.cpu().numpy().astype(np.float64) - q2).max(1), 99.9))}
+            except Exception as e:
+                f64rec = {"error": repr(e)}
+            also[name] = (w2, b2, q2,
+                          {"config_file": w2.rel, "workload": w2.title, "dtype": WIDE_DTYPE if w2.model.kernel()[0] == _lib.KERNEL_WIDE else "f32",
+                           "value": B * args.steps / e2,
                            "unit": "frames/s", "n_gpus": 1, "ms_per_step": e2 / args.steps * 1e3, "solver": d2,
-                           "roofline": w2.roofline(k2, d2["iters_mean"]), "two_streams": ts2})
+                           "roofline": w2.roofline(k2, d2["iters_mean"]), "two_streams": ts2, "f64": f64rec})
 
     # small batches (round 5): up to 2 048 frames a model on the sixteen-lane kernel runs one frame per wave with a ladder of
     # damping values (dexr_tuning.sprint_max_batch / sprint_ladder); the same batches four frames per wave beside it
+    small_ctx = {}
     if rank == 0 and not args.headline_only and args.workload == "allegro_vector":
         try:
             sb = {"frames": 700, "note": "700 tracking frames per launch: default policy (one frame per wave + ladder) vs four frames per wave"}
@@ -1092,6 +1261,10 @@ def run_single(args):
                 d4 = w3.diagnostics(w3.tracking)
                 e4, k4 = w3.timed(w3.tracking, args.steps, args.warmup)
                 w3.model.tune(sprint_max_batch=-1)
+                b3 = w3.tracking[0]
+                w3.launch(b3, w3.t_q)
+                torch.cuda.synchronize()
+                small_ctx[name] = (w3, b3, w3.t_q.cpu().numpy(), None if b3["host_state"] is None else b3["host_state"].astype(np.uint32))
                 sb[name] = {"ms_per_step": e3 / args.steps * 1e3, "value": 700 * args.steps / e3, "iters_mean": d3["iters_mean"], "iters_max": d3["iters_max"],
                             "four_per_wave": {"ms_per_step": e4 / args.steps * 1e3, "iters_mean": d4["iters_mean"], "iters_max": d4["iters_max"]}}
             sub["small_batch"] = sb
@@ -1147,11 +1320,30 @@ def run_single(args):
         rec["parity"] = parity_block(w2, b2, q2, min(4096, B), 0 if args.no_cpu_baseline else min(64, B))[0]
         out.setdefault("also", {})[name] = rec
 
+    if online_ctx is not None:
+        try:
+            online_parity(out["online_teleop"], online_ctx)
+        except Exception as e:
+            out["online_teleop"]["parity_error"] = repr(e)
+    for name, (w3, b3, q3, st3) in small_ctx.items():
+        try:
+            from oracle import cases as _cases
+
+            prob3 = _cases.problem_from_config(w3.rel)
+            out["small_batch"][name]["parity"] = frame_parity(
+                w3.rel, _cases.ref_from_keypoints(prob3, b3["host_in"]), b3["host_last"], q3, st3)
+        except Exception as e:
+            out["small_batch"][name]["parity"] = {"error": repr(e)}
     if online_ctx is not None and not args.no_cpu_baseline:
         try:
             online_cpu_port(out["online_teleop"], online_ctx)
         except Exception as e:
             out["online_teleop"]["cpu_port_error"] = repr(e)
+    if ref_script is not None and "rows" in ref_script and not args.no_cpu_baseline:
+        try:
+            reference_profile_cpu_port(ref_script)
+        except Exception as e:
+            ref_script["cpu_port_error"] = repr(e)
     if fleet_m is not None:
         import bench_fleet
 
@@ -1289,6 +1481,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every host-CPU solve (baseline and SLSQP distance)")
     ap.add_argument("--headline-only", action="store_true", help="skip the f64 / cold-start / other-config sub-records")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="frames of the workload timed on the host CPU")
+    ap.add_argument("--sustained-seconds", type=float, default=6.0, help="length of the back-to-back `sustained` record")
     ap.add_argument("--nccl-algo", default=None, help="sets NCCL_ALGO before the RCCL communicator exists (e.g. Ring, Tree, Direct)")
     ap.add_argument("--nccl-proto", default=None, help="sets NCCL_PROTO (e.g. Simple, LL, LL128)")
     ap.add_argument("--fleet-order", default="iid", choices=("iid", "sorted"),

@@ -163,6 +163,55 @@ def fleet_measure(args, batch=None, standalone=True):
                      "kernel": "dexr_retarget_multi_dev: device-side bucketing (3 small kernels) + one solve launch per model "
                                "over its index list, in-place rows"},
     }
+    out_json["dtype"] = "per model: f32, or f64 kinematics + f32 Hessian"  # (tip / register kernels; Shadow DexPilot on the sixteen-lane kernel)
+    if world == 1:
+        # the same frames in the reference's own arithmetic (float64 throughout).  dexr_retarget_multi_dev runs the
+        # float32 / mixed-precision kernels only, so: the batch bucketed by model up front (untimed torch index ops), then one
+        # float64 launch per model (dexr_retarget_kp_dev, precision = 1) over its contiguous rows -- the four launches are timed.
+        try:
+            from dex_retargeting_amd import _lib
+
+            o64 = _lib.default_options(precision=1)
+            b0 = last_b
+            per = []
+            for m, sq in enumerate(seqs):
+                idx = torch.nonzero(b0["t_mid"] == m).flatten()
+                n_m, n_opt = int(idx.numel()), sq.optimizer.opt_dof
+                per.append(dict(model=fleet.models[m], n=n_m, kp=b0["t_kp"][idx].contiguous(), last=b0["t_last"][idx][:, :n_opt].contiguous(),
+                                st0=b0["t_state0"][idx].contiguous(), st=torch.zeros(n_m, dtype=torch.int32, device=dev),
+                                out=torch.empty((n_m, n_opt), dtype=torch.float32, device=dev), idx=idx, n_opt=n_opt,
+                                dex=sq.optimizer.retargeting_type == "DEXPILOT"))
+
+            def f64_step():
+                for p_ in per:
+                    if p_["dex"]:
+                        p_["st"].copy_(p_["st0"])
+                    p_["model"].retarget_dev(p_["n"], p_["kp"].data_ptr(), 0, p_["last"].data_ptr(), p_["st"].data_ptr() if p_["dex"] else 0,
+                                             p_["out"].data_ptr(), opts=o64, stream=stream.cuda_stream, keypoints=True)
+
+            f64_step()
+            torch.cuda.synchronize()
+            s64 = max(2, min(args.steps, 3))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record(stream)
+            for _ in range(s64):
+                f64_step()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            q64 = np.zeros_like(q)
+            for p_ in per:
+                q64[p_["idx"].cpu().numpy(), : p_["n_opt"]] = p_["out"].cpu().numpy()
+            dq = np.abs(q64.astype(np.float64) - q).max(1)
+            out_json["f64"] = {"dtype": "f64", "value": B * s64 / el, "unit": "frames/s", "ms_per_step": el / s64 * 1e3, "steps": s64,
+                               "event_ms_per_step": float(e0.elapsed_time(e1)) / s64,
+                               "max_abs_dq_vs_default_rad": float(dq.max()), "p999_abs_dq_vs_default_rad": float(np.percentile(dq, 99.9)),
+                               "note": "one float64 launch per model (dexr_retarget_kp_dev, precision = 1) over its rows of the same batch, "
+                                       "bucketed by model beforehand (untimed): the fleet entry point itself runs the float32 / "
+                                       "mixed-precision kernels only"}
+        except Exception as e:
+            out_json["f64"] = {"error": repr(e)}
     if comm is not None:
         comm.close()
     return out_json, dict(q=q, last=last, st_in=st_in, mid=mid, kp=kp, world=world, standalone=standalone, coll=coll)

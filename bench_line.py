@@ -83,26 +83,37 @@ def _stub(rec):
     p = rec.get("parity")
     if isinstance(p, dict):
         out["parity"] = _parity(p)
+    f = rec.get("f64")
+    if isinstance(f, dict):  # the same config in the reference's arithmetic (float64 throughout)
+        out["f64"] = {"error": str(f["error"])[:80]} if "error" in f and "value" not in f else _pick(f, ("value", "ms_per_step"))
     return out
+
+
+def _mini_parity(p):
+    """[fraction within 1e-4 rad, frames in another minimum, of which worse] -- three numbers for blocks that come in bulk."""
+    if not isinstance(p, dict) or "frac_within_1e-4" not in p:
+        return None
+    om = p.get("other_minimum") or {}
+    return [_num(p["frac_within_1e-4"]), _num(om.get("frames")), _num(om.get("worse"))]
 
 
 def final_line(d):
     """detail dict (what run_single / bench_fleet assemble) -> the compact dict printed as the last stdout line."""
     out = {k: _num(d.get(k)) for k in CONTRACT}
     cfg = d.get("config", {}) or {}
-    out["config"] = {"workload": str(cfg.get("workload", ""))[:200]}
+    out["config"] = {"workload": str(cfg.get("workload", ""))[:110]}
     for k in ("config_file", "batch_per_gpu", "frames_per_gpu", "n_opt", "n_ref", "rccl_world_size", "models"):
         if k in cfg:
             out["config"][k] = cfg[k] if isinstance(cfg[k], (str, list)) else _num(cfg[k])
     if "collective" in cfg:
-        out["config"]["collective"] = str(cfg["collective"])[:160]
+        out["config"]["collective"] = str(cfg["collective"])[:70]
     if isinstance(d.get("solver"), dict):
         out["solver"] = _pick(d["solver"], ("iters_mean", "iters_max", "converged_frac", "active_lane_fraction"))
     out["roofline"] = _roofline(d.get("roofline"))
     if isinstance(d.get("cpu_baseline"), dict):
         c = d["cpu_baseline"]
         out["cpu_baseline"] = _pick(c, ("value", "unit", "cores", "kind"))
-        out["cpu_baseline"]["sample"] = str(c.get("sample", ""))[:160]
+        out["cpu_baseline"]["sample"] = str(c.get("sample", ""))[:70]
         ac = d.get("cpu_baseline_all_cores")
         if isinstance(ac, dict):
             out["cpu_baseline"]["all_cores"] = _pick(ac, ("value", "cores", "processes"))
@@ -124,12 +135,30 @@ def final_line(d):
             if isinstance(v, dict) and "ms_per_step" in v:
                 out["small_batch"][k] = {"ms_per_step": _num(v["ms_per_step"]), "iters_max": _num(v.get("iters_max")),
                                          "four_per_wave_ms": _num((v.get("four_per_wave") or {}).get("ms_per_step")),
-                                         "four_per_wave_iters_max": _num((v.get("four_per_wave") or {}).get("iters_max"))}
+                                         "parity": _mini_parity(v.get("parity"))}
+        out["small_batch"]["parity_is"] = "[frac within 1e-4 rad of oracle, frames in other minimum, worse ones]"
     if isinstance(d.get("also"), dict):
         out["also"] = {k: _stub(v) for k, v in d["also"].items()}
     if isinstance(d.get("online_teleop"), dict) and isinstance(d["online_teleop"].get("robots"), dict):
-        out["online_ms_per_retarget"] = {os.path.basename(k).replace(".yml", ""): _num(v.get("mean_ms"), 4)
+        # per robot: mean ms per SeqRetargeting.retarget() call + parity of the 621 calls vs the oracle (as small_batch.parity_is)
+        out["online_ms_per_retarget"] = {os.path.basename(k).replace(".yml", "").replace("_hand_right", ""):
+                                         {"ms": _num(v.get("mean_ms"), 4), "parity": _mini_parity(v.get("parity"))}
                                          for k, v in d["online_teleop"]["robots"].items() if isinstance(v, dict)}
+    su = d.get("sustained")
+    if isinstance(su, dict):
+        out["sustained"] = {"error": str(su["error"])[:100]} if "error" in su else _pick(
+            su, ("steps", "seconds", "ms_per_step", "wall_ms_per_step", "first_decile_ms_per_step", "last_decile_ms_per_step", "vs_ms_per_step"))
+    rs = d.get("reference_profile_script")
+    if isinstance(rs, dict):
+        rows = rs.get("rows") if isinstance(rs.get("rows"), list) else None
+        if rows:  # the reference's own benchmark script, unmodified: 14 "fps" rows -> five numbers (all rows: DETAIL line)
+            fps = sorted(float(r["fps"]) for r in rows)
+            pick = {(r["kind"], r["robot"]): r["fps"] for r in rows}
+            out["reference_profile_script"] = {"rows": len(rows), "fps_min": _num(fps[0], 4), "fps_median": _num(fps[len(fps) // 2], 4),
+                                               "fps_max": _num(fps[-1], 4), "allegro_vector": _num(pick.get(("vector", "allegro_hand")), 4),
+                                               "shadow_dexpilot": _num(pick.get(("dexpilot", "shadow_hand")), 4)}
+        else:
+            out["reference_profile_script"] = {"error": str(rs.get("error"))[:100]}
     mg = d.get("multi_gpu")
     if isinstance(mg, dict):
         m = {k: mg[k] for k in ("steps_per_gather", "rccl_world_size", "rccl_version") if k in mg}
@@ -139,7 +168,7 @@ def final_line(d):
         if "watchdog" in mg:
             m["watchdog"] = str(mg["watchdog"])[:160]
         out["multi_gpu"] = m
-    out["detail"] = "DETAIL lines above + bench_detail.json"
+    out["detail"] = "DETAIL lines above"
     return shrink(out)
 
 
@@ -148,13 +177,22 @@ def dumps(line):
 
 
 def shrink(line):
-    """Drop optional blocks, least important first, until the line fits."""
-    for k in ("small_batch", "online_ms_per_retarget", "two_streams", "cold_start", "general_kernel", "multi_gpu", "also", "f64", "solver"):
+    """Drop optional blocks, least important first, until the line fits.  Never raises (a ValueError here cost round 4
+    its contract line): if the contract fields + roofline + cpu_baseline alone are still too long, their strings are cut."""
+    for k in ("two_streams", "cold_start", "solver", "general_kernel", "small_batch", "online_ms_per_retarget", "reference_profile_script",
+              "sustained", "multi_gpu", "also", "f64", "parity", "detail"):
         if len(dumps(line)) <= MAX_BYTES:
             break
         line.pop(k, None)
     if len(dumps(line)) > MAX_BYTES:
-        raise ValueError("compact bench line exceeds %d bytes" % MAX_BYTES)
+        cfg = line.get("config") if isinstance(line.get("config"), dict) else {}
+        line["config"] = {"workload": str(cfg.get("workload", ""))[:80]}
+        if isinstance(line.get("cpu_baseline"), dict):
+            line["cpu_baseline"]["sample"] = str(line["cpu_baseline"].get("sample", ""))[:60]
+            line["cpu_baseline"].pop("all_cores", None)
+        if isinstance(line.get("roofline"), dict):
+            line["roofline"] = {k: line["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+        line["metric"] = str(line.get("metric", ""))[:200]
     return line
 
 
@@ -182,8 +220,9 @@ def emit(detail, path=None):
     for k, v in safe.items():
         if isinstance(v, (dict, list)):
             print("DETAIL " + json.dumps({k: v}))
-    for p in ([path] if path else [os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpurun_out", "bench_detail.json"),
-                                   "bench_detail.json"]):
+    # (the detail file lives under gpurun_out/ -- scratch, merged back by gpurun -- never in the repo root: a 220-byte stub a test
+    # once wrote there ended up in git, VERDICT r5 hygiene)
+    for p in ([path] if path else [os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpurun_out", "bench_detail.json")]):
         try:
             os.makedirs(os.path.dirname(os.path.abspath(p)), exist_ok=True)
             with open(p, "w") as f:
@@ -191,4 +230,11 @@ def emit(detail, path=None):
         except OSError:
             pass
     sys.stdout.flush()
-    print(dumps(final_line(safe)), flush=True)
+    try:
+        line = dumps(final_line(safe))
+    except Exception as e:  # the contract line is printed whatever a sub-record's shape does to the compaction above
+        line = dumps({k: _num(safe.get(k)) for k in CONTRACT} | {"config": {"workload": str((safe.get("config") or {}).get("workload", ""))[:200]},
+                                                                  "roofline": _roofline(safe.get("roofline")),
+                                                                  "cpu_baseline": _pick(safe.get("cpu_baseline") or {}, ("value", "unit", "cores", "kind")),
+                                                                  "compaction_error": repr(e)[:200]})
+    print(line, flush=True)

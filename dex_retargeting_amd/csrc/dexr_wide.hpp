@@ -1333,6 +1333,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     WPROF_STAGE(4)
     if (!done) {
       bool take = false;
+      bool sprint_floor = false;  // SPRINT: see below
       int wrow = slot;  // SPRINT: the row whose trial point is kept
       if (!pending) {
         F = Fe;
@@ -1363,6 +1364,13 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
           const bool small_own = (bool)((int)(ok || MODCHOL) & (int)finite & (int)(smax < kp.tol));
           const bool all_small = __ballot(small_own) == ~0ull;
           const bool all_finite = __ballot(finite) == ~0ull;
+          // (round 6) every row's step is below the tolerance and the least damped row's damping is small: the frame sits at the
+          // rounding floor of its float32 coordinates -- the less damped rows step one ulp uphill and are rejected, a heavily
+          // damped row "steps" zero ulps and is accepted, and its damping (x 3 or x 30, above lam_ok) kept the tiny-step exit
+          // below from firing, pass after pass up to max_iter (12 of 512 reachable-target frames of the SVH position model once
+          // the ladder stopped taking blind steps).  Same rule as the four-per-wave iteration's "a rejected step below tol ends
+          // the solve at the rounding floor".
+          sprint_floor = (bool)((int)all_small & (int)(lam * mu_0 <= fmaxf(2.f * delta, 10.f * kp.lam0)));
           if (any_ok) {
             const int src = (16 * w + l) << 2;
 #pragma unroll
@@ -1404,7 +1412,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
           blind = below_floor ? blind + 1 : 0;
           sprev = smax;
           const float lam_ok = fmaxf(2.f * delta, 10.f * kp.lam0);  // see dexr_quad.hpp
-          if ((bool)(((int)(smax < kp.tol) & (int)(lam <= lam_ok)) | (int)stalled | (int)(blind >= kp.max_blind))) {
+          if ((bool)(((int)(smax < kp.tol) & ((int)(lam <= lam_ok) | (int)sprint_floor)) | (int)stalled | (int)(blind >= kp.max_blind))) {
             done = true;
             status = ST_CONVERGED;
           } else if (smax < kp.tol) {

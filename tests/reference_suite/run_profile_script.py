@@ -5,6 +5,7 @@ is executed as `__main__` with runpy -- its own main(), its own timing loop (:18
 
     python tests/reference_suite/run_profile_script.py            # prints the script's 15 lines
     python tests/reference_suite/run_profile_script.py --json     # + one JSON line: {"rows": [{"kind", "robot", "seconds", "fps"} x 14]}
+    python tests/reference_suite/run_profile_script.py --json --passes 2   # main() twice in one process (second: warm HIP context)
 
 bench.py runs this file in a process of its own (DETAIL line `reference_profile_script`); tests/reference_suite/
 test_reference_profile_script.py runs it on the GPU and checks the 14 rows."""
@@ -66,7 +67,10 @@ def run():
 
 
 if __name__ == "__main__":
-    text, rows = run()
-    sys.stdout.write(text)
-    if "--json" in sys.argv:
-        print("REFERENCE_PROFILE_SCRIPT " + json.dumps({"rows": rows}))
+    passes = int(sys.argv[sys.argv.index("--passes") + 1]) if "--passes" in sys.argv else 1
+    for p in range(passes):  # (pass 1 pays the process's first HIP context inside the script's first row; pass 2: a warm process)
+        text, rows = run()
+        sys.stdout.write(text)
+        if "--json" in sys.argv:
+            print("REFERENCE_PROFILE_SCRIPT " + json.dumps({"pass": p + 1, "rows": rows}))
+        sys.stdout.flush()
