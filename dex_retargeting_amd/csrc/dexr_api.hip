@@ -278,6 +278,8 @@ namespace {
 // sixteen lanes per frame: four frames per wave, two waves per SIMD resident; persistent rows fed like the quads
 int launch_wide_once(const dexr_model* m, dexr::KernelParams kp, hipStream_t st, bool tail_launch = false) {
   const size_t per_wave = m->wide_mimic ? dexr::wide_lds_per_wave_m_16() : dexr::wide_lds_per_wave(m->wbucket);
+  // (a row copies its frame's input block -- keypoints or ref_value rows -- into the 1 KB term-block area of its LDS slot)
+  if (kp.kpts && kp.n_kp > 85) return fail(DEXR_ERR_UNSUPPORTED, "the sixteen-lane kernel takes at most 85 keypoints per frame (%d)", kp.n_kp);
   int wpb = 4;
   while (wpb > 1 && per_wave * wpb > 80 * 1024) wpb >>= 1;
   // ONE FRAME PER WAVE for small plain batches (dexr_wide.hpp SPRINT; dexr_tuning.sprint_max_batch):

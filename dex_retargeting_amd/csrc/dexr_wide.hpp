@@ -143,8 +143,8 @@ struct WideLds {
   static constexpr int GV = QJ + (MIMIC ? NJ * 4 : 0); // NMAX floats: gradient
   static constexpr int CF = GV + NMAX * 4;             // NJ x 4 floats: second-order vectors
   static constexpr int TB = CF + NJ * 16;              // 16 terms x 16 floats (MIMIC: reused for the second-order sums)
-  static constexpr int JR = TB + 1024;                 // 4 rows x 4 classes x NRP floats
-  static constexpr int FS = JR + 4 * 4 * NRP * 4;      // 32 bytes: row of the frame's inputs / of its item, item, frame of
+  static constexpr int JR = TB + 1024;                 // 3 rows x 4 classes x NRP floats
+  static constexpr int FS = JR + 3 * 4 * NRP * 4;      // 32 bytes: row of the frame's inputs / of its item, item, frame of
                                                        // the sequence, DexPilot bits (registers are the scarce resource)
   static constexpr int XL = FS + 32;                   // NMAX floats: regularisation target (the frame's start row)
   // (TGLDS: the terms' target vectors / weights in 256 B of the frame slot instead of four registers of the term's lane.  It
@@ -280,7 +280,14 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     const bool in = f < tb.n_frame;
 #pragma unroll
     for (int i = 0; i < 3; ++i) FO[f * 4 + i] = in ? tb.frame_off[f][i] : 0.f;
-    FO[f * 4 + 3] = 0.f;
+    // spare word of row f: the keypoint map of REFERENCE ROW f (task | origin << 8, 0xFF: no origin) -- read when a frame is
+    // taken (ref_row), from LDS instead of through a dependent global load in front of every keypoint read
+    uint32_t hm = 0xFF00u;
+    if (kp.kpts && f < kp.n_ref) {
+      const int o = kp.h_origin[f];
+      hm = (uint32_t)(kp.h_task[f] & 0xFF) | ((uint32_t)(o >= 0 ? o : 0xFF) << 8);
+    }
+    FO[f * 4 + 3] = __int_as_float((int)hm);
   }
   for (int i = lane; i < 256; i += 64) CH[i] = wt.chain[i >> 4][i & 15];
   for (int i = lane; i < NMAX; i += 64) ANCw[i] = (!MIMIC && i < nj) ? wt.anc_rev[i] : 0u;
@@ -357,7 +364,27 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
 #pragma unroll
     for (int j = 0; j < NP; ++j) Ha[i][j] = wv2{0.f, 0.f};
 
+  // KPLDS (round 6): a row that takes a frame copies the frame's input block -- the 21 raw keypoints (252 B) or its n_ref
+  // ready-made rows -- into the (then idle) term-block area of its slot with ONE coalesced round of loads, next to the loads of
+  // last_qpos and the DexPilot bits; the projection test and the targets then read LDS.  Before, the hand-out was a chain of
+  // dependent global round trips (keypoint map -> keypoints for the projection bits -> map -> keypoints for the targets):
+  // 5-7 k of a pass's ~43 k cycles at 65 536 frames (tools/prof_wide_stages.sh), and the 12-byte reads fetched every line of
+  // the block two or three times.  (Not at n = 32, whose terms re-read their targets in every pass -- TGREG.)
+  constexpr bool KPLDS = NMAX <= 24;
   auto ref_row = [&](ColdParams& kp, int row, float (&rv)[3]) {
+    if (KPLDS) {
+      const float* blk = TBl;
+      if (kp.kpts) {
+        const uint32_t hm = (uint32_t)__float_as_int(FO[row * 4 + 3]);
+        const int ta = (int)(hm & 0xFFu), o = (int)((hm >> 8) & 0xFFu);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rv[i] = blk[ta * 3 + i] - (o != 0xFF ? blk[(o != 0xFF ? o : 0) * 3 + i] : 0.f);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rv[i] = blk[row * 3 + i];
+      }
+      return;
+    }
     const int64_t irow = f_irow();
     if (kp.kpts) {
       // (32-bit element offsets inside the frame's keypoint block: as 64-bit byte offsets of a lane's own rows they are
@@ -409,6 +436,22 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     FS64[1] = lrow;
     FS64[2] = it;
     FS32[0] = t;
+    // every global read of the hand-out is issued here, in one round: the input block, last_qpos, the state word
+    float xl_pre[NJ2];
+#pragma unroll
+    for (int s = 0; s < NJ2; ++s) xl_pre[s] = jopt[s] ? xl(kp, s, lastp, t_seq) : 0.f;
+    const uint32_t st_pre = (dexpilot && !(seq && t_seq > 0) && kp.state) ? kp.state[lrow] : 0u;
+    if (KPLDS) {
+      const float* src = kp.kpts ? kp.kpts + irow * (int64_t)(kp.n_kp * 3) : kp.ref + irow * (int64_t)(kp.n_ref * 3);
+      const int cnt = kp.kpts ? kp.n_kp * 3 : kp.n_ref * 3;
+      float blk[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) blk[i] = (l + 16 * i < cnt) ? src[l + 16 * i] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (l + 16 * i < cnt) TBl[l + 16 * i] = blk[i];
+      for (int i = l + 64; i < cnt; i += 16) TBl[i] = src[i];  // (more than 21 keypoints per frame)
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -416,7 +459,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       xj[s] = 0;
       float xlast = 0;
       if (jopt[s]) {
-        xlast = xl(kp, s, lastp, t_seq);
+        xlast = xl_pre[s];
         const float v = (kp.x0 && !(seq && t_seq > 0)) ? kp.x0[lrow * ld + tb.api[jsel(s)]] : xlast;
         xj[s] = fminf(fmaxf(v, BOXw[2 * jo_[s]]), BOXw[2 * jo_[s] + 1]);
       } else if (jfix[s]) {
@@ -439,7 +482,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       // (S2 = both S1 bits and a short vector).  A loop over the rows in every lane, as the other kernels have it, waits
       // for ten dependent load round trips each time a row takes a new frame: tools/prof_wide_stages.sh showed 5 k of a
       // pass's 39 k cycles going to this hand-out at 65 536 frames.
-      const uint32_t st = (seq && t_seq > 0) ? nst : (kp.state ? kp.state[lrow] : 0u);
+      const uint32_t st = (seq && t_seq > 0) ? nst : st_pre;
       float dist = 0.f;
       if (l < n_pair) {
         float rv[3];
@@ -750,12 +793,16 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
           fvec[i] = (float)(psi * rd[i]);
           hw[i] = (float)psi;
         }
-        kap = quad ? 0.f : (float)(psi * id * id);
+        // (round 6) the Huber curvature psi (I - r r^T / d^2) of the linear regime is psi P with P a PROJECTION (P = P^T P):
+        // J^T (psi P) J = (sqrt(psi) P J)^T (sqrt(psi) P J) -- three weighted rows (c_i - r^_i (r^ . c)) instead of three rows plus
+        // a fourth, subtracted rank-one row: a quarter fewer outer products in the term loop.  rq = r^ there, 0 in the
+        // quadratic regime (P = I).
+        kap = quad ? 0.f : (float)id;
       }
       float* T = TBl + l * 16;
-      // the Hessian is accumulated as sum_k s_k (sqrt(w_k) J_k) (sqrt(w_k) J_k)^T: the square roots of the row weights
-      // travel with the term, the sign of the Huber rank-one row (-kappa) is applied by the outer product
-      *reinterpret_cast<float4*>(T) = make_float4((float)rd[0], (float)rd[1], (float)rd[2], __fsqrt_rn(kap));
+      // the Hessian is accumulated as sum_k (sqrt(w_k) J_k) (sqrt(w_k) J_k)^T: the square roots of the row weights travel with
+      // the term, and so does rq (the unit residual where the Huber loss is linear, else 0): see above
+      *reinterpret_cast<float4*>(T) = make_float4((float)rd[0] * kap, (float)rd[1] * kap, (float)rd[2] * kap, 0.f);  // rq (kap: 1 / d or 0)
       *reinterpret_cast<float4*>(T + 4) = make_float4(fvec[0], fvec[1], fvec[2], __fsqrt_rn(hw[0]));
       *reinterpret_cast<float4*>(T + 8) = make_float4(ptf[0], ptf[1], ptf[2], __fsqrt_rn(hw[1]));
       *reinterpret_cast<float4*>(T + 12) = make_float4(pof[0], pof[1], pof[2], __fsqrt_rn(hw[2]));
@@ -816,7 +863,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     // 24 joints move a DexPilot pair -- with the owner lanes collecting gradient / second-order entries through LDS:
     // 37 % fewer VALU instructions in this loop, the same 1.9 ms for Shadow DexPilot and 10 % slower for the 16-joint
     // hands; the pass is bound by LDS round trips, not by VALU issue.)
-    const int nrow = per_coord ? 3 : 4;  // SmoothL1 per coordinate has no rank-one row
+    constexpr int nrow = 3;  // weighted rows per term (round 6: the Huber rank-one correction is folded into the three rows)
     // columns of term t -> gradient / second-order accumulators and the term's weighted Jacobian rows in buffer `buf`
     auto publish = [&](int t, bool on) {  // on: SPRINT rows beyond the last term of their share contribute zero columns
       float* JRw = JRl;
@@ -885,10 +932,14 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         }
         gnew[0] += c0 * t1.x + c1 * t1.y + c2 * t1.z;
         const int pos = (l & 3) * NRP + (l >> 2);
+        if (!per_coord) {
+          asm volatile("");
+          const float u = c0 * t0.x + c1 * t0.y + c2 * t0.z;
+          c0 -= t0.x * u; c1 -= t0.y * u; c2 -= t0.z * u;
+        }
         JRw[0 * 4 * NRP + pos] = c0 * t1.w;
         JRw[1 * 4 * NRP + pos] = c1 * t2.w;
         JRw[2 * 4 * NRP + pos] = c2 * t3.w;
-        if (!per_coord) JRw[3 * 4 * NRP + pos] = (c0 * t0.x + c1 * t0.y + c2 * t0.z) * t0.w;
       } else if (NJ2 == 2) {
         // both joint slots of the lane (l, l + 16) at once in packed float32 arithmetic (v_pk_*): the two columns are
         // the same formula on different operands, and a pass is bound by the number of VALU instructions issued.
@@ -913,14 +964,20 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
         jcf2[0] += c[1] * t1.z - c[2] * t1.y;
         jcf2[1] += c[2] * t1.x - c[0] * t1.z;
         jcf2[2] += c[0] * t1.y - c[1] * t1.x;
-        const wv2 r0 = c[0] * t1.w, r1 = c[1] * t2.w, r2 = c[2] * t3.w;
-        const wv2 r3 = (c[0] * t0.x + c[1] * t0.y + c[2] * t0.z) * t0.w;
+        wv2 r0 = c[0] * t1.w, r1 = c[1] * t2.w, r2 = c[2] * t3.w;
+        if (!per_coord) {  // (wave-uniform; the empty asm keeps it a scalar BRANCH: if-converted, the position models paid for
+                           // both forms and six selects per term -- LEAP position + 3 % in the same-box A/B)
+          asm volatile("");
+          const wv2 u = c[0] * t0.x + c[1] * t0.y + c[2] * t0.z;
+          r0 = (c[0] - u * t0.x) * t1.w;
+          r1 = (c[1] - u * t0.y) * t2.w;
+          r2 = (c[2] - u * t0.z) * t3.w;
+        }
         // row k of the term's Jacobian^T: position (k mod 4) * NRP + k / 4 of each of the four rows (k = l, l + 16)
         const int pos0 = (l & 3) * NRP + (l >> 2), pos1 = pos0 + 4;
         JRw[0 * 4 * NRP + pos0] = r0.x; JRw[0 * 4 * NRP + pos1] = r0.y;
         JRw[1 * 4 * NRP + pos0] = r1.x; JRw[1 * 4 * NRP + pos1] = r1.y;
         JRw[2 * 4 * NRP + pos0] = r2.x; JRw[2 * 4 * NRP + pos1] = r2.y;
-        if (!per_coord) { JRw[3 * 4 * NRP + pos0] = r3.x; JRw[3 * 4 * NRP + pos1] = r3.y; }
       } else {
 #pragma unroll
         for (int s = 0; s < NJ2; ++s) {
@@ -946,10 +1003,14 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
           }
           // row k of the term's Jacobian^T: position (k mod 4) * NRP + k / 4 of each of the four rows
           const int pos = (k & 3) * NRP + (k >> 2);
+          if (!per_coord) {
+            asm volatile("");
+            const float u = c0 * t0.x + c1 * t0.y + c2 * t0.z;
+            c0 -= t0.x * u; c1 -= t0.y * u; c2 -= t0.z * u;
+          }
           JRw[0 * 4 * NRP + pos] = c0 * t1.w;
           JRw[1 * 4 * NRP + pos] = c1 * t2.w;
           JRw[2 * 4 * NRP + pos] = c2 * t3.w;
-          if (!per_coord) JRw[3 * 4 * NRP + pos] = (c0 * t0.x + c1 * t0.y + c2 * t0.z) * t0.w;
         }
       }
     };
@@ -957,8 +1018,8 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     auto outer = [&]() {
       const float* JRr = JRl;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        if (kk < nrow) {
+      for (int kk = 0; kk < nrow; ++kk) {
+        {
           float jr[NRP];
           wv2 jc[NRP / 2];
 #pragma unroll
@@ -973,8 +1034,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
           }
 #pragma unroll
           for (int i = 0; i < NR; ++i) {
-            const float ri = kk == 3 ? -jr[i] : jr[i];
-            const wv2 rr = wv2{ri, ri};
+            const wv2 rr = wv2{jr[i], jr[i]};
 #pragma unroll
             for (int jj = 0; jj <= i / 2; ++jj) Hx[i][jj] = __builtin_elementwise_fma(rr, jc[jj], Hx[i][jj]);
           }
