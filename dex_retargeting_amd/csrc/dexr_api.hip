@@ -635,7 +635,8 @@ int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStr
   const size_t real_sz = f64 ? 8 : 4;
   // (the tip pass keeps the placements of joints 1..3 in 64 more floats of the wave's LDS, dexr_tip.hpp)
   const bool tip_kernel = m->tip && m->chain && m->bucket == 4 && mode == dexr::MODE_SOLVE;
-  const size_t per_wave = 64 * real_sz * (size_t)(3 * m->lds_frames + 4 * m->lds_terms + (tip_kernel ? 1 : 0));
+  // (... and the float64 tip kernel parks the accepted model -- 10 + 4 + 4 doubles per lane -- in LDS: dexr_kernel.hpp PARK)
+  const size_t per_wave = 64 * real_sz * (size_t)(3 * m->lds_frames + 4 * m->lds_terms + (tip_kernel ? 1 : 0) + ((tip_kernel && f64) ? 18 : 0));
 #ifndef DEXR_WPB
 #define DEXR_WPB 4  // waves per block of the register kernels (the kernels never synchronise across waves)
 #endif

@@ -691,10 +691,17 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
   const bool valid = item_raw < nB;
   const int64_t item = valid ? item_raw : nB - 1;
 
-  const int per_wave = 64 * (3 * kp.lds_frames + 4 * kp.lds_terms + (TIP ? 1 : 0));  // (+ the tip pass's broadcast constants)
+  // PARK (round 6, float64 tip kernel): the accepted point's model -- Hessian (10), gradient (4) -- and the point the pass
+  // stepped from (4) live in per-lane LDS slots ([value][lane], 18 doubles = 9 KB per wave) instead of 36 VGPRs: at 256 VGPRs
+  // the compiler had 37 registers of exactly this cross-pass state in scratch (128 B per lane, WRITE_SIZE 35.8 MB per launch
+  // for 4.2 MB of output, profiles/pmc_allegro_vector_f64.json); each value is read and written once per pass.
+  constexpr bool PARK = TIP && sizeof(real) == 8;
+  constexpr int NPARK = PARK ? (NMAX * (NMAX + 1) / 2 + 2 * NMAX) : 0;
+  const int per_wave = 64 * (3 * kp.lds_frames + 4 * kp.lds_terms + (TIP ? 1 : 0) + NPARK);  // (+ the tip pass's broadcast constants)
   real* P = reinterpret_cast<real*>(lds_raw) + (size_t)wave_in_block * per_wave;
   real* T = P + 64 * 3 * kp.lds_frames;
   real* W = T + 64 * 3 * kp.lds_terms;
+  real* PK = W + 64 * kp.lds_terms + 64 + lane;  // PARK: value i of this lane at PK[64 * i]
 
   // `comps` is a separate __restrict__ kernel argument (not a struct member) so that the compiler may treat the
   // tables as invariant and read them with scalar loads
@@ -919,7 +926,9 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
     const real tip_beta = (real)hot(kp.huber_delta), tip_ibeta = sizeof(real) == 4 ? (real)hot(1.f / kp.huber_delta) : (real)1 / (real)kp.huber_delta;
     const real tip_w = (real)hot(kp.inv_norm), tip_nw = (real)hot(kp.newton != 0 ? 1.f : 0.f);
     const unsigned QCHUNK = kp.qchunk;
-    real Hs[LS::NH], gs[NMAX], xo[NMAX];
+    real Hs[PARK ? 1 : LS::NH], gs[PARK ? 1 : NMAX], xo[PARK ? 1 : NMAX];  // (PARK: in LDS, see PK)
+    auto Hs_get = [&](int i) -> real { if constexpr (PARK) return PK[64 * i]; else return Hs[i]; };
+    auto gs_get = [&](int k) -> real { if constexpr (PARK) return PK[64 * (LS::NH + k)]; else return gs[k]; };
     real F = 0, lam = k_lam0, nu = 2, sprev = (real)1e30;
     int my_iters = 0, blind = 0, nrej = 0;  // nrej: rejected steps of this solve (fast damping recovery only after the first)
     bool has = false, fresh = false;
@@ -1000,9 +1009,10 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
           const bool isopt = (optmask >> k) & 1u;
           // (bitwise, not short-circuit: `&&` / `||` on lane-varying conditions compile to nested exec-mask branches -- 18
           // scalar / branch instructions per joint here -- where four compares and three mask operations do)
-          const bool act = (bool)(((int)(S.x[k] <= (real)tbl.lo[k]) & (int)(gs[k] > 0)) | ((int)(S.x[k] >= (real)tbl.hi[k]) & (int)(gs[k] < 0)));
+          const real gk = gs_get(k);
+          const bool act = (bool)(((int)(S.x[k] <= (real)tbl.lo[k]) & (int)(gk > 0)) | ((int)(S.x[k] >= (real)tbl.hi[k]) & (int)(gk < 0)));
           if (isopt && !act) freemask |= 1u << k;
-          S.g[k] = (isopt && !act) ? gs[k] : (real)0;
+          S.g[k] = (isopt && !act) ? gk : (real)0;
         }
 #pragma unroll
         for (int rr = 0; rr < NMAX; ++rr) {
@@ -1010,9 +1020,9 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
 #pragma unroll
           for (int cc = 0; cc < rr; ++cc) {
             const bool fc = (freemask >> cc) & 1u;
-            S.H[LS::hidx(rr, cc)] = (fr && fc) ? Hs[LS::hidx(rr, cc)] : (real)0;
+            S.H[LS::hidx(rr, cc)] = (fr && fc) ? Hs_get(LS::hidx(rr, cc)) : (real)0;
           }
-          S.H[LS::hidx(rr, rr)] = fr ? Hs[LS::hidx(rr, rr)] + (real)2 * k_delta + lam : (real)1;
+          S.H[LS::hidx(rr, rr)] = fr ? Hs_get(LS::hidx(rr, rr)) + (real)2 * k_delta + lam : (real)1;
         }
         real gm[NMAX];
 #pragma unroll
@@ -1038,7 +1048,7 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
         pred = alpha * ((real)1 - (real)0.5 * alpha) * gd + (real)0.5 * alpha * alpha * lam * dd;
 #pragma unroll
         for (int k = 0; k < NMAX; ++k) {
-          xo[k] = S.x[k];
+          if constexpr (PARK) PK[64 * (LS::NH + NMAX + k)] = S.x[k]; else xo[k] = S.x[k];
           if ((optmask >> k) & 1u) {
             const real xt = RT::clamp(S.x[k] + alpha * d[k], (real)tbl.lo[k], (real)tbl.hi[k]);
             smax = fmax(smax, fabs(xt - S.x[k]));
@@ -1141,7 +1151,7 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
 #pragma unroll
               for (int k = 0; k < NMAX; ++k)
                 if ((optmask >> k) & 1u) {
-                  ds += Hs[LS::hidx(k, k)];
+                  ds += Hs_get(LS::hidx(k, k));
                   ++dn;
                 }
               lam = fmax(lam, k_lam_jump * ds / (real)(dn > 0 ? dn : 1));
@@ -1162,11 +1172,24 @@ __global__ void __launch_bounds__((TIP && sizeof(real) == 4) ? DEXR_TIP_BLOCK_MA
       WTRACE_PASS()
 #pragma unroll
       for (int k = 0; k < NMAX; ++k) {
-        S.x[k] = accept ? S.x[k] : xo[k];
-        gs[k] = accept ? S.g[k] : gs[k];
+        if constexpr (PARK) {
+          // (a lane that stepped reads back the point it stepped from; `fresh` lanes -- accept is true for them -- never wrote one)
+          if (!accept) S.x[k] = PK[64 * (LS::NH + NMAX + k)];
+          if (accept) PK[64 * (LS::NH + k)] = S.g[k];
+        } else {
+          S.x[k] = accept ? S.x[k] : xo[k];
+          gs[k] = accept ? S.g[k] : gs[k];
+        }
       }
+      if constexpr (PARK) {
+        if (accept) {
 #pragma unroll
-      for (int i = 0; i < LS::NH; ++i) Hs[i] = accept ? S.H[i] : Hs[i];
+          for (int i = 0; i < LS::NH; ++i) PK[64 * i] = S.H[i];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < LS::NH; ++i) Hs[i] = accept ? S.H[i] : Hs[i];
+      }
 
       // (5) retire finished frames
       SPROF_STAGE(4)
