@@ -650,7 +650,11 @@ int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStr
   // 47.5 us (16 waves per block: 47.9; 1 wave per block: 52.3).  Smaller launches are faster in blocks of 4 (16 384 frames:
   // 27.2 vs 33.3 us), so the policy is by size.
   if (tip_kernel && !f64 && (kp.B + 63) / 64 * kp.n_comp >= 4096) wpb = DEXR_TIP_WPB_BIG;
-  while (wpb > 1 && per_wave * wpb > 48 * 1024) wpb >>= 1;
+  // (float64 tip kernel: 14.8 KB per wave with the parked model -- blocks of FOUR waves all the same (59 KB, two blocks per CU): the
+  // four finger components of a tile of frames read the same keypoint / last_qpos lines, and in blocks of two they sat on different
+  // CUs and XCDs -- FETCH_SIZE 38.9 MB per launch against 24.9 MB algorithmic, the float32 kernel's blocks of eight fetch 25.1)
+  const size_t block_lds_cap = (tip_kernel && f64) ? 64 * 1024 : 48 * 1024;
+  while (wpb > 1 && per_wave * wpb > block_lds_cap) wpb >>= 1;
   if (per_wave > 64 * 1024) return fail(DEXR_ERR_UNSUPPORTED, "component needs %zu B of LDS per wave", per_wave);
   const int64_t tiles = (kp.B + 63) / 64;
   int64_t waves = tiles * kp.n_comp;
