@@ -1241,6 +1241,50 @@ def run_single(args):
                           "p999_abs_dq_vs_default_rad": float(np.percentile(np.abs(w2.t_q.cpu().numpy().astype(np.float64) - q2).max(1), 99.9))}
             except Exception as e:
                 f64rec = {"error": repr(e)}
+            # ... and on the GENERAL kernel (csrc/dexr_gen.hpp: one wavefront per frame, float64 kinematics, Hessian, factorisation) through
+            # the generic table format of the SAME config (Optimizer.use_generic_tables): the float64 implementation that does not
+            # spill -- this is the like-for-like figure of the record; the register kernel's stays beside it
+            try:
+                from dex_retargeting_amd.retargeting_config import RetargetingConfig as _RC
+                import bench_data as _bd
+
+                sg = _RC.load_from_file(os.path.join(_bd.CONFIG_DIR, w2.rel)).build()
+                sg.optimizer.use_generic_tables = True
+                mg = sg.optimizer.device_model()
+                assert mg.kernel()[0] == _lib.KERNEL_GENERAL
+                t_qg, t_itg = torch.empty_like(w2.t_q), torch.zeros(B, dtype=torch.int32, device=dev)
+
+                def go_g(b, diag=False):
+                    if w2.dexpilot:
+                        w2.t_state.copy_(b["t_state0"])
+                    mg.retarget_dev(B, b["t_in"].data_ptr(), 0, b["t_last"].data_ptr(), w2.t_state.data_ptr() if w2.dexpilot else 0,
+                                    t_qg.data_ptr(), iters_ptr=t_itg.data_ptr() if diag else 0, stream=w2.stream.cuda_stream, keypoints=True)
+
+                go_g(w2.tracking[0])
+                torch.cuda.synchronize()
+                sgn = max(2, min(args.steps, 5))
+                eg0, eg1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                tg0 = time.perf_counter()
+                eg0.record(w2.stream)
+                for k_ in range(sgn):
+                    go_g(w2.tracking[k_ % N_BATCHES])
+                eg1.record(w2.stream)
+                torch.cuda.synchronize()
+                elg = time.perf_counter() - tg0
+                go_g(b2, diag=True)
+                torch.cuda.synchronize()
+                qg = t_qg.cpu().numpy().astype(np.float64)
+                itg = t_itg.cpu().numpy()
+                dqg = np.abs(qg - q2).max(1)
+                f64rec = {"dtype": "f64", "value": B * sgn / elg, "unit": "frames/s", "ms_per_step": elg / sgn * 1e3, "steps": sgn,
+                          "kernel_ms": float(eg0.elapsed_time(eg1)) / sgn,
+                          "kernel": "dexr_gen_kernel (one wavefront per frame; float64 kinematics, Hessian and factorisation) on the generic "
+                                    "tables of the same config",
+                          "solver": {"iters_mean": float(itg.mean()), "iters_max": int(itg.max())},
+                          "frac_within_1e-4_of_default": float((dqg < 1e-4).mean()), "p99_abs_dq_vs_default_rad": float(np.percentile(dqg, 99)),
+                          "register_kernel": f64rec}
+            except Exception as e:
+                f64rec = dict(f64rec, general_kernel_error=repr(e))
             also[name] = (w2, b2, q2,
                           {"config_file": w2.rel, "workload": w2.title, "dtype": WIDE_DTYPE if w2.model.kernel()[0] == _lib.KERNEL_WIDE else "f32",
                            "value": B * args.steps / e2,

@@ -173,11 +173,19 @@ def fleet_measure(args, batch=None, standalone=True):
 
             o64 = _lib.default_options(precision=1)
             b0 = last_b
-            per = []
+            per, kernels_used = [], []
             for m, sq in enumerate(seqs):
                 idx = torch.nonzero(b0["t_mid"] == m).flatten()
                 n_m, n_opt = int(idx.numel()), sq.optimizer.opt_dof
-                per.append(dict(model=fleet.models[m], n=n_m, kp=b0["t_kp"][idx].contiguous(), last=b0["t_last"][idx][:, :n_opt].contiguous(),
+                mdl, which = fleet.models[m], "dexr_kernel<.., double> (register / tip kernel)"
+                if mdl.kernel()[0] == _lib.KERNEL_WIDE:
+                    # (the sixteen-lane family's all-float64 counterpart is the general kernel on the generic tables of the same
+                    # config -- the register kernel dexr_kernel<24, double> spills 16 000 registers: 57 ms for these 32 768 rows)
+                    sg = RetargetingConfig.load_from_file(os.path.join(bench_data.CONFIG_DIR, FLEET[m])).build()
+                    sg.optimizer.use_generic_tables = True
+                    mdl, which = sg.optimizer.device_model(), "dexr_gen_kernel (generic tables, float64 throughout)"
+                kernels_used.append(f"{FLEET[m]}: {which}")
+                per.append(dict(model=mdl, n=n_m, kp=b0["t_kp"][idx].contiguous(), last=b0["t_last"][idx][:, :n_opt].contiguous(),
                                 st0=b0["t_state0"][idx].contiguous(), st=torch.zeros(n_m, dtype=torch.int32, device=dev),
                                 out=torch.empty((n_m, n_opt), dtype=torch.float32, device=dev), idx=idx, n_opt=n_opt,
                                 dex=sq.optimizer.retargeting_type == "DEXPILOT"))
@@ -207,6 +215,7 @@ def fleet_measure(args, batch=None, standalone=True):
             out_json["f64"] = {"dtype": "f64", "value": B * s64 / el, "unit": "frames/s", "ms_per_step": el / s64 * 1e3, "steps": s64,
                                "event_ms_per_step": float(e0.elapsed_time(e1)) / s64,
                                "max_abs_dq_vs_default_rad": float(dq.max()), "p999_abs_dq_vs_default_rad": float(np.percentile(dq, 99.9)),
+                               "kernels": kernels_used,
                                "note": "one float64 launch per model (dexr_retarget_kp_dev, precision = 1) over its rows of the same batch, "
                                        "bucketed by model beforehand (untimed): the fleet entry point itself runs the float32 / "
                                        "mixed-precision kernels only"}

@@ -70,14 +70,24 @@ class DeviceSeqRetargeting:
         self.filtered = torch.zeros_like(self.robot_qpos)
         self._kp_mano = None
         self._no_fixed = torch.zeros((B, max(self.n_fixed, 1)), dtype=torch.float32, device=dev)
+        self._filter_init = False
         self.reset()
 
     def reset(self):
+        """seq_retarget.py:155-158 of the reference, per sequence: last_qpos back to the limit midpoint, counters to zero; the
+        low-pass filter and the DexPilot projection bits keep their state, as the reference's reset() leaves `self.filter` and
+        `optimizer.projected` alone (reset_filter() / reset_state() clear them; same meaning in all three batch wrappers)."""
         mid = self.torch.tensor(self.joint_limits.mean(1).astype(np.float32), device=self.device)
         self.last_qpos.copy_(mid[None].expand(self.batch, -1))
-        self.state.zero_()
-        self._filter_init = False
         self.num_retargeting = 0
+
+    def reset_filter(self):
+        """[not-in-ref] forget the low-pass filter state: the next frame initialises it (LPFilter.reset)."""
+        self._filter_init = False
+
+    def reset_state(self):
+        """[not-in-ref] clear the DexPilot projection bits of every sequence."""
+        self.state.zero_()
 
     def set_qpos(self, target_qpos):
         """(B, n_opt) start point for the next frame (== SeqRetargeting.set_qpos per sequence)."""

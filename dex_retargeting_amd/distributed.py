@@ -76,13 +76,41 @@ def unshard_by_model(full: np.ndarray, shards, B: int) -> np.ndarray:
     return out
 
 
+def mixed_fleet_solve(fleet) -> Callable:
+    """The per-shard `solve` of :class:`ShardedFleet` on the GPU (``MixedFleet.retarget`` itself takes and returns
+    device tensors with int32 state words, ShardedFleet hands numpy arrays with uint32 ones): host arrays -> the fleet's device
+    -> ``dexr_retarget_multi_dev`` -> host arrays, `state` updated in place.  Tested on the GPU against the unsharded fleet
+    call (tests/test_gpu_parity.py::test_sharded_fleet_with_the_mixed_fleet_adapter)."""
+
+    def solve(model_id, keypoints, last, state):
+        torch = fleet.torch
+        dev = fleet.device
+        b = int(model_id.shape[0])
+        if b == 0:
+            return np.zeros((0, fleet.n_max), np.float32)
+        t_state = None
+        if state is not None:
+            t_state = torch.from_numpy(np.ascontiguousarray(state).view(np.int32).copy()).to(dev)
+        elif any(o.retargeting_type == "DEXPILOT" for o in fleet.optimizers):
+            t_state = torch.zeros(b, dtype=torch.int32, device=dev)
+        out = fleet.retarget(torch.from_numpy(np.ascontiguousarray(model_id, dtype=np.int32)).to(dev),
+                             torch.from_numpy(np.ascontiguousarray(keypoints, dtype=np.float32)).to(dev),
+                             torch.from_numpy(np.ascontiguousarray(last, dtype=np.float32)).to(dev), t_state)
+        if state is not None:
+            state[:] = t_state.cpu().numpy().view(np.uint32)
+        return out.cpu().numpy()
+
+    return solve
+
+
 class ShardedFleet:
     """Mixed-fleet batch over N ranks: rank r solves ``shard_by_model(model_id, N)[r]`` (an equal share of every robot's
     frames) and ONE all-gather reassembles the (B, n_max) rows and the DexPilot state words on every rank.
 
-    `solve(model_id, keypoints, last, state) -> (b, n_max) float32` is the per-shard fleet call (``MixedFleet.retarget``
-    on the GPU; the world-size-2 gloo tests inject a CPU interpreter of the same tables); `state` (uint32) is updated in
-    place.  `work(model_id) -> float` (optional) is recorded per call in ``last_work`` so a test / a bench can show the
+    `solve(model_id, keypoints, last, state) -> (b, n_max) float32` is the per-shard fleet call on HOST arrays
+    (``mixed_fleet_solve(MixedFleet(...))`` on the GPU; the world-size-2 gloo tests inject a CPU interpreter of the same
+    tables); `state` (uint32) is updated in place.  (Host arrays in and out: this wrapper is the convenience path; the
+    device-resident N > 1 path of the bench is bench_fleet.py -- shard_by_model on ids, MixedFleet on tensors, dexr_allgather.)  `work(model_id) -> float` (optional) is recorded per call in ``last_work`` so a test / a bench can show the
     solve work each rank received."""
 
     def __init__(self, solve: Callable, n_max: int, device: str = "cpu", group=None, n_models: Optional[int] = None):

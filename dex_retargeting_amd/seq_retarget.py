@@ -160,15 +160,28 @@ class BatchedSeqRetargeting:
             optimizer.set_joint_limit(joint_limits[optimizer.idx_pin2target])
         self.joint_limits = joint_limits[optimizer.idx_pin2target]
         self.alpha = low_pass_alpha
-        self.reset()
-
-    def reset(self):
-        mid = self.joint_limits.mean(1).astype(np.float32)
-        self.last_qpos = np.repeat(mid[None], self.batch, 0)
         self.filtered: Optional[np.ndarray] = None
         st = self.optimizer._state_in(self.batch)
         self.state = None if st is None else np.zeros(self.batch, dtype=np.uint32)
+        self.reset()
+
+    def reset(self):
+        """seq_retarget.py:155-158 of the reference, per sequence: last_qpos back to the limit midpoint, counters to zero.  The
+        low-pass filter and the DexPilot projection bits keep their state -- the reference's reset() touches neither
+        `self.filter` nor `optimizer.projected`; reset_filter() / reset_state() clear them (the three batch wrappers -- this one,
+        DeviceSeqRetargeting, MultiRobotSeqRetargeting -- mean the same thing by reset())."""
+        mid = self.joint_limits.mean(1).astype(np.float32)
+        self.last_qpos = np.repeat(mid[None], self.batch, 0)
         self.num_retargeting = 0
+
+    def reset_filter(self):
+        """[not-in-ref] forget the low-pass filter state: the next frame initialises it (LPFilter.reset)."""
+        self.filtered = None
+
+    def reset_state(self):
+        """[not-in-ref] clear the DexPilot projection bits of every sequence."""
+        if self.state is not None:
+            self.state[:] = 0
 
     def warm_start(self, wrist_pos: np.ndarray, wrist_quat: np.ndarray, hand_type: HandType = HandType.right,
                    is_mano_convention: bool = False):

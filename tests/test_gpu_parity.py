@@ -1080,6 +1080,59 @@ def test_longest_first_ordering_changes_the_schedule_not_the_answers():
             assert np.array_equal(q, out[0][0][0]) and np.array_equal(st, out[0][0][1]) and np.array_equal(it, out[0][0][2])
 
 
+def test_sharded_fleet_with_the_mixed_fleet_adapter():
+    """distributed.ShardedFleet's per-shard `solve` on the GPU is `mixed_fleet_solve(MixedFleet(...))` (host arrays,
+    uint32 state words <-> device tensors, int32).  One rank (gloo, world size 1: all a 1-GPU box holds) -- shard, solve, all-gather,
+    unshard -- must return exactly the unsharded fleet call's rows and state words; the adapter alone on a subset of the batch
+    (what rank r of N would be handed) returns that subset's rows of the full call."""
+    torch = pytest.importorskip("torch")
+    import socket
+
+    import torch.distributed as dist
+
+    from dex_retargeting_amd.distributed import ShardedFleet, mixed_fleet_solve, shard_by_model
+    from dex_retargeting_amd.fleet import MixedFleet
+
+    rels = ["teleop/allegro_hand_right.yml", "teleop/shadow_hand_right_dexpilot.yml", "teleop/ability_hand_right.yml"]
+    builds = [build(r) for r in rels]
+    fleet = MixedFleet([b[0].optimizer for b in builds])
+    shadow = builds[1][0].optimizer.device_model()
+    shadow.tune(sprint_max_batch=0)
+    B = 3001
+    rng = np.random.default_rng(5)
+    mid = np.sort(rng.integers(0, len(rels), B)).astype(np.int32)  # a robot-sorted batch
+    kp = cases.human_keypoints(B, seed=21)
+    last = np.zeros((B, fleet.n_max), np.float32)
+    for m, (seq, prob) in enumerate(builds):
+        last[mid == m, : prob.n_opt] = prob.joint_limits.mean(1).astype(np.float32)
+    st_ref = torch.zeros(B, dtype=torch.int32, device="cuda")
+    want = fleet.retarget(torch.from_numpy(mid).cuda(), torch.from_numpy(kp).cuda(), torch.from_numpy(last).cuda(), st_ref).cpu().numpy()
+    want_st = st_ref.cpu().numpy().view(np.uint32)
+    solve = mixed_fleet_solve(fleet)
+    # the adapter on what rank 1 of 2 would be handed: the same rows of the full call, bitwise (the launch shape of the
+    # sixteen-lane model's bucket follows the size of the call -- dexr_tuning.sprint_max_batch, a contract stated by
+    # test_a_frame_answers_the_same_on_either_side_of_the_small_batch_threshold -- so it is pinned to four frames per wave here)
+    idx = shard_by_model(mid, 2, len(rels))[1]
+    st1 = np.zeros(idx.size, np.uint32)
+    q1 = solve(mid[idx], kp[idx], last[idx], st1)
+    assert q1.shape == (idx.size, fleet.n_max) and q1.dtype == np.float32
+    assert np.array_equal(q1, want[idx]) and np.array_equal(st1, want_st[idx])
+    # the whole wrapper, one rank
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        sf = ShardedFleet(solve, fleet.n_max, device="cpu", n_models=len(rels))
+        st = np.zeros(B, np.uint32)
+        q = sf.retarget(mid, kp, last, st)
+    finally:
+        dist.destroy_process_group()
+        shadow.tune(sprint_max_batch=-1)
+    assert np.array_equal(q, want) and np.array_equal(st, want_st)
+
+
 @pytest.mark.parametrize("rel", ["teleop/shadow_hand_right_dexpilot.yml", "offline/leap_hand_right.yml", "teleop/shadow_hand_right.yml",
                                  "teleop/allegro_hand_right_dexpilot.yml", "offline/shadow_hand_right.yml", "offline/panda_gripper.yml",
                                  "teleop/inspire_hand_right_dexpilot.yml", "offline/schunk_svh_hand_right.yml",
