@@ -290,6 +290,8 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     FO[f * 4 + 3] = __int_as_float((int)hm);
   }
   for (int i = lane; i < 256; i += 64) CH[i] = wt.chain[i >> 4][i & 15];
+  // (sincos_f64_tab's 512-byte table is read from global memory through the vector L1: a copy in the wave's LDS measured the
+  // same, profiles/r06_wide_ab_sincos_table_same_box.txt)
   for (int i = lane; i < NMAX; i += 64) ANCw[i] = (!MIMIC && i < nj) ? wt.anc_rev[i] : 0u;
 
   uint32_t revmask = 0;
@@ -598,7 +600,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
           q = (double)xj[s < NJ2 ? s : 0];
         }
         double sn = q, cs = 0.0;
-        if ((revmask >> k) & 1u) sincos_f64(q, &sn, &cs);
+        if ((revmask >> k) & 1u) sincos_f64_tab(q, &sn, &cs);  // (table + short polynomials: dexr_math.hpp)
         SCl[2 * k] = sn;
         SCl[2 * k + 1] = cs;
       }
