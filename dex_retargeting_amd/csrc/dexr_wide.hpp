@@ -123,7 +123,10 @@ struct WideLds {
   static constexpr int NR = NMAX / 4;
   static constexpr int NRP = NR <= 4 ? 4 : 8;          // class chunk of a Jacobian row, padded for 16-byte reads
   static constexpr int XT = 0;                         // NJ x 16 floats: X[12], fbeg | fend << 8, var + 1, vmul, off
-  static constexpr int FO = XT + NJ * 64;              // 16 frames x 4 floats
+  // (row stride of XT in words: 20, not 16 -- rows 256 B apart share their banks, and the kinematic chains' lanes read the rows of
+  // four to five different joints with one ds_read_b128; the 16-row grids' LDS budget is exact, they keep 16)
+  static constexpr int XTS = (!MIMIC && NMAX > 16) ? 20 : 16;
+  static constexpr int FO = XT + NJ * XTS * 4;         // 16 frames x 4 floats
   static constexpr int CH = FO + 256;                  // 16 x 16 chain bytes
   static constexpr int ANC = CH + 256;                 // NMAX words: revolute ancestors-or-self of each joint
   static constexpr int BOX = ANC + NMAX * 4;           // NMAX x (lo, hi): box of each grid variable
@@ -210,7 +213,8 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   // per-term ancestor masks (mt, mo): read with the term's block at the top of every iteration of the term loop instead of
   // two DEPENDENT scalar loads from the tables (term_task -> frame_anc: ~2 scalar-memory round trips per term and pass)
   uint32_t* TMw = MIMIC ? reinterpret_cast<uint32_t*>(wbase + L::TM) : reinterpret_cast<uint32_t*>(wbase + L::XT) + 13;
-  constexpr int TMS = MIMIC ? 2 : 16;  // words between consecutive terms' mask pairs
+  constexpr int XTS = L::XTS;
+  constexpr int TMS = MIMIC ? 2 : XTS;  // words between consecutive terms' mask pairs
   unsigned char* sbase = wbase + L::SLOT0 + (size_t)slot * L::SLOT;
   double* Pl = reinterpret_cast<double*>(sbase + L::P);
   float* AXl = reinterpret_cast<float*>(sbase + L::AX);
@@ -256,14 +260,14 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
   for (int k = lane; k < NJ; k += 64) {
     const bool in = k < nj;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) XT[k * 16 + i] = in ? tb.X[k][i] : 0.f;
-    XT[k * 16 + 12] = __int_as_float(in ? (tb.fbeg[k] | (tb.fend[k] << 8)) : 0);
+    for (int i = 0; i < 12; ++i) XT[k * XTS + i] = in ? tb.X[k][i] : 0.f;
+    XT[k * XTS + 12] = __int_as_float(in ? (tb.fbeg[k] | (tb.fend[k] << 8)) : 0);
     if (MIMIC) {
-      XT[k * 16 + 13] = __int_as_float(in ? tb.var[k] + 1 : 0);  // 0: not driven by a variable (fixed joint)
-      XT[k * 16 + 14] = in ? tb.vmul[k] : 0.f;
-      XT[k * 16 + 15] = in ? tb.off[k] : 0.f;
+      XT[k * XTS + 13] = __int_as_float(in ? tb.var[k] + 1 : 0);  // 0: not driven by a variable (fixed joint)
+      XT[k * XTS + 14] = in ? tb.vmul[k] : 0.f;
+      XT[k * XTS + 15] = in ? tb.off[k] : 0.f;
     } else {
-      XT[k * 16 + 15] = 0.f;
+      XT[k * XTS + 15] = 0.f;
     }
   }
   for (int t = lane; t < 16; t += 64) {
@@ -593,7 +597,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       if (k < nj) {
         double q;
         if (MIMIC) {  // q = vmul * x[var] + off in float64 (a float32 product makes F a step function of x)
-          const float4 x3 = *reinterpret_cast<const float4*>(XT + k * 16 + 12);
+          const float4 x3 = *reinterpret_cast<const float4*>(XT + k * XTS + 12);
           const int vc = __float_as_int(x3.y);
           q = vc > 0 ? fma((double)x3.z, (double)XVl[vc > 0 ? vc - 1 : 0], (double)x3.w) : (double)QJl[k];
         } else {
@@ -615,19 +619,19 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       double r0 = ri == 0 ? 1.0 : 0.0, r1 = ri == 1 ? 1.0 : 0.0, r2 = ri == 2 ? 1.0 : 0.0, pi = 0.0;
       unsigned cb = depth > 0 ? CH[ch * 16] : 0xFFu;
       int kf = cb != 0xFFu ? (int)(cb & 0x7Fu) : 0;
-      float4 x0 = *reinterpret_cast<const float4*>(XT + kf * 16);
-      float4 x1 = *reinterpret_cast<const float4*>(XT + kf * 16 + 4);
-      float4 x2 = *reinterpret_cast<const float4*>(XT + kf * 16 + 8);
-      float4 x3 = *reinterpret_cast<const float4*>(XT + kf * 16 + 12);
+      float4 x0 = *reinterpret_cast<const float4*>(XT + kf * XTS);
+      float4 x1 = *reinterpret_cast<const float4*>(XT + kf * XTS + 4);
+      float4 x2 = *reinterpret_cast<const float4*>(XT + kf * XTS + 8);
+      float4 x3 = *reinterpret_cast<const float4*>(XT + kf * XTS + 12);
       double scs = SCl[2 * kf], scc = SCl[2 * kf + 1];
 #pragma clang loop unroll(disable) vectorize(disable)
       for (int s = 0; s < depth; ++s) {
         const unsigned cbn = (s + 1 < depth) ? CH[ch * 16 + s + 1] : 0xFFu;
         const int kn = cbn != 0xFFu ? (int)(cbn & 0x7Fu) : 0;
-        const float4 y0 = *reinterpret_cast<const float4*>(XT + kn * 16);
-        const float4 y1 = *reinterpret_cast<const float4*>(XT + kn * 16 + 4);
-        const float4 y2 = *reinterpret_cast<const float4*>(XT + kn * 16 + 8);
-        const float4 y3 = *reinterpret_cast<const float4*>(XT + kn * 16 + 12);
+        const float4 y0 = *reinterpret_cast<const float4*>(XT + kn * XTS);
+        const float4 y1 = *reinterpret_cast<const float4*>(XT + kn * XTS + 4);
+        const float4 y2 = *reinterpret_cast<const float4*>(XT + kn * XTS + 8);
+        const float4 y3 = *reinterpret_cast<const float4*>(XT + kn * XTS + 12);
         const double scsn = SCl[2 * kn], sccn = SCl[2 * kn + 1];
         if (cb != 0xFFu) {
           const int k = (int)(cb & 0x7Fu);
@@ -670,10 +674,10 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
     constexpr bool PREFETCH = MIMIC || NMAX > 16;
     unsigned cb = depth > 0 ? CH[l * 16] : 0xFFu;
     int kf = cb != 0xFFu ? (int)(cb & 0x7Fu) : 0;
-    float4 x0 = *reinterpret_cast<const float4*>(XT + kf * 16);
-    float4 x1 = *reinterpret_cast<const float4*>(XT + kf * 16 + 4);
-    float4 x2 = *reinterpret_cast<const float4*>(XT + kf * 16 + 8);
-    float4 x3 = *reinterpret_cast<const float4*>(XT + kf * 16 + 12);
+    float4 x0 = *reinterpret_cast<const float4*>(XT + kf * XTS);
+    float4 x1 = *reinterpret_cast<const float4*>(XT + kf * XTS + 4);
+    float4 x2 = *reinterpret_cast<const float4*>(XT + kf * XTS + 8);
+    float4 x3 = *reinterpret_cast<const float4*>(XT + kf * XTS + 12);
     double scs = SCl[2 * kf], scc = SCl[2 * kf + 1];
 #pragma clang loop unroll(disable) vectorize(disable)
     for (int s = 0; s < depth; ++s) {
@@ -683,10 +687,10 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
       auto fetch_next = [&]() {
         cbn = (s + 1 < depth) ? CH[l * 16 + s + 1] : 0xFFu;
         const int kn = cbn != 0xFFu ? (int)(cbn & 0x7Fu) : 0;
-        y0 = *reinterpret_cast<const float4*>(XT + kn * 16);
-        y1 = *reinterpret_cast<const float4*>(XT + kn * 16 + 4);
-        y2 = *reinterpret_cast<const float4*>(XT + kn * 16 + 8);
-        y3 = *reinterpret_cast<const float4*>(XT + kn * 16 + 12);
+        y0 = *reinterpret_cast<const float4*>(XT + kn * XTS);
+        y1 = *reinterpret_cast<const float4*>(XT + kn * XTS + 4);
+        y2 = *reinterpret_cast<const float4*>(XT + kn * XTS + 8);
+        y3 = *reinterpret_cast<const float4*>(XT + kn * XTS + 12);
         scsn = SCl[2 * kn];
         sccn = SCl[2 * kn + 1];
       };
@@ -1132,7 +1136,7 @@ __global__ void __launch_bounds__(256, DEXR_WIDE_MINW) dexr_wide_kernel(const Ke
           const int k = (int)(w & 31u), j = (int)((w >> 5) & 31u), e = (int)((w >> 10) & 15u);
           const float4 aj = *reinterpret_cast<const float4*>(AXl + j * 4);
           const float4 cf = *reinterpret_cast<const float4*>(CFl + k * 4);
-          float val = XT[k * 16 + 14] * XT[j * 16 + 14] * (aj.x * cf.x + aj.y * cf.y + aj.z * cf.z);
+          float val = XT[k * XTS + 14] * XT[j * XTS + 14] * (aj.x * cf.x + aj.y * cf.y + aj.z * cf.z);
           if ((w >> 14) & 1u) val += val;
           HBl[e] += val;
         }
