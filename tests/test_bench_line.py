@@ -20,13 +20,13 @@ import bench_line  # noqa: E402
 
 RECORDED = ["r04_bench_default.json", "r04_bench_mixed_fleet.json", "r04_bench_1rank_native_rccl_allegro_vector.json",
             "r04_bench_1rank_native_rccl_leap_position.json", "r04_bench_1rank_native_rccl_mixed_fleet.json"]
-RECORDED += [n for n in sorted(os.listdir(PROF)) if n.startswith("r05_bench_detail")]
+RECORDED += [n for n in sorted(os.listdir(PROF)) if n.startswith("r05_bench_detail") or n.startswith("r06_bench_detail")]
 
 
 def _detail(name):
     with open(os.path.join(PROF, name)) as f:
         txt = f.read().strip()
-    if txt.startswith("{\n") or name.startswith("r05_bench_detail"):
+    if txt.startswith("{\n") or name.startswith("r05_bench_detail") or name.startswith("r06_bench_detail"):
         return json.loads(txt)
     return json.loads([ln for ln in txt.splitlines() if ln.startswith("{")][-1])
 

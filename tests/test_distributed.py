@@ -323,33 +323,49 @@ def test_committed_bench_lines_follow_the_driver_contract():
     REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prof = os.path.join(REPO, "profiles")
     lines = {}
-    for name in ("r03_bench_default.json", "r03_bench_mixed_fleet.json", "r03_bench_1rank_native_rccl.json"):
+    # (this used to validate the round-3 lines; now the lines of the last two rounds, as the driver's boxes printed them)
+    names = ("r05_bench_default.json", "r05_bench_mixed_fleet.json", "r06_bench_default.json", "r06_bench_mixed_fleet.json",
+             "r06_bench_1rank_native_rccl_allegro_vector.json", "r06_bench_1rank_native_rccl_leap_position.json",
+             "r06_bench_1rank_native_rccl_mixed_fleet.json")
+    for name in names:
         with open(os.path.join(prof, name)) as f:
             lines[name] = json.loads([ln for ln in f if ln.startswith("{")][-1])
+        assert len(json.dumps(lines[name], separators=(",", ":"))) <= 4096, name  # the compact line the driver parses
     base = json.load(open(os.path.join(REPO, "BASELINE.json")))
     for name, d in lines.items():
         for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                   "vs_baseline", "dtype", "data", "config"):
             assert k in d, (name, k)
         assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
-        assert d["dtype"] == "f32" and "synthetic" in d["data"] and "workload" in d["config"]
+        assert "synthetic" in d["data"] and "workload" in d["config"]
+        fleet = "mixed_fleet" in name
+        # (the arithmetic type the path computes in: the tip kernel is float32 throughout; a fleet mixes kernels, said per model)
+        assert d["dtype"] == "f32" or (fleet and "f32" in d["dtype"]), (name, d["dtype"])
         assert d["unit"] == "frames/s"
-        if name != "r03_bench_mixed_fleet.json":
+        if not fleet and "leap_position" not in name:
             assert d["metric"] == base["metric"], (d["metric"], base["metric"])
         r = d["roofline"]
         for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
             assert k in r, (name, k)
-        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 * r["frac"] + 1e-9  # (compact lines: 6 significant digits each)
         assert 0 < r["frac"] < 1 and r["peak"] == 8000.0
         # throughput and step time describe the same run
         frames = d["config"].get("batch_per_gpu", d["config"].get("frames_per_gpu", None))
         if frames:
             assert abs(d["value"] - d["n_gpus"] * frames / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.02
-    c = lines["r03_bench_default.json"]["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
-        assert k in c
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
-    assert lines["r03_bench_1rank_native_rccl.json"]["config"].get("rccl_world_size") == 1
+    for name in ("r05_bench_default.json", "r06_bench_default.json"):
+        c = lines[name]["cpu_baseline"]
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in c
+        assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    assert lines["r06_bench_1rank_native_rccl_allegro_vector.json"]["config"].get("rccl_world_size") == 1
+    # round 6: the blocks VERDICT r5 asked for travel in the compact line
+    d6 = lines["r06_bench_default.json"]
+    for k in ("sustained", "reference_profile_script", "online_ms_per_retarget", "small_batch", "also", "f64"):
+        assert k in d6, k
+    assert d6["reference_profile_script"]["rows"] == 14 and d6["sustained"]["steps"] >= 40000
+    assert all("parity" in v for v in d6["online_ms_per_retarget"].values())
+    assert all("f64" in v and "f32" in v["dtype"] for v in d6["also"].values())
 
 
 # ---- skew-proof fleet sharding ----------------------------------------------------
