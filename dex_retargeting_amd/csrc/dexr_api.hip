@@ -618,13 +618,26 @@ int launch_gen_model(const dexr_model* m, int mode, dexr::KernelParams kp, hipSt
   return DEXR_OK;
 }
 
+#ifndef DEXR_RED_SMALL_BATCH
+#define DEXR_RED_SMALL_BATCH 16384
+#endif
 int launch(const dexr_model* m, int mode, int f64, dexr::KernelParams kp, hipStream_t st) {
   if (kp.B <= 0) return DEXR_OK;
   if (m->gen) return launch_gen_model(m, mode, kp, st);
   // fleet buckets / frame sequences / padded rows need the kernels with extended addressing (KernelParams)
   const bool ext = kp.perm != nullptr || kp.bucket != nullptr || kp.T > 0 || kp.ld != kp.n_opt;
   if (mode == dexr::MODE_SOLVE && !f64 && selected_family(m) != FAM_REGISTER) {
-    const Family fam = selected_family(m);
+    Family fam = selected_family(m);
+    // THE REDUCED-VARIABLE KERNEL IS A THROUGHPUT KERNEL (round 6).  It holds a frame per LANE and walks rolled joint loops: a pass
+    // of a lone wave takes ~25 us, whatever the batch.  The mimic vector models it serves by policy (Schunk SVH) also fit the
+    // sixteen-lane kernel's variable grid, which is 2 x faster up to 16 384 frames and 1.5 x slower at 65 536 (one MI355X, tracking
+    // frames: B = 1: 108 -> 51 us, 2 048: 309 -> 194, 16 384: 560 -> 327, 65 536: 708 vs 1 067; profiles/r06_svh_vector_reduced_vs_wide.txt)
+    // -- and the reference's own benchmark (profile_online_retargeting.py, one frame per call) had this row at 3 266 fps on the GPU
+    // against 5 968 for the CPU port.  So batches of up to DEXR_RED_SMALL_BATCH frames of such a model take the sixteen-lane
+    // kernel (automatic policy only: dexr_tuning.kernel = DEXR_KERNEL_REDUCED keeps the reduced kernel at every size).
+    // Like sprint_max_batch this makes the ITERATION a function of the batch size: same minimiser, same tolerance, and the
+    // 16 384 / 16 385 straddle test (tests/test_gpu_all_configs.py) pins how often a multi-modal frame settles elsewhere.
+    if (fam == FAM_RED && m->wide_ok && m->tune.kernel == DEXR_KERNEL_AUTO && kp.B <= DEXR_RED_SMALL_BATCH && !kp.screen) fam = FAM_WIDE;
     kp.lam_jump = family_lam_jump(m, fam);
     kp.lam_fastdec = family_lam_fastdec(m, fam);
     return fam == FAM_RED ? launch_red(m, kp, st) : fam == FAM_WIDE ? launch_wide(m, kp, st)
