@@ -71,7 +71,10 @@ typedef struct dexr_solve_options {
                                   wavefront per frame, every table in memory, float64 (dexr_gen.hpp); not selectable      */
 typedef struct dexr_tuning {
   uint32_t struct_size; /* sizeof(dexr_tuning) of the caller's header: lets the struct grow compatibly          */
-  int32_t kernel;       /* DEXR_KERNEL_*: float32 solve kernel family (AUTO: measured policy, dexr_api.hip)      */
+  int32_t kernel;       /* DEXR_KERNEL_*: float32 solve kernel family (AUTO: measured policy, dexr_api.hip).  Under AUTO
+                           the family may follow the SIZE of the call: models the policy gives to the reduced-variable kernel
+                           (mimic vector models) take the sixteen-lane kernel for batches of <= 16 384 frames (2 x faster there;
+                           dexr_model_kernel reports the large-batch family).  An explicit family holds at every size.         */
   int32_t chain;        /* 1: serial-chain specialisation (+ its tip pass) where the tables allow it (default), 2: serial-chain
                            specialisation without the tip pass, 0: never                                           */
   int32_t persist_occ;  /* small components: resident waves per SIMD in queue mode (0: derived from the kernel)  */
@@ -127,7 +130,9 @@ typedef struct dexr_tuning {
                            frames that start at an indefinite model (the clean one-frame-per-call regime: Shadow vector 8.5 -> 5.7
                            passes in the host emulation), but ANOTHER iteration than the four-frames-per-wave launch's: answers agree
                            to 1e-4 rad except where a multi-modal frame settles in a different certified minimum.  1 on, 0 off
-                           (the rows are copies of one iteration), -1 measured policy                                   */
+                           (the rows are copies of one iteration), -1 measured policy.  Round 6: with the ladder on EVERY
+                           step is verified by an evaluation at the new point (no unverified last step); the pass that
+                           confirms convergence costs kinematics + value only.                                          */
   int32_t tail_passes;  /* sixteen-lane kernel, plain LARGE batches (>= 16 384 frames of a single-component model): the main launch
                            stops every frame after this many passes; the few per cent still unfinished are listed on the device
                            and handed to a second launch in the one-frame-per-wave shape with the ladder above -- a launch is
