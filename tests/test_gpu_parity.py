@@ -1080,6 +1080,31 @@ def test_longest_first_ordering_changes_the_schedule_not_the_answers():
             assert np.array_equal(q, out[0][0][0]) and np.array_equal(st, out[0][0][1]) and np.array_equal(it, out[0][0][2])
 
 
+@pytest.mark.parametrize("tag", ["panda_1849", "leap_dexpilot_419", "leap_dexpilot_1041"])
+def test_round6_blind_step_frames_reach_their_minimum(tag):
+    """Regression fixtures of the three frames round 6's new gates caught (tests/golden/blind_step_frames.npz: inputs + the
+    float64 minimiser, which a tight scipy minimisation does not move): the unverified last step ended them 1.2e-4 (offline Panda,
+    ladder, 2 passes), 4.6e-4 (LEAP DexPilot, ladder, 5 passes) and 1.5e-3 rad (LEAP DexPilot, FOUR frames per wave: a held
+    joint's multiplier changed sign under the step) short.  Every launch shape must reach the minimum: B = 1 (one frame per wave +
+    ladder), the ladder off, and the same frame inside a batch of 2 049 (four frames per wave)."""
+    d = np.load(os.path.join(GOLD, "blind_step_frames.npz"))
+    rel = str(d[tag + "__rel"])
+    seq, prob = build(rel)
+    model = seq.optimizer.device_model()
+    ref, last, q_min = d[tag + "__ref"], d[tag + "__last"], d[tag + "__q_min"]
+    st0 = d[tag + "__state"].astype(np.uint32) if d[tag + "__state"].size else None
+    try:
+        for name, tk, reps in (("ladder", {}, 1), ("copies", dict(sprint_ladder=0), 1), ("four per wave", {}, 2049)):
+            model.tune(sprint_ladder=-1, sprint_max_batch=-1)
+            model.tune(**tk)
+            st = None if st0 is None else np.repeat(st0, reps)
+            q, info = model.retarget(np.repeat(ref, reps, 0), None, np.repeat(last, reps, 0), state=st, want_info=True)
+            assert (info["status"] == 0).all()
+            assert np.abs(q.astype(np.float64) - q_min).max() < 2e-5, (tag, name, np.abs(q.astype(np.float64) - q_min).max(), info["iters"][:3])
+    finally:
+        model.tune(sprint_ladder=-1, sprint_max_batch=-1)
+
+
 def test_sharded_fleet_with_the_mixed_fleet_adapter():
     """distributed.ShardedFleet's per-shard `solve` on the GPU is `mixed_fleet_solve(MixedFleet(...))` (host arrays,
     uint32 state words <-> device tensors, int32).  One rank (gloo, world size 1: all a 1-GPU box holds) -- shard, solve, all-gather,
