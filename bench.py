@@ -258,9 +258,22 @@ class Workload:
         per = np.array([evs[c].elapsed_time(evs[c + 1]) / chunk for c in range(n_chunks)])
         tenth = max(1, n_chunks // 10)
         steps = n_chunks * chunk
+        # the contract's own window -- 20 steps between two synchronizes -- on the chip as the long run leaves it, and again after
+        # 100 ms of idling: the difference between `ms_per_step` of the line and the sustained rate is the power state a short
+        # burst finds the chip in (tools probe, round 6: 39.2 us per step right after activity, 41.1 / 41.9 after 10 / 100 ms idle)
+        def window(idle_s):
+            torch.cuda.synchronize()
+            time.sleep(idle_s)
+            t1 = time.perf_counter()
+            for k2 in range(20):
+                self.launch(batches[k2 % len(batches)], self.t_q)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / 20 * 1e3
+        w_busy, w_idle = window(0.0), window(0.1)
         return {"steps": steps, "seconds": wall, "ms_per_step": float(evs[0].elapsed_time(evs[-1])) / steps, "wall_ms_per_step": wall / steps * 1e3,
                 "first_decile_ms_per_step": float(per[:tenth].mean()), "last_decile_ms_per_step": float(per[-tenth:].mean()),
                 "min_chunk_ms_per_step": float(per.min()), "max_chunk_ms_per_step": float(per.max()),
+                "window20_right_after_ms_per_step": w_busy, "window20_after_100ms_idle_ms_per_step": w_idle,
                 "value": self.B * steps / wall, "unit": "frames/s",
                 "note": f"{steps} consecutive launches ({n_chunks} chunks of {chunk} between HIP events), {len(batches)} staged batches rotating, single stream"}
 

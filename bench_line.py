@@ -147,7 +147,8 @@ def final_line(d):
     su = d.get("sustained")
     if isinstance(su, dict):
         out["sustained"] = {"error": str(su["error"])[:100]} if "error" in su else _pick(
-            su, ("steps", "seconds", "ms_per_step", "wall_ms_per_step", "first_decile_ms_per_step", "last_decile_ms_per_step", "vs_ms_per_step"))
+            su, ("steps", "seconds", "ms_per_step", "first_decile_ms_per_step", "last_decile_ms_per_step", "vs_ms_per_step",
+                 "window20_right_after_ms_per_step", "window20_after_100ms_idle_ms_per_step"))
     rs = d.get("reference_profile_script")
     if isinstance(rs, dict):
         rows = rs.get("rows") if isinstance(rs.get("rows"), list) else None
