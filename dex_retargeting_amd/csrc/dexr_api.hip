@@ -586,6 +586,9 @@ bool build_wide_tables(dexr_model* m) {
   return true;
 }
 
+#ifndef DEXR_GEN_LAM_JUMP
+#define DEXR_GEN_LAM_JUMP 0.03f  // (measured, 16 384 tracking frames: arm + hand 10.3 -> 7.2 passes, -11 % time; Shadow DexPilot on generic tables 9.8 -> 8.2, -15 %; LEAP position -3 %; larger jumps leave frames over-damped up to max_iter -- profiles/r06_general_kernel_damping_jump.txt)
+#endif
 int launch_gen_model(const dexr_model* m, int mode, dexr::KernelParams kp, hipStream_t st) {
   const size_t lds = dexr::gen_lds_bytes(m->gen_tab);
   if (lds > 160 * 1024) return fail(DEXR_ERR_UNSUPPORTED, "model needs %zu B of LDS per frame", lds);
@@ -602,6 +605,7 @@ int launch_gen_model(const dexr_model* m, int mode, dexr::KernelParams kp, hipSt
     kp.g64out = gprof;
   }
 #endif
+  kp.lam_jump = m->lam_jump_user >= 0.f ? m->lam_jump_user : DEXR_GEN_LAM_JUMP;  // (x mean diag of the free block, dexr_gen.hpp)
   hipError_t e = dexr::launch_gen(mode, kp, m->gen_tab, dim3((unsigned)blocks), lds, st);
   if (e != hipSuccess) return fail(DEXR_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e));
 #ifdef DEXR_GEN_PROF

@@ -80,7 +80,8 @@ __host__ __device__ inline size_t gen_lds_doubles(int nj, int nf, int nt, int nv
 #endif
 // The 8 x 8 lane grid holds NI x NI tiles: NI = 5 serves up to 40 variables (15 entries of the lower triangle per lane, the
 // factorisation's 40 rows in registers, two waves per SIMD), NI = 8 up to 64 (36 entries, one wave per SIMD)
-constexpr int GEN_NI_SMALL = 5, GEN_NI_BIG = 8;
+constexpr int GEN_NI_TINY = 3, GEN_NI_SMALL = 5, GEN_NI_BIG = 8;  // (TINY, round 6: models of <= 24 variables -- the hands' own configs on
+                                                                   // generic tables, the all-float64 path of the sixteen-lane family)
 
 typedef double gen_d2 __attribute__((ext_vector_type(2)));
 
@@ -263,7 +264,7 @@ __device__ __noinline__ bool gen_factor_solve(int lane, int nv, unsigned aH, uns
 }
 
 template <int MODE, int NI>
-__global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kernel(KernelParams kp, GenTab tb) {
+__global__ void __launch_bounds__(64, NI <= GEN_NI_SMALL ? 2 : 1) dexr_gen_kernel(KernelParams kp, GenTab tb) {
   extern __shared__ __align__(16) double gen_lds[];
   constexpr int NSLOT = NI * (NI + 1) / 2;  // entries of the lower triangle a lane of the grid owns: tiles (i, j), j <= i
   constexpr int NV = NI * 8;                // rows the register factorisation holds
@@ -839,7 +840,10 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
           gen_sync();
         };
         auto with_rows = [&](auto POS) {
-          if constexpr (NI == GEN_NI_SMALL) {
+          if constexpr (NI == GEN_NI_TINY) {
+            if (nv <= 16) model(POS, std::integral_constant<int, 2>{});
+            else model(POS, std::integral_constant<int, 3>{});
+          } else if constexpr (NI == GEN_NI_SMALL) {
             if (nv <= 16) model(POS, std::integral_constant<int, 2>{});
             else if (nv <= 32) model(POS, std::integral_constant<int, 4>{});
             else model(POS, std::integral_constant<int, 5>{});
@@ -1034,6 +1038,20 @@ __global__ void __launch_bounds__(64, NI == GEN_NI_SMALL ? 2 : 1) dexr_gen_kerne
         } else {
           lam *= nu;
           nu *= 2.0;
+          if (kp.lam_jump > 0.f) {
+            // (round 6) go straight to a damping that matters next to the curvature -- the rule of every other family (lam_jump x
+            // mean diagonal of the free block): creeping up from lambda0 = 1e-4 by x 2, x 4, x 8 ... an indefinite Newton model
+            // took ten failed factorisations (each 40 % of a pass) to reach 1e-1; Shadow DexPilot on these tables needed 9.8
+            // passes per frame where the sixteen-lane kernel needs 4.8
+            double hd = 0.0, nf_ = 0.0;
+            if (is_v && act[lane] == 0.0) {
+              hd = H[GEN_TRI(lane, lane)];
+              nf_ = 1.0;
+            }
+            hd = gen_wave_sum(hd);
+            nf_ = gen_wave_sum(nf_);
+            lam = fmax(lam, (double)kp.lam_jump * hd / fmax(nf_, 1.0));
+          }
           if (lam > 1e12) {
             status = ST_CONVERGED;  // no descent direction left at any damping: x is stationary to rounding
             break;

@@ -18,6 +18,9 @@ hipError_t launch_gen(int mode, const KernelParams& kp, const GenTab& tb, dim3 g
   // the lower triangle of the Hessian is tiled over an 8 x 8 lane grid, NI x NI tiles per lane: NI = 5 serves models of up to
   // 40 variables at 2 waves per SIMD, the NI = 8 instantiation the rest (up to 64 variables)
   const bool small = tb.nv <= 8 * GEN_NI_SMALL;
+  // (round 6) <= 24 variables: the NI = 3 instantiation of the solve -- 24 instead of 40 register rows in the factorisation, 6 instead
+  // of 15 accumulator slots per lane
+  if (mode == MODE_SOLVE && tb.nv <= 8 * GEN_NI_TINY) return launch_gen_mode<MODE_SOLVE, GEN_NI_TINY>(kp, tb, grid, lds, st);
   if (mode == MODE_SOLVE) return small ? launch_gen_mode<MODE_SOLVE, GEN_NI_SMALL>(kp, tb, grid, lds, st) : launch_gen_mode<MODE_SOLVE, GEN_NI_BIG>(kp, tb, grid, lds, st);
   if (mode == MODE_EVAL) return small ? launch_gen_mode<MODE_EVAL, GEN_NI_SMALL>(kp, tb, grid, lds, st) : launch_gen_mode<MODE_EVAL, GEN_NI_BIG>(kp, tb, grid, lds, st);
   return launch_gen_mode<MODE_FK, GEN_NI_SMALL>(kp, tb, grid, lds, st);
