@@ -441,3 +441,36 @@ def test_add_dummy_joint_like_the_reference(robot_name):
     assert robot.dof == dof0 + 6
     assert r1.joint_limits.shape == (act0 + 6, 2)
     assert all("dummy" in n for n in robot.dof_joint_names[:6])
+
+
+def test_sincos_table_of_the_sixteen_lane_kernel_is_exact_and_the_scheme_accurate():
+    """csrc/dexr_math.hpp sincos_f64_tab (round 6): the 32 table rows are the correctly rounded (sin, cos)(k pi / 16), and the
+    scheme -- k = rint(16 a / pi), two-constant Cody-Waite remainder, degree-9 / -10 Taylor sums, angle-sum recombination --
+    restated here in numpy float64 with the header's own constants stays within 2.5e-16 of numpy's sin / cos on float32-valued
+    angles (what the kernel feeds it: joint values are float32)."""
+    import re
+
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dex_retargeting_amd", "csrc", "dexr_math.hpp")).read()
+    body = src[src.index("SINCOS_TAB16[32][2] = {"):]
+    body = body[:body.index("};")]
+    rows = re.findall(r"\{\s*([-+0-9.eE]+),\s*([-+0-9.eE]+)\}", body)
+    assert len(rows) == 32
+    tab = np.array(rows, dtype=np.float64)
+    k = np.arange(32)
+    # exact multiples of pi/2 are exact in the table; everywhere else within 1 ulp of numpy's value at the rounded argument
+    assert np.abs(tab[:, 0] - np.sin(k * np.pi / 16)).max() < 7e-16 and np.abs(tab[:, 1] - np.cos(k * np.pi / 16)).max() < 7e-16
+    assert tab[0, 0] == 0.0 and tab[8, 1] == 0.0 and tab[16, 0] == 0.0 and tab[24, 1] == 0.0 and tab[8, 0] == 1.0 and tab[16, 1] == -1.0
+    fn = src[src.index("static __device__ __forceinline__ void sincos_f64_tab"):]
+    inv, hi, lo = (float(x) for x in (re.search(r"a \* ([0-9.eE+-]+)\)", fn).group(1), re.search(r"fma\(-kf, ([0-9.eE+-]+), a\)", fn).group(1),
+                                      re.search(r"fma\(-kf, ([0-9.eE+-]+), r\)", fn).group(1)))
+    assert abs(inv - 16 / np.pi) < 1e-15 and abs(hi + lo - np.pi / 16) < 1e-17
+    a = np.random.default_rng(0).uniform(-8, 8, 200000).astype(np.float32).astype(np.float64)
+    kf = np.rint(a * inv)
+    r = (a - kf * hi) - kf * lo
+    kk = kf.astype(np.int64) & 31
+    S, C = tab[kk, 0], tab[kk, 1]
+    z = r * r
+    sr = r + r * z * (-1.6666666666666666e-01 + z * (8.333333333333333e-03 + z * (-1.984126984126984e-04 + z * 2.7557319223985893e-06)))
+    cm = z * (-0.5 + z * (4.1666666666666664e-02 + z * (-1.388888888888889e-03 + z * (2.48015873015873e-05 + z * -2.755731922398589e-07))))
+    s_, c_ = S + (S * cm + C * sr), C + (C * cm - S * sr)
+    assert np.abs(s_ - np.sin(a)).max() < 2.5e-16 and np.abs(c_ - np.cos(a)).max() < 2.5e-16
