@@ -37,6 +37,11 @@ class _OptHandle:
         self.ftol_abs = None
 
     def last_optimum_value(self):
+        p = getattr(self, "_pending", None)
+        if p is not None:
+            delta, q, last, fval = p
+            self._last = float(fval[0]) - delta * float(((q.astype(np.float64) - last.astype(np.float64)) ** 2).sum())
+            self._pending = None
         return self._last
 
     def set_ftol_abs(self, v):
@@ -222,8 +227,9 @@ class Optimizer:
         # nlopt's last_optimum_value() is the closure's return value, i.e. the data term WITHOUT the regulariser
         # (optimizer.py:198,304,575; printed by SeqRetargeting.verbose as "Last distance"); the kernels report
         # F = f + norm_delta |x - last|^2
-        reg = float(self.norm_delta) * float(((q[0].astype(np.float64) - last[0].astype(np.float64)) ** 2).sum())
-        self.opt._last = float(self.last_info["fval"][0]) - reg
+        # (formed when somebody asks -- SeqRetargeting.verbose() -- not on every frame: three float64 numpy operations per call
+        # of the one-frame-per-call loop)
+        self.opt._pending = (float(self.norm_delta), q[0], last[0], self.last_info["fval"])
         return q[0]
 
     def get_objective_function(self, ref_value: np.ndarray, fixed_qpos: np.ndarray, last_qpos: np.ndarray):
