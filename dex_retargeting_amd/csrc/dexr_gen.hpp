@@ -264,7 +264,10 @@ __device__ __noinline__ bool gen_factor_solve(int lane, int nv, unsigned aH, uns
 }
 
 template <int MODE, int NI>
-__global__ void __launch_bounds__(64, NI <= GEN_NI_SMALL ? 2 : 1) dexr_gen_kernel(KernelParams kp, GenTab tb) {
+#ifndef DEXR_GEN_SMALL_MINW
+#define DEXR_GEN_SMALL_MINW 2
+#endif
+__global__ void __launch_bounds__(64, NI <= GEN_NI_TINY ? 2 : (NI == GEN_NI_SMALL ? DEXR_GEN_SMALL_MINW : 1)) dexr_gen_kernel(KernelParams kp, GenTab tb) {
   extern __shared__ __align__(16) double gen_lds[];
   constexpr int NSLOT = NI * (NI + 1) / 2;  // entries of the lower triangle a lane of the grid owns: tiles (i, j), j <= i
   constexpr int NV = NI * 8;                // rows the register factorisation holds

@@ -754,7 +754,8 @@ def test_mixed_fleet_equals_per_model_calls(B):
                                  "offline/leap_hand_right.yml",            # sixteen-lane kernel, free joints, alpha = 1
                                  "teleop/shadow_hand_right.yml",           # sixteen-lane kernel, vector objective
                                  "offline/shadow_hand_right.yml",          # sixteen-lane kernel, 30 joints (32-row grid)
-                                 "teleop/inspire_hand_right_dexpilot.yml"])  # sixteen-lane kernel on the variable grid (mimic)
+                                 "teleop/inspire_hand_right_dexpilot.yml",  # sixteen-lane kernel on the variable grid (mimic)
+                                 "teleop/schunk_svh_hand_right.yml"])      # reduced-variable model: <= 16 384 sequences -> sixteen-lane kernel, two components
 def test_fused_sequence_kernel_equals_frame_by_frame(rel):
     """dexr_retarget_seq_dev + dexr_seq_compose_dev (two launches for T x B frames, every lane looping over its
     sequence's frames inside the kernel) == DeviceSeqRetargeting.retarget called T times (one solve launch + torch
@@ -996,6 +997,37 @@ def test_sixteen_lane_and_four_lane_kernels_agree(rel):
     dq = np.abs(qw.astype(np.float64) - qq).max(1)
     assert (dq > 1e-4).mean() < 0.01, (dq > 1e-4).sum()
     assert np.percentile(dq, 95) < 2e-5, np.percentile(dq, [50, 95, 99])
+
+
+def test_small_fleet_with_a_reduced_kernel_model_equals_per_model_calls():
+    """Round 6: batches of <= 16 384 frames of a model the policy gives to the reduced-variable kernel (SVH vector) take the
+    sixteen-lane kernel -- also as a bucket of a fleet batch (index list + bucket size on the device) next to a per-finger model.
+    Fleet call == per-model calls, bitwise (both sides below the threshold: the same kernel, the same arithmetic per frame);
+    above the threshold both sides run the reduced-variable kernel: bitwise again."""
+    torch = pytest.importorskip("torch")
+    from dex_retargeting_amd.fleet import MixedFleet
+
+    rels = ["teleop/schunk_svh_hand_right.yml", "teleop/allegro_hand_right.yml"]
+    builds = [build(r) for r in rels]
+    opts = [b[0].optimizer for b in builds]
+    fleet = MixedFleet(opts)
+    for B in (3000, 40000):
+        rng = np.random.default_rng(8)
+        mid = rng.integers(0, 2, B)
+        if B > 16384:
+            mid[:] = 0
+            mid[::7] = 1  # > 16 384 SVH frames in the per-model call as well
+        kp = cases.human_keypoints(B, seed=10)
+        last = np.zeros((B, fleet.n_max), np.float32)
+        for m, (seq, prob) in enumerate(builds):
+            last[mid == m, : prob.n_opt] = prob.joint_limits.mean(1).astype(np.float32)
+        out = fleet.retarget(torch.from_numpy(mid).cuda(), torch.from_numpy(kp).cuda(), torch.from_numpy(last).cuda(), None)
+        torch.cuda.synchronize()
+        out = out.cpu().numpy()
+        for m, (seq, prob) in enumerate(builds):
+            sel = mid == m
+            want = opts[m].retarget_keypoints_batch(kp[sel], None, last[sel][:, : prob.n_opt])
+            assert np.array_equal(out[sel][:, : prob.n_opt], want), (B, rels[m], np.abs(out[sel][:, : prob.n_opt] - want).max())
 
 
 def test_kernel_policy_for_models_with_mimic_joints():
