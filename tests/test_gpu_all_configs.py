@@ -192,6 +192,61 @@ def test_baseline_configs_at_full_batch_size_frame_by_frame(rel, table_full):
     _check_certified(rel, table_full[rel])
 
 
+FLEET_RELS = ["teleop/allegro_hand_right.yml", "teleop/shadow_hand_right_dexpilot.yml", "teleop/leap_hand_right.yml",
+              "teleop/ability_hand_right.yml"]  # BASELINE.json configs[4]: 4 URDFs in one batch (bench.py FLEET)
+FLEET_FULL_CEILINGS = {"far": 1, "worse": 1}  # measured (round 6): 1 Ability vector frame of 131 072 in another (worse, certified) minimum
+
+
+def test_mixed_fleet_at_full_per_gpu_size_frame_by_frame(require_gpu):
+    """BASELINE.json configs[4] at its per-GPU size -- 131 072 frames of four robots interleaved in ONE dexr_retarget_multi_dev
+    call (tracking workload: warm start = the fleet's own answer for the previous frame) -- against the oracle frame by frame,
+    every model's rows with that model's oracle: within 1e-4 rad, or certified elsewhere and counted."""
+    torch = pytest.importorskip("torch")
+    from dex_retargeting_amd.fleet import MixedFleet
+
+    B = 131072
+    seqs = [RetargetingConfig.load_from_file(os.path.join(cases.CONFIG_DIR, r)).build() for r in FLEET_RELS]
+    probs = [cases.problem_from_config(r) for r in FLEET_RELS]
+    fleet = MixedFleet([q.optimizer for q in seqs])
+    mid = np.random.default_rng(cases.SEED + 5).integers(0, len(FLEET_RELS), B).astype(np.int32)
+    kp = cases.human_keypoints(B + 1, seed=cases.SEED + 5)
+    start = np.zeros((B, fleet.n_max), np.float32)
+    for m, pr in enumerate(probs):
+        start[mid == m, : pr.n_opt] = pr.joint_limits.mean(1).astype(np.float32)
+    t_mid = torch.from_numpy(mid).cuda()
+    st = torch.zeros(B, dtype=torch.int32, device="cuda")
+    t_last = fleet.retarget(t_mid, torch.from_numpy(np.ascontiguousarray(kp[:-1])).cuda(), torch.from_numpy(start).cuda(), st).clone()
+    st_in = st.cpu().numpy().view(np.uint32).copy()
+    q = fleet.retarget(t_mid, torch.from_numpy(np.ascontiguousarray(kp[1:])).cuda(), t_last, st).cpu().numpy()
+    last = t_last.cpu().numpy()
+    far_total = worse_total = 0
+    lines = []
+    with _pool() as ex:
+        for m, (rel, pr) in enumerate(zip(FLEET_RELS, probs)):
+            idx = np.nonzero(mid == m)[0]
+            ref = np.ascontiguousarray(cases.ref_from_keypoints(pr, kp[1:][idx]), dtype=np.float32)
+            la = np.ascontiguousarray(last[idx][:, : pr.n_opt])
+            got = q[idx][:, : pr.n_opt].astype(np.float64)
+            s_in = st_in[idx] if pr.kind == "dexpilot" else None
+            o = oracle_jobs.pooled_oracle_solve(rel, ref, la, s_in, got, chunk=512, pool=ex)
+            dq = np.abs(got - o["want"]).max(1)
+            far = dq >= TOL
+            worse = far & (o["F_gpu"] > o["F_want"] + 1e-10)
+            assert np.percentile(dq[~far], 99.9) < TOL and np.all(q[idx][:, pr.n_opt:] == 0)
+            if far.any():
+                sel = np.nonzero(far)[0][:64]
+                moved, dF = oracle_jobs.certify_local_minimum((rel, ref[sel], la[sel], None if s_in is None else s_in[sel], got[sel]))
+                assert np.all(moved < TOL) and np.all(dF < 1e-7), (rel, moved.max(), dF.max())
+            far_total += int(far.sum())
+            worse_total += int(worse.sum())
+            lines.append(f"{rel:44s} frames {len(idx):6d}  p50 dq {np.median(dq):.1e}  max dq (same minimum) {dq[~far].max():.1e}  >=1e-4 {int(far.sum())}  worse {int(worse.sum())}")
+    out = os.path.join(REPO, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "fleet_full_size_parity.txt"), "w") as f:
+        f.write(f"# mixed fleet, {B} frames in one dexr_retarget_multi_dev call, library defaults, every frame against its model's oracle\n" + "\n".join(lines) + "\n")
+    assert far_total <= FLEET_FULL_CEILINGS["far"] and worse_total <= FLEET_FULL_CEILINGS["worse"], (far_total, worse_total, lines)
+
+
 @pytest.mark.parametrize("rel", ALL)
 def test_default_options_meet_1e4_rad_against_oracle(rel, table):
     _check_row(rel, table[rel], CEILINGS[rel])
